@@ -1,0 +1,300 @@
+// agt_api.hip -- C ABI (include/agt_hip.h) over the gfx950 kernels: context, pyramid slots,
+// argument checking, launches.  No host<->device copies and no synchronisation on the
+// per-frame path; everything is enqueued on the context's stream.
+#include "agt_kernels.h"
+#include <new>
+#include <string.h>
+
+struct agt_ctx {
+    agt_config cfg;
+    hipStream_t stream;
+    int last_hip;
+    int eff_max_level;                       // after OpenCV's early stop
+    int lw[AGT_MAX_LEVELS], lh[AGT_MAX_LEVELS];
+    long lpitch[AGT_MAX_LEVELS];             // levels >= 1 (context-owned)
+    uint8_t* lmem[2][AGT_MAX_LEVELS];
+    const uint8_t* l0_ptr[2];
+    long l0_pitch[2], l0_bstride[2];
+    int built_B[2];
+    // tracker
+    float* corners[2];                       // ping-pong [B][n][2]
+    uint8_t* status;                         // [B][n]
+    float* lkerr;                            // [B][n]
+    float* obj;                              // [n][3]
+    double* pose;                            // [B][6]
+    AgtTrackState* tstate;                   // [B]
+    AgtCameraHost cam;
+    int trk_n, trk_B, trk_slot, trk_cur, enhance_ape, trk_ready;
+};
+
+namespace {
+
+int g_last_hip = 0;      // last failing HIP call made without a context (agt_create)
+
+int hip_fail(agt_ctx* c, hipError_t e)
+{
+    if (c) c->last_hip = (int)e;
+    g_last_hip = (int)e;
+    (void)hipGetLastError();   // clear the sticky error so later launches are not blamed
+    return AGT_ERR_HIP;
+}
+
+int fill_camera(const double* K, const double* dist, int ndist, AgtCameraHost* cam)
+{
+    if (!K) return AGT_ERR_ARG;
+    if (!(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12)) return AGT_ERR_DIST;
+    if (ndist > 0 && !dist) return AGT_ERR_ARG;
+    cam->fx = K[0]; cam->fy = K[4]; cam->cx = K[2]; cam->cy = K[5];
+    for (int i = 0; i < 12; i++) cam->k[i] = i < ndist ? dist[i] : 0.0;
+    return AGT_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int agt_version(void) { return AGT_VERSION; }
+
+const char* agt_error_string(int code)
+{
+    switch (code) {
+    case AGT_OK: return "ok";
+    case AGT_ERR_ARG: return "invalid argument";
+    case AGT_ERR_ALLOC: return "allocation failed";
+    case AGT_ERR_DIST: return "unsupported distortion coefficient count";
+    case AGT_ERR_NPOINTS: return "bad point count";
+    case AGT_ERR_HIP: return "HIP runtime error";
+    case AGT_ERR_UNSUPPORTED: return "unsupported configuration";
+    case AGT_ERR_STATE: return "bad context state";
+    default: return "unknown error";
+    }
+}
+
+int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
+{
+    if (!cfg || !out) return AGT_ERR_ARG;
+    *out = nullptr;
+    if (cfg->width <= 0 || cfg->height <= 0 || cfg->max_level < 0 || cfg->max_level >= AGT_MAX_LEVELS) return AGT_ERR_ARG;
+    if (cfg->max_points <= 0 || cfg->max_points > 256) return AGT_ERR_NPOINTS;
+    if (cfg->max_streams <= 0) return AGT_ERR_ARG;
+    if (!agt_lk_window_supported(cfg->win)) return AGT_ERR_UNSUPPORTED;
+    for (int i = 0; i < 8; i++) if (cfg->reserved[i] != 0) return AGT_ERR_ARG;
+    hipError_t e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return hip_fail(nullptr, e);
+    agt_ctx* c = new (std::nothrow) agt_ctx;
+    if (!c) return AGT_ERR_ALLOC;
+    memset(c, 0, sizeof(*c));
+    c->cfg = *cfg;
+    c->stream = (hipStream_t)hip_stream;
+    // buildOpticalFlowPyramid level geometry + early stop
+    int w = cfg->width, h = cfg->height;
+    for (int l = 0; l <= cfg->max_level; l++) {
+        c->lw[l] = w; c->lh[l] = h;
+        c->lpitch[l] = ((long)w + 63) & ~63L;
+        c->eff_max_level = l;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        if (w <= cfg->win || h <= cfg->win) break;
+    }
+    const size_t B = (size_t)cfg->max_streams, N = (size_t)cfg->max_points;
+    bool ok = true;
+    for (int s = 0; s < 2 && ok; s++)
+        for (int l = 1; l <= c->eff_max_level && ok; l++)
+            ok = hipMalloc((void**)&c->lmem[s][l], B * (size_t)c->lh[l] * (size_t)c->lpitch[l]) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->corners[0], B * N * 2 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->corners[1], B * N * 2 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->status, B * N) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->lkerr, B * N * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->obj, N * 3 * sizeof(float)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
+    if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
+    c->built_B[0] = c->built_B[1] = 0;
+    *out = c;
+    return AGT_OK;
+}
+
+int agt_destroy(agt_ctx* c)
+{
+    if (!c) return AGT_OK;
+    for (int s = 0; s < 2; s++)
+        for (int l = 1; l < AGT_MAX_LEVELS; l++) if (c->lmem[s][l]) (void)hipFree(c->lmem[s][l]);
+    if (c->corners[0]) (void)hipFree(c->corners[0]);
+    if (c->corners[1]) (void)hipFree(c->corners[1]);
+    if (c->status) (void)hipFree(c->status);
+    if (c->lkerr) (void)hipFree(c->lkerr);
+    if (c->obj) (void)hipFree(c->obj);
+    if (c->pose) (void)hipFree(c->pose);
+    if (c->tstate) (void)hipFree(c->tstate);
+    delete c;
+    return AGT_OK;
+}
+
+int agt_set_stream(agt_ctx* c, void* hip_stream)
+{
+    if (!c) return AGT_ERR_ARG;
+    c->stream = (hipStream_t)hip_stream;
+    return AGT_OK;
+}
+
+int agt_last_hip_error(const agt_ctx* c) { return c ? c->last_hip : g_last_hip; }
+
+int agt_synchronize(agt_ctx* c)
+{
+    if (!c) return AGT_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_pyr_down_u8(agt_ctx* c, const uint8_t* d_src, int sw, int sh, size_t spitch, size_t sbatch,
+                    uint8_t* d_dst, size_t dpitch, size_t dbatch, int B)
+{
+    if (!c || !d_src || !d_dst || sw <= 0 || sh <= 0 || B <= 0) return AGT_ERR_ARG;
+    if ((spitch & 3) || (dpitch & 3) || ((uintptr_t)d_src & 3) || ((uintptr_t)d_dst & 3) || (sbatch & 3) || (dbatch & 3)) return AGT_ERR_ARG;
+    if (spitch < (size_t)sw || dpitch < (size_t)((sw + 1) / 2)) return AGT_ERR_ARG;
+    hipError_t e = agt_launch_pyr_down(c->stream, d_src, sw, sh, (long)spitch, (long)sbatch, d_dst, (long)dpitch, (long)dbatch, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
+{
+    if (!c || !d_frames || slot < 0 || slot > 1 || B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
+    if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
+    c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
+    const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
+    for (int l = 1; l <= c->eff_max_level; l++) {
+        const long db = (long)c->lh[l] * c->lpitch[l];
+        hipError_t e = agt_launch_pyr_down(c->stream, src, c->lw[l - 1], c->lh[l - 1], sp, sb, c->lmem[slot][l], c->lpitch[l], db, B);
+        if (e != hipSuccess) return hip_fail(c, e);
+        src = c->lmem[slot][l]; sp = c->lpitch[l]; sb = db;
+    }
+    c->built_B[slot] = B;
+    return AGT_OK;
+}
+
+int agt_pyramid_max_level(const agt_ctx* c) { return c ? c->eff_max_level : AGT_ERR_ARG; }
+
+int agt_pyramid_level(const agt_ctx* c, int slot, int level, const uint8_t** d_ptr,
+                      int* w, int* h, size_t* pitch, size_t* batch_stride)
+{
+    if (!c || slot < 0 || slot > 1 || level < 0 || level > c->eff_max_level) return AGT_ERR_ARG;
+    if (c->built_B[slot] <= 0) return AGT_ERR_STATE;
+    if (d_ptr) *d_ptr = level == 0 ? c->l0_ptr[slot] : c->lmem[slot][level];
+    if (w) *w = c->lw[level];
+    if (h) *h = c->lh[level];
+    if (pitch) *pitch = (size_t)(level == 0 ? c->l0_pitch[slot] : c->lpitch[level]);
+    if (batch_stride) *batch_stride = (size_t)(level == 0 ? c->l0_bstride[slot] : (long)c->lh[level] * c->lpitch[level]);
+    return AGT_OK;
+}
+
+static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
+{
+    for (int l = 0; l <= c->eff_max_level; l++) {
+        L[l].w = c->lw[l]; L[l].h = c->lh[l];
+        if (l == 0) { L[l].ptr = c->l0_ptr[slot]; L[l].pitch = c->l0_pitch[slot]; L[l].bstride = c->l0_bstride[slot]; }
+        else { L[l].ptr = c->lmem[slot][l]; L[l].pitch = c->lpitch[l]; L[l].bstride = (long)c->lh[l] * c->lpitch[l]; }
+    }
+}
+
+int agt_lk_track(agt_ctx* c, int prev_slot, int next_slot,
+                 const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                 int n, int B, int crit_type, int crit_max_count, double crit_eps,
+                 int flags, double min_eig_threshold)
+{
+    if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
+    if (prev_slot < 0 || prev_slot > 1 || next_slot < 0 || next_slot > 1) return AGT_ERR_ARG;
+    if (n < 0 || B <= 0) return AGT_ERR_ARG;
+    if (n == 0) return AGT_OK;
+    if (c->built_B[prev_slot] < B || c->built_B[next_slot] < B) return AGT_ERR_STATE;
+    AgtLkParams p;
+    memset(&p, 0, sizeof(p));
+    fill_levels(c, prev_slot, p.prev);
+    fill_levels(c, next_slot, p.next);
+    p.max_level = c->eff_max_level;
+    p.n = n;
+    // SparsePyrLKOpticalFlowImpl::calc criteria normalisation
+    p.max_count = (crit_type & AGT_TERM_COUNT) ? (crit_max_count < 0 ? 0 : crit_max_count > 100 ? 100 : crit_max_count) : 30;
+    double eps = (crit_type & AGT_TERM_EPS) ? (crit_eps < 0. ? 0. : crit_eps > 10. ? 10. : crit_eps) : 0.01;
+    p.eps2 = eps * eps;
+    p.flags = flags;
+    p.min_eig_threshold = min_eig_threshold;
+    p.prev_pts = d_prev_pts; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
+    hipError_t e = agt_launch_lk(c->stream, p, c->cfg.win, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_solve_pnp(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, const void* d_img, int dtype,
+                  const uint8_t* d_mask, int n, int B,
+                  const double* K, const double* dist, int ndist,
+                  double* d_pose, int use_guess, int32_t* d_info, double* d_err)
+{
+    if (!c || !d_obj || !d_img || !d_pose || B <= 0) return AGT_ERR_ARG;
+    if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
+    if (n < 3 || n > 256) return AGT_ERR_NPOINTS;
+    if (!use_guess && n < 4) return AGT_ERR_NPOINTS;
+    AgtPnpParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = fill_camera(K, dist, ndist, &p.cam);
+    if (rc) return rc;
+    p.obj = d_obj; p.obj_bstride = (long)obj_batch_stride; p.img = d_img; p.mask = d_mask; p.dtype = dtype;
+    p.n = n; p.use_guess = use_guess ? 1 : 0; p.pose = d_pose; p.info = d_info; p.err = d_err;
+    p.gate_px = 2.0;
+    hipError_t e = agt_launch_pnp(c->stream, p, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_project_points(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, int dtype, int n, int B,
+                       const double* d_pose, const double* K, const double* dist, int ndist,
+                       void* d_img_out, double* d_jac)
+{
+    if (!c || !d_obj || !d_pose || !d_img_out || n <= 0 || B <= 0) return AGT_ERR_ARG;
+    if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
+    AgtProjParams p;
+    memset(&p, 0, sizeof(p));
+    int rc = fill_camera(K, dist, ndist, &p.cam);
+    if (rc) return rc;
+    p.obj = d_obj; p.obj_bstride = (long)obj_batch_stride; p.dtype = dtype; p.n = n; p.pose = d_pose;
+    p.img_out = d_img_out; p.jac = d_jac;
+    hipError_t e = agt_launch_project(c->stream, p, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float* d_obj, int n, int B,
+                      const double* K, const double* dist, int ndist, int enhance_ape)
+{
+    if (!c || !d_corners || !d_obj || slot < 0 || slot > 1) return AGT_ERR_ARG;
+    if (n < 4 || n > c->cfg.max_points) return AGT_ERR_NPOINTS;
+    if (B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
+    if (c->built_B[slot] < B) return AGT_ERR_STATE;
+    int rc = fill_camera(K, dist, ndist, &c->cam);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(c->corners[0], d_corners, (size_t)B * n * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->pose, 0, (size_t)B * 6 * sizeof(double), c->stream);
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->trk_n = n; c->trk_B = B; c->trk_slot = slot; c->trk_cur = 0; c->enhance_ape = enhance_ape ? 1 : 0; c->trk_ready = 1;
+    return AGT_OK;
+}
+
+int agt_tracker_set_pose(agt_ctx* c, const double* d_pose, int B)
+{
+    (void)c; (void)d_pose; (void)B;
+    return AGT_ERR_UNSUPPORTED;
+}
+
+int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                    double* d_state_out)
+{
+    (void)c; (void)d_frames; (void)pitch; (void)batch_stride; (void)B; (void)d_state_out;
+    return AGT_ERR_UNSUPPORTED;
+}
+
+int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t** d_status)
+{
+    if (!c || !c->trk_ready) return AGT_ERR_STATE;
+    if (d_corners) *d_corners = c->corners[c->trk_cur];
+    if (d_status) *d_status = c->status;
+    return AGT_OK;
+}
+
+}  // extern "C"

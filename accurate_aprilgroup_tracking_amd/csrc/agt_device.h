@@ -1,0 +1,337 @@
+// agt_device.h -- device-side helpers shared by the gfx950 kernels.
+// Wave = 64 lanes everywhere (CDNA4); no 32-wide assumptions.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <float.h>
+
+#define AGT_WAVE 64
+
+// cv::borderInterpolate(p, len, BORDER_REFLECT_101); valid for any p
+__device__ __forceinline__ int agt_reflect101(int p, int len)
+{
+    if ((unsigned)p < (unsigned)len) return p;
+    if (len == 1) return 0;
+    do {
+        p = p < 0 ? -p : 2 * (len - 1) - p;
+    } while ((unsigned)p >= (unsigned)len);
+    return p;
+}
+
+// ---------------------------------------------------------------------------
+// DPP helpers: sum within a 16-lane row without touching LDS, then combine the
+// four rows through SGPRs (v_readlane) so the total is wave-uniform.
+template <int CTRL>
+__device__ __forceinline__ int agt_dpp_i32(int v)
+{
+    return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xf, 0xf, true);
+}
+
+__device__ __forceinline__ long long agt_dpp_add_i64_step(long long v, int lo, int hi)
+{
+    long long o = ((long long)hi << 32) | (unsigned int)lo;
+    return v + o;
+}
+
+#define AGT_DPP_STEP_I64(v, CTRL)                                            \
+    do {                                                                      \
+        int lo_ = agt_dpp_i32<CTRL>((int)(v));                                \
+        int hi_ = agt_dpp_i32<CTRL>((int)((v) >> 32));                        \
+        (v) = agt_dpp_add_i64_step((v), lo_, hi_);                            \
+    } while (0)
+
+// exact 64-lane integer sum; result identical (and uniform) in every lane
+__device__ __forceinline__ long long agt_wave_sum_i64(long long v)
+{
+    AGT_DPP_STEP_I64(v, 0xB1);   // quad_perm [1,0,3,2]
+    AGT_DPP_STEP_I64(v, 0x4E);   // quad_perm [2,3,0,1]
+    AGT_DPP_STEP_I64(v, 0x141);  // row_half_mirror
+    AGT_DPP_STEP_I64(v, 0x140);  // row_mirror  -> every lane holds its row's total
+    int lo = (int)v, hi = (int)(v >> 32);
+    long long t = 0;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        unsigned int l = (unsigned int)__builtin_amdgcn_readlane(lo, r * 16);
+        int h = __builtin_amdgcn_readlane(hi, r * 16);
+        t += ((long long)h << 32) | l;
+    }
+    return t;
+}
+
+// wave-uniform broadcast of lane 0's value (keeps loop control scalar)
+__device__ __forceinline__ int agt_uniform(int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ float agt_uniform(float v)
+{
+    return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v)));
+}
+
+// ---------------------------------------------------------------------------
+// FP64 geometry (OpenCV calibration.cpp semantics; see oracle/cv_pnp.c for the restatement)
+
+// cvRodrigues2 vector->matrix.  J (3x9, J[i*9+k] = dR[k]/dr[i]) only when JAC.
+template <bool JAC>
+__device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9], double J[27])
+{
+    double rx = r_in[0], ry = r_in[1], rz = r_in[2];
+    double theta = sqrt(rx * rx + ry * ry + rz * rz);
+    if (theta < DBL_EPSILON) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
+        if (JAC) {
+#pragma unroll
+            for (int i = 0; i < 27; i++) J[i] = 0.0;
+            J[5] = J[15] = J[19] = -1.0;
+            J[7] = J[11] = J[21] = 1.0;
+        }
+        return;
+    }
+    double s, c;
+    sincos(theta, &s, &c);
+    double c1 = 1.0 - c, itheta = 1.0 / theta;
+    rx *= itheta; ry *= itheta; rz *= itheta;
+    const double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
+    const double r_x[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
+#pragma unroll
+    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * r_x[k];
+    if (JAC) {
+        const double drrt[27] = { rx + rx, ry, rz, ry, 0, 0, rz, 0, 0,
+                                  0, rx, 0, rx, ry + ry, rz, 0, rz, 0,
+                                  0, 0, rx, 0, 0, ry, rx, ry, rz + rz };
+        const double d_r_x_[27] = { 0, 0, 0, 0, 0, -1, 0, 1, 0,
+                                    0, 0, 1, 0, 0, 0, -1, 0, 0,
+                                    0, -1, 0, 1, 0, 0, 0, 0, 0 };
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            double ri = i == 0 ? rx : i == 1 ? ry : rz;
+            double a0 = -s * ri, a1 = (s - 2 * c1 * itheta) * ri, a2 = c1 * itheta;
+            double a3 = (c - s * itheta) * ri, a4 = s * itheta;
+#pragma unroll
+            for (int k = 0; k < 9; k++)
+                J[i * 9 + k] = a0 * ((k % 4 == 0) ? 1.0 : 0.0) + a1 * rrt[k] + a2 * drrt[i * 9 + k] +
+                               a3 * r_x[k] + a4 * d_r_x_[i * 9 + k];
+        }
+    }
+}
+
+struct AgtCamera {
+    double fx, fy, cx, cy;
+    double k[12];     // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+};
+
+// cvProjectPoints2Internal for one point.  jr/jt: rows (du/d., dv/d.) x 3.
+template <bool JAC>
+__device__ __forceinline__ void agt_project(const AgtCamera& cam, const double R[9], const double dRdr[27],
+                                            const double t[3], double X, double Y, double Z,
+                                            double& u, double& v, double jr[6], double jt[6])
+{
+    const double* k = cam.k;
+    double x = R[0] * X + R[1] * Y + R[2] * Z + t[0];
+    double y = R[3] * X + R[4] * Y + R[5] * Z + t[1];
+    double z = R[6] * X + R[7] * Y + R[8] * Z + t[2];
+    z = z != 0.0 ? 1.0 / z : 1.0;
+    x *= z; y *= z;
+    double r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+    double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+    double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
+    double icdist2 = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
+    double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4;
+    double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4;
+    u = xd * cam.fx + cam.cx;
+    v = yd * cam.fy + cam.cy;
+    if (JAC) {
+        const double dxdt[3] = { z, 0, -x * z }, dydt[3] = { 0, z, -y * z };
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double dr2dt = 2 * x * dxdt[j] + 2 * y * dydt[j];
+            double dcdist_dt = k[0] * dr2dt + 2 * k[1] * r2 * dr2dt + 3 * k[4] * r4 * dr2dt;
+            double dicdist2_dt = -icdist2 * icdist2 * (k[5] * dr2dt + 2 * k[6] * r2 * dr2dt + 3 * k[7] * r4 * dr2dt);
+            double da1dt = 2 * (x * dydt[j] + y * dxdt[j]);
+            double dmxdt = (dxdt[j] * cdist * icdist2 + x * dcdist_dt * icdist2 + x * cdist * dicdist2_dt +
+                            k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]) + k[8] * dr2dt + 2 * r2 * k[9] * dr2dt);
+            double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + y * cdist * dicdist2_dt +
+                            k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt + k[10] * dr2dt + 2 * r2 * k[11] * dr2dt);
+            jt[j] = cam.fx * dmxdt;
+            jt[3 + j] = cam.fy * dmydt;
+        }
+        const double dx0dr[3] = { X * dRdr[0] + Y * dRdr[1] + Z * dRdr[2],
+                                  X * dRdr[9] + Y * dRdr[10] + Z * dRdr[11],
+                                  X * dRdr[18] + Y * dRdr[19] + Z * dRdr[20] };
+        const double dy0dr[3] = { X * dRdr[3] + Y * dRdr[4] + Z * dRdr[5],
+                                  X * dRdr[12] + Y * dRdr[13] + Z * dRdr[14],
+                                  X * dRdr[21] + Y * dRdr[22] + Z * dRdr[23] };
+        const double dz0dr[3] = { X * dRdr[6] + Y * dRdr[7] + Z * dRdr[8],
+                                  X * dRdr[15] + Y * dRdr[16] + Z * dRdr[17],
+                                  X * dRdr[24] + Y * dRdr[25] + Z * dRdr[26] };
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            double dxdr = z * (dx0dr[j] - x * dz0dr[j]);
+            double dydr = z * (dy0dr[j] - y * dz0dr[j]);
+            double dr2dr = 2 * x * dxdr + 2 * y * dydr;
+            double dcdist_dr = (k[0] + 2 * k[1] * r2 + 3 * k[4] * r4) * dr2dr;
+            double dicdist2_dr = -icdist2 * icdist2 * (k[5] + 2 * k[6] * r2 + 3 * k[7] * r4) * dr2dr;
+            double da1dr = 2 * (x * dydr + y * dxdr);
+            double dmxdr = (dxdr * cdist * icdist2 + x * dcdist_dr * icdist2 + x * cdist * dicdist2_dr +
+                            k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr) + (k[8] + 2 * r2 * k[9]) * dr2dr);
+            double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + y * cdist * dicdist2_dr +
+                            k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr + (k[10] + 2 * r2 * k[11]) * dr2dr);
+            jr[j] = cam.fx * dmxdr;
+            jr[3 + j] = cam.fy * dmydr;
+        }
+    }
+}
+
+// One-sided Jacobi SVD of a 3x3 (row-major A).  Outputs sorted descending; U columns = left
+// vectors, Vt rows = right vectors (the layout of oracle cvo_svd).
+__device__ inline void agt_svd3(const double A[9], double W[3], double U[9], double Vt[9])
+{
+    double At[3][3], V[3][3], w[3];
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        double sd = 0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { At[i][k] = A[k * 3 + i]; sd += At[i][k] * At[i][k]; V[i][k] = (i == k) ? 1.0 : 0.0; }
+        w[i] = sd;
+    }
+    const double eps = DBL_EPSILON * 2;
+    for (int iter = 0; iter < 30; iter++) {
+        bool changed = false;
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+#pragma unroll
+            for (int j = i + 1; j < 3; j++) {
+                double a = w[i], b = w[j];
+                double p = At[i][0] * At[j][0] + At[i][1] * At[j][1] + At[i][2] * At[j][2];
+                if (fabs(p) <= eps * sqrt(a * b)) continue;
+                p *= 2;
+                double beta = a - b, gamma = hypot(p, beta), c, s;
+                if (beta < 0) {
+                    double delta = (gamma - beta) * 0.5;
+                    s = sqrt(delta / gamma);
+                    c = p / (gamma * s * 2);
+                } else {
+                    c = sqrt((gamma + beta) / (gamma * 2));
+                    s = p / (gamma * c * 2);
+                }
+                a = b = 0;
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    double t0 = c * At[i][k] + s * At[j][k];
+                    double t1 = -s * At[i][k] + c * At[j][k];
+                    At[i][k] = t0; At[j][k] = t1;
+                    a += t0 * t0; b += t1 * t1;
+                    double v0 = c * V[i][k] + s * V[j][k];
+                    double v1 = -s * V[i][k] + c * V[j][k];
+                    V[i][k] = v0; V[j][k] = v1;
+                }
+                w[i] = a; w[j] = b;
+                changed = true;
+            }
+        if (!changed) break;
+    }
+#pragma unroll
+    for (int i = 0; i < 3; i++) w[i] = sqrt(At[i][0] * At[i][0] + At[i][1] * At[i][1] + At[i][2] * At[i][2]);
+    // sort descending (3 elements: fixed compare-exchange network, static indices)
+#define AGT_SVD3_CSWAP(i, j)                                                   \
+    if (w[i] < w[j]) {                                                         \
+        double t_ = w[i]; w[i] = w[j]; w[j] = t_;                              \
+        for (int k = 0; k < 3; k++) {                                          \
+            t_ = At[i][k]; At[i][k] = At[j][k]; At[j][k] = t_;                 \
+            t_ = V[i][k]; V[i][k] = V[j][k]; V[j][k] = t_;                     \
+        }                                                                      \
+    }
+    AGT_SVD3_CSWAP(0, 1) AGT_SVD3_CSWAP(0, 2) AGT_SVD3_CSWAP(1, 2)
+#undef AGT_SVD3_CSWAP
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        W[i] = w[i];
+        double s = w[i] > 0 ? 1.0 / w[i] : 0.0;
+#pragma unroll
+        for (int k = 0; k < 3; k++) { U[k * 3 + i] = At[i][k] * s; Vt[i * 3 + k] = V[i][k]; }
+    }
+}
+
+__device__ __forceinline__ void agt_mat3_mul(const double A[9], const double B[9], double C[9])
+{
+    double T[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) T[i * 3 + j] = A[i * 3] * B[j] + A[i * 3 + 1] * B[3 + j] + A[i * 3 + 2] * B[6 + j];
+#pragma unroll
+    for (int i = 0; i < 9; i++) C[i] = T[i];
+}
+
+__device__ __forceinline__ double agt_det3(const double M[9])
+{
+    return M[0] * (M[4] * M[8] - M[5] * M[7]) - M[1] * (M[3] * M[8] - M[5] * M[6]) + M[2] * (M[3] * M[7] - M[4] * M[6]);
+}
+
+// cvRodrigues2 matrix->vector (no Jacobian)
+__device__ inline void agt_rodrigues_inv(const double Rin[9], double r[3])
+{
+    double W[3], U[9], Vt[9], R[9];
+    agt_svd3(Rin, W, U, Vt);
+    agt_mat3_mul(U, Vt, R);
+    double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
+    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double c = (R[0] + R[4] + R[8] - 1) * 0.5;
+    c = c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c;
+    double theta = acos(c);
+    if (s < 1e-5) {
+        if (c > 0) rx = ry = rz = 0;
+        else {
+            double t;
+            t = (R[0] + 1) * 0.5; rx = sqrt(t > 0.0 ? t : 0.0);
+            t = (R[4] + 1) * 0.5; ry = sqrt(t > 0.0 ? t : 0.0) * (R[1] < 0 ? -1.0 : 1.0);
+            t = (R[8] + 1) * 0.5; rz = sqrt(t > 0.0 ? t : 0.0) * (R[2] < 0 ? -1.0 : 1.0);
+            if (fabs(rx) < fabs(ry) && fabs(rx) < fabs(rz) && (R[5] > 0) != (ry * rz > 0)) rz = -rz;
+            theta /= sqrt(rx * rx + ry * ry + rz * rz);
+            rx *= theta; ry *= theta; rz *= theta;
+        }
+    } else {
+        double vth = 1 / (2 * s);
+        vth *= theta;
+        rx *= vth; ry *= vth; rz *= vth;
+    }
+    r[0] = rx; r[1] = ry; r[2] = rz;
+}
+
+// Solve the damped 6x6 normal equations A x = b, A symmetric positive definite
+// (upper triangle used).  LDL^T, no square roots.  Returns false on a non-positive pivot.
+__device__ __forceinline__ bool agt_solve6(const double A[36], const double b[6], double x[6])
+{
+    double L[6][6], D[6];
+    bool ok = true;
+#pragma unroll
+    for (int j = 0; j < 6; j++) {
+        double d = A[j * 6 + j];
+#pragma unroll
+        for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
+        if (!(d > 0.0)) ok = false;
+        D[j] = d;
+        double id = 1.0 / d;
+#pragma unroll
+        for (int i = j + 1; i < 6; i++) {
+            double v = A[j * 6 + i];
+#pragma unroll
+            for (int k = 0; k < j; k++) v -= L[i][k] * L[j][k] * D[k];
+            L[i][j] = v * id;
+        }
+    }
+    double y[6];
+#pragma unroll
+    for (int i = 0; i < 6; i++) {
+        double v = b[i];
+#pragma unroll
+        for (int k = 0; k < i; k++) v -= L[i][k] * y[k];
+        y[i] = v;
+    }
+#pragma unroll
+    for (int i = 5; i >= 0; i--) {
+        double v = y[i] / D[i];
+#pragma unroll
+        for (int k = i + 1; k < 6; k++) v -= L[k][i] * x[k];
+        x[i] = v;
+    }
+    return ok;
+}

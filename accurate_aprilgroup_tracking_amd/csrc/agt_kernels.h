@@ -1,0 +1,81 @@
+// agt_kernels.h -- host-visible launch interface of the gfx950 kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/agt_hip.h"
+
+struct AgtLevel {
+    const uint8_t* ptr;   // level base for stream 0
+    long pitch;           // bytes per row (multiple of 4)
+    long bstride;         // bytes between streams
+    int w, h;
+};
+
+struct AgtLkParams {
+    AgtLevel prev[AGT_MAX_LEVELS];
+    AgtLevel next[AGT_MAX_LEVELS];
+    int max_level;            // effective (after OpenCV's early stop)
+    int n;                    // points per stream
+    int max_count;            // criteria, already clamped
+    double eps2;              // epsilon^2
+    int flags;
+    double min_eig_threshold;
+    const float* prev_pts;    // [B][n][2]
+    float* next_pts;          // [B][n][2]
+    uint8_t* status;          // [B][n]
+    float* err;               // [B][n] or null
+};
+
+struct AgtCameraHost {
+    double fx, fy, cx, cy;
+    double k[12];
+};
+
+struct AgtPnpParams {
+    const void* obj;          // n x 3, f32 or f64
+    long obj_bstride;         // elements between streams (0 = shared)
+    const void* img;          // [B][n][2]
+    const uint8_t* mask;      // [B][n] or null
+    int dtype;                // AGT_F32 / AGT_F64 (img and obj)
+    int img_f32_obj_f32;      // unused, keeps layout explicit
+    int n;
+    int use_guess;
+    AgtCameraHost cam;
+    double* pose;             // [B][6] in/out
+    int32_t* info;            // [B][4] or null
+    double* err;              // [B] or null
+    // tracker epilogue (null = plain solvePnP)
+    struct AgtTrackState* track;   // [B]
+    double* state_out;             // [B][AGT_STATE_STRIDE] or null
+    float* corners;                // [B][n][2] tracker corners to update in place (LK output) or null
+    int enhance_ape;
+    double gate_px;                // reprojection gate (2.0, detect_pose.py:539)
+};
+
+// device-resident per-stream tracker state: the attributes of PoseDetector
+// (detect_pose.py:74-83) that _estimate_pose mutates
+struct AgtTrackState {
+    double guess[6];        // extrinsic_guess (rvec, tvec)
+    double prev[6];         // prev_transform
+    double rot_vel[2][9];   // rot_velocities (oldest first)
+    double tran_vel[2][3];  // tran_velocities
+    int has_guess;
+    int has_prev;
+    int n_vel;
+    int frame;
+};
+
+struct AgtProjParams {
+    const void* obj; long obj_bstride; int dtype; int n;
+    const double* pose;       // [B][6]
+    AgtCameraHost cam;
+    void* img_out;            // [B][n][2]
+    double* jac;              // [B][2n][6] or null
+};
+
+hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
+                               uint8_t* dst, long dpitch, long dbatch, int B);
+hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B);
+hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B);
+hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
+bool agt_lk_window_supported(int win);

@@ -1,0 +1,268 @@
+"""cv2-shaped entry points backed by the gfx950 HIP library.
+
+The reference's hot path is Python calling four cv2 functions; this
+module offers the same four with the same argument meaning, return shapes and error
+behaviour, so `import accurate_aprilgroup_tracking_amd.cv_hip as cv` drops in for the
+calls at detect_pose.py:509-526 (solvePnP), transform_helper.py:106-111 (projectPoints),
+transform_helper.py:87 (Rodrigues) and the north-star calcOpticalFlowPyrLK.
+
+PyTorch-ROCm is used only as the device-buffer allocator / stream provider
+(tensor.data_ptr(), torch.cuda.current_stream().cuda_stream).  There is no CPU path:
+without the HIP library or a GPU these functions raise.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import hiplib as H
+from .host_math import Rodrigues  # noqa: F401  (host-side 3x3 algebra, as in the reference)
+
+SOLVEPNP_ITERATIVE = 0
+OPTFLOW_USE_INITIAL_FLOW = H.LK_USE_INITIAL_FLOW
+OPTFLOW_LK_GET_MIN_EIGENVALS = H.LK_GET_MIN_EIGENVALS
+TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS = H.TERM_COUNT, H.TERM_EPS
+
+
+class error(ValueError):
+    """stands in for cv2.error (argument / shape violations)"""
+
+
+def _require_gpu():
+    if not torch.cuda.is_available():
+        raise RuntimeError("accurate_aprilgroup_tracking_amd needs a ROCm GPU (no CPU fallback)")
+
+
+def _ptr(t):
+    return C.c_void_p(t.data_ptr()) if t is not None else None
+
+
+def _host_f64(a, n=None):
+    if a is None:
+        return None, 0
+    a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
+    return a, a.size
+
+
+class Context:
+    """One agt_ctx: pyramid slots + tracker state for B streams of W x H frames."""
+
+    def __init__(self, width, height, max_level=2, win=21, max_points=64, max_streams=1, device=None):
+        _require_gpu()
+        self.L = H.lib()
+        self.device = torch.cuda.current_device() if device is None else device
+        cfg = H.Config(self.device, width, height, max_level, win, max_points, max_streams)
+        self.h = C.c_void_p()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        H.check(self.L.agt_create(C.byref(cfg), C.c_void_p(stream), C.byref(self.h)), "agt_create")
+        self.width, self.height, self.max_level, self.win = width, height, max_level, win
+        self.max_points, self.max_streams = max_points, max_streams
+        self._keep = {}          # frames aliased by pyramid level 0 must stay alive
+
+    def close(self):
+        if getattr(self, "h", None) and self.h.value:
+            self.L.agt_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def use_current_stream(self):
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        H.check(self.L.agt_set_stream(self.h, C.c_void_p(stream)), "agt_set_stream")
+
+    def synchronize(self):
+        H.check(self.L.agt_synchronize(self.h), "agt_synchronize")
+
+    @property
+    def eff_max_level(self):
+        return self.L.agt_pyramid_max_level(self.h)
+
+    # ---- images
+    def pyr_down(self, src):
+        """src: cuda uint8 [B,H,W] (contiguous rows, W % 4 == 0) -> [B,(H+1)//2,(W+1)//2 padded to 4]"""
+        assert src.dtype == torch.uint8 and src.is_cuda and src.dim() == 3
+        B, h, w = src.shape
+        dw, dh = (w + 1) // 2, (h + 1) // 2
+        dp = (dw + 3) & ~3
+        dst = torch.empty((B, dh, dp), dtype=torch.uint8, device=src.device)
+        H.check(self.L.agt_pyr_down_u8(self.h, _ptr(src), w, h, src.stride(1), src.stride(0),
+                                       _ptr(dst), dst.stride(1), dst.stride(0), B), "agt_pyr_down_u8")
+        return dst[:, :, :dw]
+
+    def pyramid_build(self, slot, frames):
+        """frames: cuda uint8 [B,H,W]; level 0 aliases it (kept alive by this object)."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.dim() == 3
+        B, h, w = frames.shape
+        if (h, w) != (self.height, self.width):
+            raise error("frame size %dx%d does not match the context (%dx%d)" % (w, h, self.width, self.height))
+        H.check(self.L.agt_pyramid_build(self.h, slot, _ptr(frames), frames.stride(1), frames.stride(0), B),
+                "agt_pyramid_build")
+        self._keep[slot] = frames
+
+    # ---- LK
+    def lk_track(self, prev_slot, next_slot, prev_pts, next_pts=None, criteria=(3, 30, 0.01), flags=0,
+                 min_eig_threshold=1e-4, want_err=True):
+        """prev_pts: cuda f32 [B,n,2].  Returns (next_pts [B,n,2] f32, status [B,n] u8, err [B,n] f32|None)."""
+        assert prev_pts.dtype == torch.float32 and prev_pts.is_cuda and prev_pts.is_contiguous()
+        B, n, _ = prev_pts.shape
+        if next_pts is None:
+            next_pts = torch.zeros_like(prev_pts)
+        else:
+            assert next_pts.dtype == torch.float32 and next_pts.is_contiguous() and next_pts.shape == prev_pts.shape
+        status = torch.empty((B, n), dtype=torch.uint8, device=prev_pts.device)
+        err = torch.empty((B, n), dtype=torch.float32, device=prev_pts.device) if want_err else None
+        H.check(self.L.agt_lk_track(self.h, prev_slot, next_slot, _ptr(prev_pts), _ptr(next_pts), _ptr(status),
+                                    _ptr(err), n, B, int(criteria[0]), int(criteria[1]), float(criteria[2]),
+                                    int(flags), float(min_eig_threshold)), "agt_lk_track")
+        return next_pts, status, err
+
+    # ---- PnP
+    def solve_pnp(self, obj, img, K, dist, pose=None, use_guess=False, mask=None):
+        """obj: cuda [n,3] (shared) or [B,n,3]; img: cuda [B,n,2]; same float dtype.
+        pose: cuda f64 [B,6] (rvec|tvec) in/out.  Returns (pose, info [B,4] i32, err [B] f64)."""
+        assert obj.is_cuda and img.is_cuda and obj.dtype == img.dtype and obj.dtype in (torch.float32, torch.float64)
+        assert obj.is_contiguous() and img.is_contiguous()
+        B, n, _ = img.shape
+        shared = obj.dim() == 2
+        if (obj.shape[0] if shared else obj.shape[1]) != n:
+            raise error("solvePnP: object/image point counts differ")
+        dtype = H.F32 if obj.dtype == torch.float32 else H.F64
+        if pose is None:
+            pose = torch.zeros((B, 6), dtype=torch.float64, device=img.device)
+        assert pose.dtype == torch.float64 and pose.is_contiguous() and pose.shape == (B, 6)
+        info = torch.zeros((B, 4), dtype=torch.int32, device=img.device)
+        err = torch.zeros((B,), dtype=torch.float64, device=img.device)
+        Kh, _ = _host_f64(K)
+        dh, nd = _host_f64(dist)
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (B, n)
+        H.check(self.L.agt_solve_pnp(self.h, _ptr(obj), 0 if shared else n * 3, _ptr(img), dtype, _ptr(mask), n, B,
+                                     Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                                     _ptr(pose), 1 if use_guess else 0, _ptr(info), _ptr(err)), "agt_solve_pnp")
+        return pose, info, err
+
+    def project_points(self, obj, pose, K, dist, jacobian=False):
+        """obj cuda [n,3] or [B,n,3]; pose cuda f64 [B,6] -> (img [B,n,2] obj.dtype, jac [B,2n,6] f64|None)"""
+        assert obj.is_cuda and obj.is_contiguous() and obj.dtype in (torch.float32, torch.float64)
+        assert pose.dtype == torch.float64 and pose.is_contiguous()
+        B = pose.shape[0]
+        shared = obj.dim() == 2
+        n = obj.shape[0] if shared else obj.shape[1]
+        dtype = H.F32 if obj.dtype == torch.float32 else H.F64
+        out = torch.empty((B, n, 2), dtype=obj.dtype, device=obj.device)
+        jac = torch.empty((B, 2 * n, 6), dtype=torch.float64, device=obj.device) if jacobian else None
+        Kh, _ = _host_f64(K)
+        dh, nd = _host_f64(dist)
+        H.check(self.L.agt_project_points(self.h, _ptr(obj), 0 if shared else n * 3, dtype, n, B, _ptr(pose),
+                                          Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                                          _ptr(out), _ptr(jac)), "agt_project_points")
+        return out, jac
+
+
+# ------------------------------------------------------------------------------------
+# numpy-in / numpy-out functions with cv2's signatures (one synchronous call per frame,
+# exactly how the reference uses cv2, detect_pose.py:669-681)
+_ctx_cache = {}
+
+
+def _context(width, height, max_level, win, n):
+    key = (width, height, max_level, win, torch.cuda.current_device())
+    ctx = _ctx_cache.get(key)
+    if ctx is None or ctx.max_points < n:
+        ctx = Context(width, height, max_level=max_level, win=win, max_points=max(64, min(256, n)), max_streams=1)
+        _ctx_cache[key] = ctx
+    ctx.use_current_stream()
+    return ctx
+
+
+def _geom_context(n):
+    return _context(64, 64, 0, 21, n)
+
+
+def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
+                         criteria=(TERM_CRITERIA_COUNT | TERM_CRITERIA_EPS, 30, 0.01), flags=0, minEigThreshold=1e-4):
+    """cv2.calcOpticalFlowPyrLK for 8-bit single-channel images -> (nextPts (N,1,2) f32, status (N,1) u8, err (N,1) f32)."""
+    _require_gpu()
+    a = np.asarray(prevImg); b = np.asarray(nextImg)
+    if a.dtype != np.uint8 or b.dtype != np.uint8 or a.ndim != 2 or a.shape != b.shape:
+        raise error("calcOpticalFlowPyrLK: prevImg/nextImg must be equal-size 8-bit single-channel images")
+    if winSize[0] != winSize[1]:
+        raise error("calcOpticalFlowPyrLK: only square windows are built")
+    if maxLevel >= H.MAX_LEVELS:
+        raise error("calcOpticalFlowPyrLK: maxLevel too large")
+    pts = np.ascontiguousarray(np.asarray(prevPts, dtype=np.float32).reshape(-1, 2))
+    n = pts.shape[0]
+    h, w = a.shape
+    if n == 0:
+        return np.zeros((0, 1, 2), np.float32), np.zeros((0, 1), np.uint8), np.zeros((0, 1), np.float32)
+    try:
+        ctx = _context(w, h, maxLevel, winSize[0], n)
+    except H.AgtError as e:
+        raise error(str(e))
+    wp = (w + 3) & ~3
+    dev = torch.device("cuda", ctx.device)
+    fa = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fa[0, :, :w] = torch.from_numpy(a).to(dev)
+    fb = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fb[0, :, :w] = torch.from_numpy(b).to(dev)
+    ctx.pyramid_build(0, fa[:, :, :w])      # views keep the padded pitch (multiple of 4)
+    ctx.pyramid_build(1, fb[:, :, :w])
+    pp = torch.from_numpy(pts).to(dev).reshape(1, n, 2).contiguous()
+    nx = None
+    if nextPts is not None and (flags & OPTFLOW_USE_INITIAL_FLOW):
+        nx = torch.from_numpy(np.ascontiguousarray(np.asarray(nextPts, np.float32).reshape(1, n, 2))).to(dev)
+    nx, st, er = ctx.lk_track(0, 1, pp, nx, criteria=criteria, flags=flags, min_eig_threshold=minEigThreshold)
+    return (nx.cpu().numpy().reshape(n, 1, 2), st.cpu().numpy().reshape(n, 1), er.cpu().numpy().reshape(n, 1))
+
+
+def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None,
+             useExtrinsicGuess=False, flags=SOLVEPNP_ITERATIVE):
+    """cv2.solvePnP(flags=SOLVEPNP_ITERATIVE) -> (ok, rvec (3,1) f64, tvec (3,1) f64).
+    Fresh arrays are returned; a supplied guess is NOT overwritten (SURVEY.md 8b 'Ownership')."""
+    _require_gpu()
+    if flags != SOLVEPNP_ITERATIVE:
+        raise error("solvePnP: only SOLVEPNP_ITERATIVE is built")
+    obj = np.asarray(objectPoints); img = np.asarray(imagePoints)
+    obj = obj.reshape(-1, 3); img = img.reshape(-1, 2)
+    n = obj.shape[0]
+    if img.shape[0] != n or not (n >= 4 or (n == 3 and useExtrinsicGuess)) or n > 256:
+        raise error("solvePnP: need 4 <= N <= 256 matching object/image points")
+    dt = np.float32 if (obj.dtype == np.float32 and img.dtype == np.float32) else np.float64
+    ctx = _geom_context(n)
+    dev = torch.device("cuda", ctx.device)
+    o = torch.from_numpy(np.ascontiguousarray(obj, dtype=dt)).to(dev)
+    m = torch.from_numpy(np.ascontiguousarray(img, dtype=dt)).to(dev).reshape(1, n, 2)
+    pose = torch.zeros((1, 6), dtype=torch.float64, device=dev)
+    if useExtrinsicGuess:
+        g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
+        pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
+    try:
+        pose, info, _ = ctx.solve_pnp(o, m, cameraMatrix, distCoeffs, pose, useExtrinsicGuess)
+    except H.AgtError as e:
+        raise error(str(e))
+    p = pose.cpu().numpy().reshape(6)
+    inf = info.cpu().numpy().reshape(4)
+    if not inf[H.INFO_OK]:
+        if inf[H.INFO_FLAGS] & H.PNP_PLANAR:
+            raise error("solvePnP: un-guessed solve on a planar point set is not built yet")
+        raise error("solvePnP: not enough usable points")
+    return True, p[:3].reshape(3, 1).copy(), p[3:].reshape(3, 1).copy()
+
+
+def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, jacobian=False):
+    """cv2.projectPoints -> (imagePoints (N,1,2) in objectPoints' depth, jacobian (2N,6) f64 | None)."""
+    _require_gpu()
+    obj = np.asarray(objectPoints)
+    dt = np.float32 if obj.dtype == np.float32 else np.float64
+    obj = np.ascontiguousarray(obj.reshape(-1, 3), dtype=dt)
+    n = obj.shape[0]
+    ctx = _geom_context(min(n, 256))
+    dev = torch.device("cuda", ctx.device)
+    g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
+    pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
+    try:
+        out, jac = ctx.project_points(torch.from_numpy(obj).to(dev), pose, cameraMatrix, distCoeffs, jacobian)
+    except H.AgtError as e:
+        raise error(str(e))
+    return out.cpu().numpy().reshape(n, 1, 2), (jac.cpu().numpy().reshape(2 * n, 6) if jacobian else None)

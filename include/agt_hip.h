@@ -1,0 +1,167 @@
+/*
+ * agt_hip.h -- C ABI of the MI355X (gfx950) AprilGroup tracking hot path.
+ *
+ * The reference (Virtana/accurate-aprilgroup-tracking) has no FFI layer: its hot path
+ * is Python calling OpenCV.  A drop-in therefore replaces the four
+ * cv2 entry points the path uses, plus a fused per-frame step, behind plain C
+ * functions that a Python maintainer binds with ctypes:
+ *
+ *   agt_solve_pnp        <- cv.solvePnP(..., flags=SOLVEPNP_ITERATIVE)
+ *                           /root/reference/aprilgroup_tracking/aprilgroup_pose_estimation/detect_pose.py:509-515 (no guess)
+ *                           detect_pose.py:517-526 (useExtrinsicGuess=True)
+ *   agt_project_points   <- cv.projectPoints      transform_helper.py:106-111, detect_pose.py:455-461
+ *   agt_reproj_error     <- TransformHelper.get_reprojection_error   transform_helper.py:98-121
+ *   agt_pyramid_build /
+ *   agt_lk_track         <- cv.calcOpticalFlowPyrLK (north-star step; no call site in the
+ *                           reference, belongs at the hole detect_pose.py:573-574)
+ *   agt_track_frame      <- one PoseDetector._estimate_pose step (detect_pose.py:467-574)
+ *                           with LK-tracked corners, state kept on the device
+ *
+ * Conventions: every function returns 0 (AGT_OK) or a negative AGT_ERR_*; nothing
+ * throws across the ABI.  Pointers named d_* are raw device addresses (e.g.
+ * torch.Tensor.data_ptr()); the library never frees or retains caller memory beyond
+ * what each function documents.  All work is enqueued on the context's HIP stream;
+ * nothing synchronises unless stated.  One context per host thread / stream; a context
+ * is not re-entrant.  B = number of independent streams (frames/sequences) per call.
+ */
+#ifndef AGT_HIP_H
+#define AGT_HIP_H
+
+#include <stdint.h>
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGT_VERSION 100
+
+#define AGT_OK               0
+#define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
+#define AGT_ERR_ALLOC       (-2)
+#define AGT_ERR_DIST        (-3)   /* distortion count not in {0,4,5,8,12} */
+#define AGT_ERR_NPOINTS     (-4)   /* too few / too many points */
+#define AGT_ERR_HIP         (-5)   /* a HIP runtime call failed; see agt_last_hip_error */
+#define AGT_ERR_UNSUPPORTED (-6)   /* e.g. LK window size not compiled in */
+#define AGT_ERR_STATE       (-7)   /* pyramid slot not built, context mismatch */
+
+#define AGT_MAX_LEVELS 6
+
+/* cv::OPTFLOW_* / cv::TermCriteria bits (same numeric values as OpenCV) */
+#define AGT_LK_USE_INITIAL_FLOW   4
+#define AGT_LK_GET_MIN_EIGENVALS  8
+#define AGT_TERM_COUNT 1
+#define AGT_TERM_EPS   2
+
+/* element type of object / image point arrays */
+#define AGT_F32 0
+#define AGT_F64 1
+
+/* agt_solve_pnp info[b*4 + ...] */
+#define AGT_INFO_OK     0   /* 1 = a pose was produced */
+#define AGT_INFO_ITERS  1   /* CvLevMarq iteration count */
+#define AGT_INFO_NUSED  2   /* points with mask != 0 */
+#define AGT_INFO_FLAGS  3   /* AGT_PNP_* bits */
+#define AGT_PNP_SINGULAR  1 /* a damped normal-equation solve hit a non-positive pivot */
+#define AGT_PNP_PLANAR    2 /* un-guessed solve on a planar point set (homography init) */
+#define AGT_PNP_TOO_FEW   4 /* fewer usable points than the solve needs; pose untouched */
+
+/* agt_track_frame state flags, state_out[b*AGT_STATE_STRIDE + ...] (doubles) */
+#define AGT_STATE_STRIDE 16
+#define AGT_ST_RVEC    0    /* 0..2 pose rvec of this frame (valid if AGT_ST_OK) */
+#define AGT_ST_TVEC    3    /* 3..5 pose tvec */
+#define AGT_ST_OK      6    /* 1.0 = pose accepted (mean reprojection error < gate) */
+#define AGT_ST_ERR     7    /* mean reprojection error, px (transform_helper.py:98-121) */
+#define AGT_ST_NTRACK  8    /* corners with LK status 1 */
+#define AGT_ST_ITERS   9    /* LM iterations */
+#define AGT_ST_GUESS   10   /* 1.0 = an extrinsic guess was used for this frame */
+#define AGT_ST_FLAGS   11   /* AGT_PNP_* bits | AGT_TRK_* bits */
+#define AGT_TRK_ZERO_VELOCITY 256  /* a velocity element was exactly 0: reference raises ValueError (detect_pose.py:236-237) */
+
+typedef struct agt_ctx agt_ctx;
+
+typedef struct agt_config {
+    int device;        /* HIP device ordinal */
+    int width, height; /* level-0 frame size in pixels */
+    int max_level;     /* LK maxLevel: pyramid levels 0..max_level ("3-level" = 2) */
+    int win;           /* square LK window; 21 is compiled in */
+    int max_points;    /* correspondences per stream (<= 256) */
+    int max_streams;   /* B upper bound */
+    int reserved[8];   /* must be 0 */
+} agt_config;
+
+/* ---- lifetime ---- */
+int  agt_version(void);
+const char* agt_error_string(int code);
+/* hip_stream: a hipStream_t (NULL = default stream).  Allocates the context's pyramid
+ * storage (levels >= 1 for two slots), tracker state and scratch. */
+int  agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out);
+int  agt_destroy(agt_ctx* ctx);
+int  agt_set_stream(agt_ctx* ctx, void* hip_stream);
+int  agt_last_hip_error(const agt_ctx* ctx);   /* hipError_t of the last failing HIP call */
+int  agt_synchronize(agt_ctx* ctx);            /* hipStreamSynchronize(ctx stream) */
+
+/* ---- image pyramid (cv::pyrDown / buildOpticalFlowPyramid) ---- */
+/* One pyrDown: dst is ((sw+1)/2) x ((sh+1)/2).  Pitches and batch strides in bytes;
+ * base pointers and pitches must be multiples of 4. */
+int agt_pyr_down_u8(agt_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t spitch, size_t sbatch,
+                    uint8_t* d_dst, size_t dpitch, size_t dbatch, int B);
+/* Build slot (0/1) of the context's pyramid from B frames of cfg.width x cfg.height.
+ * Level 0 aliases d_frames: the caller keeps those frames valid and unmodified until
+ * the last agt_lk_track / agt_track_frame that reads the slot has completed. */
+int agt_pyramid_build(agt_ctx* ctx, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B);
+/* Introspection (tests): device pointer and geometry of one level of a built slot. */
+int agt_pyramid_level(const agt_ctx* ctx, int slot, int level, const uint8_t** d_ptr,
+                      int* w, int* h, size_t* pitch, size_t* batch_stride);
+/* number of usable levels - 1 (OpenCV stops early when a level would be <= win) */
+int agt_pyramid_max_level(const agt_ctx* ctx);
+
+/* ---- cv::calcOpticalFlowPyrLK on two built slots ---- */
+/* d_prev_pts, d_next_pts: [B][n][2] f32.  d_next_pts is read only with
+ * AGT_LK_USE_INITIAL_FLOW.  d_status: [B][n] u8.  d_err: [B][n] f32 or NULL. */
+int agt_lk_track(agt_ctx* ctx, int prev_slot, int next_slot,
+                 const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                 int n, int B, int crit_type, int crit_max_count, double crit_eps,
+                 int flags, double min_eig_threshold);
+
+/* ---- cv::solvePnP(SOLVEPNP_ITERATIVE), batched ---- */
+/* d_obj: n x 3 (obj_batch_stride = 0: shared by all B) or [B][n][3] (stride in elements).
+ * d_img: [B][n][2].  dtype: AGT_F32 / AGT_F64 for both arrays.
+ * d_mask: [B][n] u8 (0 = skip the point, e.g. LK status) or NULL.
+ * K: 9 host doubles row-major.  dist: ndist host doubles (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4]]]) or NULL.
+ * d_pose: [B][6] f64 (rvec, tvec): read when use_guess, always written on success
+ * (cv2 overwrites the guess arrays in place too, detect_pose.py:487-490).
+ * d_info: [B][4] i32 (AGT_INFO_*), d_err: [B] f64 mean reprojection error; either may be NULL. */
+int agt_solve_pnp(agt_ctx* ctx, const void* d_obj, size_t obj_batch_stride, const void* d_img, int dtype,
+                  const uint8_t* d_mask, int n, int B,
+                  const double* K, const double* dist, int ndist,
+                  double* d_pose, int use_guess, int32_t* d_info, double* d_err);
+
+/* ---- cv::projectPoints, batched ---- */
+/* d_pose: [B][6] f64.  d_img_out: [B][n][2] in dtype.  d_jac: [B][2n][6] f64 (d/dr | d/dt) or NULL. */
+int agt_project_points(agt_ctx* ctx, const void* d_obj, size_t obj_batch_stride, int dtype, int n, int B,
+                       const double* d_pose, const double* K, const double* dist, int ndist,
+                       void* d_img_out, double* d_jac);
+
+/* ---- fused per-frame step (PoseDetector._estimate_pose with LK-tracked corners) ---- */
+/* Tracker state lives in the context, one record per stream: current corners, the
+ * extrinsic guess, prev_transform and the two-deep velocity buffers of
+ * detect_pose.py:74-83, 229-349. */
+/* (Re)initialise streams [0,B): corners [B][n][2] f32 seen in the frames of `slot`
+ * (already built), shared object points n x 3 f32, camera; clears guess and buffers. */
+int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const float* d_obj, int n, int B,
+                      const double* K, const double* dist, int ndist, int enhance_ape);
+/* Optionally seed the guess / prev_transform (e.g. from a detector-based solve). */
+int agt_tracker_set_pose(agt_ctx* ctx, const double* d_pose /* [B][6] */, int B);
+/* One frame for B streams: pyramid(new frames) -> LK(prev corners) -> solvePnP(guess) ->
+ * reprojection gate -> motion-model guess update.  d_state_out: [B][AGT_STATE_STRIDE] f64 or NULL
+ * (device memory; read it back whenever convenient).  No host synchronisation. */
+int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                    double* d_state_out);
+/* device pointers to the live tracker buffers (corners [B][n][2] f32, status [B][n] u8) */
+int agt_tracker_buffers(const agt_ctx* ctx, const float** d_corners, const uint8_t** d_status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

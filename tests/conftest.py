@@ -1,0 +1,37 @@
+import os
+import sys
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def oracle():
+    """CPU oracle (test infrastructure only)."""
+    from oracle import cvoracle
+    cvoracle.build()
+    return cvoracle
+
+
+@pytest.fixture(scope="session")
+def seq640():
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    return syn.Sequence(640, 480, n_tags=12, n_frames=6, seed=0)
+
+
+@pytest.fixture(scope="session")
+def seq720():
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    return syn.Sequence(1280, 720, n_tags=12, n_frames=4, seed=1)
+
+
+@pytest.fixture(scope="session")
+def seq640_dist():
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    return syn.Sequence(640, 480, n_tags=12, n_frames=4, seed=2, dist=syn.MILD_DIST)

@@ -1,0 +1,194 @@
+"""-m gpu: parity of the HIP path (through the C ABI) against the CPU oracle.
+
+Integer / byte work (pyrDown, LK nextPts/status/err) must be BIT-EXACT.  Floating-point
+pose work must agree to POSE_TOL (north_star: pose error <= 1e-4 vs the reference path;
+we hold the HIP-vs-oracle gap five orders tighter).
+"""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+POSE_TOL = 1e-9      # |d rvec|, |d tvec| HIP vs oracle on identical inputs (north_star bound: 1e-4)
+PROJ_TOL = 1e-9      # projected pixels, f64
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a ROCm device"
+    return torch
+
+
+@pytest.fixture(scope="module")
+def cvh(torch_cuda):
+    from accurate_aprilgroup_tracking_amd import cv_hip
+    return cv_hip
+
+
+def test_library_loaded():
+    from accurate_aprilgroup_tracking_amd import hiplib
+    assert hiplib.lib().agt_version() == 100
+
+
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260)])
+def test_pyr_down_bit_exact(torch_cuda, cvh, oracle, shape):
+    torch = torch_cuda
+    rng = np.random.default_rng(shape[0] * 1000 + shape[1])
+    h, w = shape
+    img = rng.integers(0, 256, size=(3, h, w), dtype=np.uint8)
+    ctx = cvh.Context(64, 64, max_level=0)
+    wp = (w + 3) & ~3
+    d = torch.zeros((3, h, wp), dtype=torch.uint8, device="cuda")
+    d[:, :, :w] = torch.from_numpy(img).cuda()
+    out = ctx.pyr_down(d[:, :, :w]).cpu().numpy()
+    for b in range(3):
+        ref = oracle.pyrDown(img[b])
+        assert out[b].shape == ref.shape
+        assert np.array_equal(out[b], ref)
+
+
+def _lk_both(cvh, oracle, a, b, pts, **kw):
+    nx_o, st_o, er_o = oracle.calcOpticalFlowPyrLK(a, b, pts, **kw)
+    nx_g, st_g, er_g = cvh.calcOpticalFlowPyrLK(a, b, pts, **kw)
+    return (nx_o, st_o, er_o), (nx_g, st_g, er_g)
+
+
+def _assert_lk_equal(o, g):
+    assert np.array_equal(o[1], g[1]), "status differs"
+    assert np.array_equal(o[0].view(np.uint32), g[0].view(np.uint32)), \
+        "nextPts not bit-identical, max diff %g" % np.abs(o[0] - g[0]).max()
+    assert np.array_equal(o[2].view(np.uint32), g[2].view(np.uint32)), "err not bit-identical"
+
+
+def test_lk_bit_exact_640(cvh, oracle, seq640):
+    for k in range(3):
+        o, g = _lk_both(cvh, oracle, seq640.frame(k), seq640.frame(k + 1), seq640.corners(k), maxLevel=2)
+        _assert_lk_equal(o, g)
+        assert o[1].sum() == 48
+
+
+def test_lk_bit_exact_720(cvh, oracle, seq720):
+    o, g = _lk_both(cvh, oracle, seq720.frame(0), seq720.frame(1), seq720.corners(0), maxLevel=2)
+    _assert_lk_equal(o, g)
+
+
+def test_lk_edge_cases(cvh, oracle, seq640):
+    """points near / outside the border, flat regions (minEig reject), big jumps, level early-stop"""
+    a, b = seq640.frame(0), seq640.frame(2)
+    h, w = a.shape
+    rng = np.random.default_rng(5)
+    pts = np.concatenate([
+        seq640.corners(0)[:16],
+        np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [-5.5, 10.25], [w + 3.0, 7.0], [3.2, h + 8.9], [-40.0, -40.0],
+                  [w + 30.0, h + 30.0], [10.5, 10.5], [w - 11.0, h - 11.0], [1.0, h / 2.0]], np.float32),
+        rng.uniform([-15, -15], [w + 15, h + 15], size=(40, 2)).astype(np.float32)])
+    for ml in (0, 1, 2, 3, 4):
+        o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=ml)
+        _assert_lk_equal(o, g)
+    # flags / criteria variants
+    init = pts + rng.normal(0, 1.5, pts.shape).astype(np.float32)
+    for kw in (dict(flags=4, nextPts=init), dict(flags=8), dict(criteria=(1, 5, 0.0)), dict(criteria=(2, 0, 0.03)),
+               dict(minEigThreshold=1e-2)):
+        o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2, **kw)
+        _assert_lk_equal(o, g)
+
+
+def test_lk_random_texture_other_sizes(cvh, oracle):
+    from scipy.ndimage import gaussian_filter, shift
+    rng = np.random.default_rng(11)
+    for (h, w) in ((97, 131), (240, 320)):
+        base = gaussian_filter(rng.standard_normal((h, w)), 1.5)
+        base = (base - base.min()) / (base.max() - base.min()) * 255
+        a = base.astype(np.uint8)
+        b = np.clip(shift(base, (1.3, -2.1), order=3, mode="reflect"), 0, 255).astype(np.uint8)
+        pts = rng.uniform([5, 5], [w - 5, h - 5], size=(64, 2)).astype(np.float32)
+        o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2)
+        _assert_lk_equal(o, g)
+        good = o[1].ravel() == 1
+        d = (o[0].reshape(-1, 2) - pts)[good]
+        assert np.abs(np.median(d, axis=0) - np.array([-2.1, 1.3])).max() < 0.1
+
+
+def test_project_points(cvh, oracle, seq640_dist):
+    s = seq640_dist
+    for dt in (np.float64, np.float32):
+        ref, jref = oracle.projectPoints(s.obj.astype(dt), s.rvecs[1], s.tvecs[1], s.K, s.dist, jacobian=True)
+        out, jac = cvh.projectPoints(s.obj.astype(dt), s.rvecs[1], s.tvecs[1], s.K, s.dist, jacobian=True)
+        assert out.dtype == dt and out.shape == ref.shape
+        tol = PROJ_TOL if dt == np.float64 else 1e-4
+        assert np.abs(out - ref).max() < tol
+        assert np.abs(jac - jref).max() < 1e-7 * np.abs(jref).max()
+
+
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_solve_pnp_guess_and_dlt(cvh, oracle, seq640, seq640_dist, use_dist):
+    s = seq640_dist if use_dist else seq640
+    rng = np.random.default_rng(3)
+    for k in range(3):
+        img = s.corners(k).astype(np.float64) + rng.normal(0, 0.05, (48, 2))
+        obj32, img32 = s.obj.astype(np.float32), img.astype(np.float32)
+        # no guess (DLT init + LM)
+        ok_o, r_o, t_o = oracle.solvePnP(obj32, img32, s.K, s.dist)
+        ok_g, r_g, t_g = cvh.solvePnP(obj32, img32, s.K, s.dist)
+        assert ok_g and r_g.shape == (3, 1) and r_g.dtype == np.float64
+        assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
+        # guess
+        g_r = s.rvecs[k] + 0.02; g_t = (s.tvecs[k] + 0.003).astype(np.float32)
+        ok_o, r_o, t_o = oracle.solvePnP(obj32, img32, s.K, s.dist, g_r, g_t, True)
+        ok_g, r_g, t_g = cvh.solvePnP(obj32, img32, s.K, s.dist, g_r, g_t, True)
+        assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
+        # ground truth on the clean points
+        assert np.abs(r_g.ravel() - s.rvecs[k]).max() < 5e-3
+
+
+def test_solve_pnp_batched_masked_f64(torch_cuda, cvh, oracle, seq640):
+    torch = torch_cuda
+    s = seq640
+    rng = np.random.default_rng(9)
+    B, n = 7, 48
+    img = np.stack([s.corners(k % len(s)).astype(np.float64) + rng.normal(0, 0.1, (n, 2)) for k in range(B)])
+    mask = (rng.uniform(size=(B, n)) > 0.3).astype(np.uint8)
+    guess = np.stack([np.concatenate([s.rvecs[k % len(s)] + 0.01, s.tvecs[k % len(s)] - 0.002]) for k in range(B)])
+    ctx = cvh.Context(64, 64, max_level=0, max_points=64, max_streams=B)
+    pose = torch.from_numpy(guess.copy()).cuda()
+    pose, info, err = ctx.solve_pnp(torch.from_numpy(s.obj).cuda(), torch.from_numpy(img).cuda(), s.K, None,
+                                    pose, True, torch.from_numpy(mask).cuda())
+    pose, info, err = pose.cpu().numpy(), info.cpu().numpy(), err.cpu().numpy()
+    for b in range(B):
+        m = mask[b] > 0
+        ok, r, t, it = oracle.solvePnP(s.obj[m], img[b][m], s.K, None, guess[b, :3], guess[b, 3:], True, return_iters=True)
+        assert info[b, 0] == 1 and info[b, 2] == m.sum()
+        assert np.abs(pose[b, :3] - r.ravel()).max() < POSE_TOL and np.abs(pose[b, 3:] - t.ravel()).max() < POSE_TOL
+        assert info[b, 1] == it
+        e = oracle.mean_reproj_error(s.obj[m], img[b][m], r, t, s.K, None)
+        assert abs(err[b] - e) < 1e-9
+
+
+def test_solve_pnp_large_n(cvh, oracle):
+    """N = 240 (config 5 size): four correspondences per lane"""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    g = syn.make_april_group(n_tags=60, seed=4)
+    obj = syn.group_object_points(g)
+    K = syn.camera_matrix(1280, 720)
+    r = np.array([0.1, 0.2, -0.3]); t = np.array([0.02, 0.01, 0.6])
+    rng = np.random.default_rng(2)
+    img = syn.project(obj, r, t, K, syn.MILD_DIST) + rng.normal(0, 0.1, (240, 2))
+    ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, syn.MILD_DIST)
+    ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, syn.MILD_DIST)
+    assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
+    ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, syn.MILD_DIST, r + 0.03, t + 0.01, True)
+    ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, syn.MILD_DIST, r + 0.03, t + 0.01, True)
+    assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
+
+
+def test_error_behaviour(cvh):
+    obj = np.zeros((3, 3)); img = np.zeros((3, 2)); K = np.eye(3)
+    with pytest.raises(ValueError):
+        cvh.solvePnP(obj, img, K, None)                     # N < 4 without a guess
+    with pytest.raises(ValueError):
+        cvh.solvePnP(np.zeros((5, 3)), np.zeros((4, 2)), K, None)   # count mismatch
+    with pytest.raises(ValueError):
+        cvh.solvePnP(np.random.rand(8, 3), np.random.rand(8, 2), K, np.zeros(3))   # bad dist count
+    with pytest.raises(ValueError):
+        cvh.calcOpticalFlowPyrLK(np.zeros((10, 10), np.float32), np.zeros((10, 10), np.float32), np.zeros((1, 2)))
