@@ -25,6 +25,10 @@ struct agt_ctx {
     AgtTrackState* tstate;                   // [B]
     AgtCameraHost cam;
     int trk_n, trk_B, trk_slot, trk_cur, enhance_ape, trk_ready;
+    int reproject, min_points;
+    double gate_px;
+    // LK parameters of the fused step (COUNT+EPS (30, 0.01), minEig 1e-4, flags 0)
+    int lk_max_count; double lk_eps; double lk_min_eig;
 };
 
 namespace {
@@ -109,6 +113,8 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
     c->built_B[0] = c->built_B[1] = 0;
+    c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
+    c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
     *out = c;
     return AGT_OK;
 }
@@ -261,32 +267,77 @@ int agt_project_points(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, i
 int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float* d_obj, int n, int B,
                       const double* K, const double* dist, int ndist, int enhance_ape)
 {
-    if (!c || !d_corners || !d_obj || slot < 0 || slot > 1) return AGT_ERR_ARG;
+    if (!c || !d_obj || slot < 0 || slot > 1) return AGT_ERR_ARG;
     if (n < 4 || n > c->cfg.max_points) return AGT_ERR_NPOINTS;
     if (B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
-    if (c->built_B[slot] < B) return AGT_ERR_STATE;
+    if (d_corners && c->built_B[slot] < B) return AGT_ERR_STATE;
     int rc = fill_camera(K, dist, ndist, &c->cam);
     if (rc) return rc;
-    hipError_t e = hipMemcpyAsync(c->corners[0], d_corners, (size_t)B * n * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
+    hipError_t e = hipSuccess;
+    if (d_corners) e = hipMemcpyAsync(c->corners[0], d_corners, (size_t)B * n * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->pose, 0, (size_t)B * 6 * sizeof(double), c->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(c->status, 1, (size_t)B * n, c->stream);
     if (e != hipSuccess) return hip_fail(c, e);
-    c->trk_n = n; c->trk_B = B; c->trk_slot = slot; c->trk_cur = 0; c->enhance_ape = enhance_ape ? 1 : 0; c->trk_ready = 1;
+    c->trk_n = n; c->trk_B = B; c->trk_slot = slot; c->trk_cur = 0; c->enhance_ape = enhance_ape ? 1 : 0;
+    c->trk_ready = d_corners ? 2 : 1;
     return AGT_OK;
 }
 
-int agt_tracker_set_pose(agt_ctx* c, const double* d_pose, int B)
+int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_px)
 {
-    (void)c; (void)d_pose; (void)B;
-    return AGT_ERR_UNSUPPORTED;
+    if (!c || min_points < 6 || min_points > 256 || !(gate_px > 0.0)) return AGT_ERR_ARG;
+    c->reproject = reproject ? 1 : 0; c->min_points = min_points; c->gate_px = gate_px;
+    return AGT_OK;
+}
+
+static int launch_estimate(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out, float* corners_rw)
+{
+    AgtPnpParams p;
+    memset(&p, 0, sizeof(p));
+    p.obj = c->obj; p.obj_bstride = 0; p.img = d_img; p.mask = d_mask; p.dtype = AGT_F32;
+    p.n = c->trk_n; p.cam = c->cam; p.pose = c->pose;
+    p.track = c->tstate; p.state_out = d_state_out; p.corners_rw = corners_rw;
+    p.enhance_ape = c->enhance_ape; p.reproject = c->reproject; p.min_points = c->min_points; p.gate_px = c->gate_px;
+    hipError_t e = agt_launch_pnp(c->stream, p, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out)
+{
+    if (!c || !d_img) return AGT_ERR_ARG;
+    if (!c->trk_ready) return AGT_ERR_STATE;
+    if (B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
+    return launch_estimate(c, d_img, d_mask, B, d_state_out, nullptr);
 }
 
 int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out)
 {
-    (void)c; (void)d_frames; (void)pitch; (void)batch_stride; (void)B; (void)d_state_out;
-    return AGT_ERR_UNSUPPORTED;
+    if (!c || !d_frames) return AGT_ERR_ARG;
+    if (c->trk_ready != 2) return AGT_ERR_STATE;
+    if (B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
+    const int prev_slot = c->trk_slot, next_slot = 1 - prev_slot;
+    int rc = agt_pyramid_build(c, next_slot, d_frames, pitch, batch_stride, B);
+    if (rc) return rc;
+    const int cur = c->trk_cur, nxt = 1 - cur;
+    rc = agt_lk_track(c, prev_slot, next_slot, c->corners[cur], c->corners[nxt], c->status, nullptr,
+                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+    if (rc) return rc;
+    rc = launch_estimate(c, c->corners[nxt], c->status, B, d_state_out, c->corners[nxt]);
+    if (rc) return rc;
+    c->trk_slot = next_slot; c->trk_cur = nxt;
+    return AGT_OK;
+}
+
+int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }
+
+int agt_tracker_state_read(agt_ctx* c, void* host_dst, int B)
+{
+    if (!c || !host_dst || !c->trk_ready || B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
+    hipError_t e = hipMemcpyAsync(host_dst, c->tstate, (size_t)B * sizeof(AgtTrackState), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
 int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t** d_status)

@@ -44,11 +44,13 @@ struct AgtPnpParams {
     double* pose;             // [B][6] in/out
     int32_t* info;            // [B][4] or null
     double* err;              // [B] or null
-    // tracker epilogue (null = plain solvePnP)
+    // tracker mode (null = plain solvePnP): PoseDetector._estimate_pose on device state
     struct AgtTrackState* track;   // [B]
     double* state_out;             // [B][AGT_STATE_STRIDE] or null
-    float* corners;                // [B][n][2] tracker corners to update in place (LK output) or null
+    float* corners_rw;             // [B][n][2] corner set to refresh by reprojection, or null
     int enhance_ape;
+    int reproject;
+    int min_points;                // corners needed to attempt a pose (8 = two tags)
     double gate_px;                // reprojection gate (2.0, detect_pose.py:539)
 };
 
@@ -59,10 +61,13 @@ struct AgtTrackState {
     double prev[6];         // prev_transform
     double rot_vel[2][9];   // rot_velocities (oldest first)
     double tran_vel[2][3];  // tran_velocities
-    int has_guess;
-    int has_prev;
-    int n_vel;
+    int has_guess;          // extrinsic_guess[0] is not None
+    int has_prev;           // prev_transform[0] is not None
+    int n_vel;              // len(rot_velocities)
     int frame;
+    int guess_t_f32;        // dtype of extrinsic_guess[1] is float32 (from get_rmat_tvec, transform_helper.py:158-159)
+    int prev_t_f32;         // dtype of prev_transform[1] is float32
+    int pad[2];
 };
 
 struct AgtProjParams {

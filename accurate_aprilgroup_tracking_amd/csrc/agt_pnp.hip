@@ -127,6 +127,96 @@ __device__ void smallest_eigvec(double* A, int n, double* v, double* tmp)
     }
 }
 
+// ---- motion model of PoseDetector (serial, one lane) ------------------------------------
+// transform_helper.py:239-259 rotation_matrix_to_euler_angles
+__device__ inline void rot_to_euler(const double R[9], double e[3])
+{
+    const double sy = sqrt(R[0] * R[0] + R[3] * R[3]);
+    if (!(sy < 1e-6)) { e[0] = atan2(R[7], R[8]); e[1] = atan2(-R[6], sy); e[2] = atan2(R[3], R[0]); }
+    else { e[0] = atan2(-R[5], R[4]); e[1] = atan2(-R[6], sy); e[2] = 0.0; }
+}
+// transform_helper.py:215-236 euler_angles_to_rotation_matrix: R = Rz * Ry * Rx
+__device__ inline void euler_to_rot(const double e[3], double R[9])
+{
+    double sx, cx, sy, cy, sz, cz;
+    sincos(e[0], &sx, &cx); sincos(e[1], &sy, &cy); sincos(e[2], &sz, &cz);
+    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx };
+    const double Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy };
+    const double Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
+    double T[9];
+    agt_mat3_mul(Ry, Rx, T);
+    agt_mat3_mul(Rz, T, R);
+}
+// A^T B
+__device__ inline void mat3_tmul(const double A[9], const double B[9], double C[9])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
+}
+// A^T v
+__device__ inline void mat3_tvec(const double A[9], const double v[3], double o[3])
+{
+#pragma unroll
+    for (int i = 0; i < 3; i++) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
+}
+
+// detect_pose.py:553-566: get_pose_vel_acc (245-301) + _update_buffers (229-243) +
+// apply_vel_acc (303-349).  curr/prev = (rvec, tvec).  Returns AGT_TRK_* flags.
+__device__ inline int motion_model_update(AgtTrackState& ts, const double curr[6], bool curr_t_f32,
+                                          const double prev[6], bool prev_t_f32)
+{
+    double Rp[9], Rc[9];
+    agt_rodrigues<false>(prev, Rp, nullptr);
+    agt_rodrigues<false>(curr, Rc, nullptr);
+    // get_relative_trans (transform_helper.py:184): rot_mat.T @ (tvec0 - tvec1); numpy subtracts in
+    // float32 when both operands are float32 arrays
+    double d[3], tran_vel[3], rot_vel[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+        d[i] = (curr_t_f32 && prev_t_f32) ? (double)((float)prev[3 + i] - (float)curr[3 + i]) : prev[3 + i] - curr[3 + i];
+    mat3_tvec(Rc, d, tran_vel);
+    mat3_tmul(Rc, Rp, rot_vel);                  // get_relative_rot: rmat1.T @ rmat0
+    bool any_zero = false;
+#pragma unroll
+    for (int i = 0; i < 9; i++) any_zero |= rot_vel[i] == 0.0;
+#pragma unroll
+    for (int i = 0; i < 3; i++) any_zero |= tran_vel[i] == 0.0;
+    if (any_zero) return AGT_TRK_ZERO_VELOCITY;  // reference raises ValueError here
+    if (ts.n_vel >= 2) {
+        for (int i = 0; i < 9; i++) ts.rot_vel[0][i] = ts.rot_vel[1][i];
+        for (int i = 0; i < 3; i++) ts.tran_vel[0][i] = ts.tran_vel[1][i];
+        ts.n_vel = 1;
+    }
+    const int slot = ts.n_vel;
+    for (int i = 0; i < 9; i++) ts.rot_vel[slot][i] = rot_vel[i];
+    for (int i = 0; i < 3; i++) ts.tran_vel[slot][i] = tran_vel[i];
+    ts.n_vel = slot + 1;
+    if (ts.n_vel < 2) return 0;                  // success = False: the guess is left as is
+    double dv[3], tran_acc[3], rot_acc[9], old_rv[9];
+    for (int i = 0; i < 3; i++) dv[i] = ts.tran_vel[0][i] - tran_vel[i];
+    for (int i = 0; i < 9; i++) old_rv[i] = ts.rot_vel[0][i];
+    mat3_tvec(rot_vel, dv, tran_acc);
+    mat3_tmul(rot_vel, old_rv, rot_acc);
+    // apply_vel_acc on the PREVIOUS pose
+    double e[3], RA[9], M[9], Rpred[9], tp[3], tpred[3];
+    rot_to_euler(rot_acc, e);
+    e[0] *= 0.5; e[1] *= 0.5; e[2] *= 0.5;
+    euler_to_rot(e, RA);
+    agt_mat3_mul(RA, rot_vel, M);                // (acc @ vel) @ pose
+    agt_mat3_mul(M, Rp, Rpred);
+    for (int i = 0; i < 3; i++) tp[i] = prev[3 + i];
+    for (int i = 0; i < 3; i++)
+        tpred[i] = (M[i * 3] * tp[0] + M[i * 3 + 1] * tp[1] + M[i * 3 + 2] * tp[2]) +
+                   (RA[i * 3] * tran_vel[0] + RA[i * 3 + 1] * tran_vel[1] + RA[i * 3 + 2] * tran_vel[2] + 0.5 * tran_acc[i]);
+    double rpred[3];
+    agt_rodrigues_inv(Rpred, rpred);
+    for (int i = 0; i < 3; i++) { ts.guess[i] = rpred[i]; ts.guess[3 + i] = (double)(float)tpred[i]; }
+    ts.guess_t_f32 = 1;                          // get_rmat_tvec casts to float32 (transform_helper.py:158-159)
+    return 0;
+}
+
 template <typename T, int PPL>
 __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 {
@@ -158,10 +248,33 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
     const int n_used = (int)agt_wave_sum_i64(cnt);
     int flags = 0;
     double param[6];
+    AgtTrackState* ts = P.track ? P.track + b : nullptr;
+    bool use_guess = P.use_guess != 0;
+    double unchanged_prev[6] = { 0, 0, 0, 0, 0, 0 };
+    int had_guess = 0, guess_f32 = 0, prev_f32 = 0;
+    if (ts) {
+        // detect_pose.py:490 deepcopy(prev_transform); :508 guess selection
+        had_guess = ts->has_guess; guess_f32 = ts->guess_t_f32; prev_f32 = ts->prev_t_f32;
+        use_guess = had_guess && P.enhance_ape;
 #pragma unroll
-    for (int i = 0; i < 6; i++) param[i] = P.pose[(long)b * 6 + i];
+        for (int i = 0; i < 6; i++) { unchanged_prev[i] = ts->prev[i]; param[i] = ts->guess[i]; }
+        if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
+            if (lane == 0) {
+                ts->has_guess = 0; ts->frame++;
+                if (P.state_out) {
+                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+                    for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
+                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
+                }
+            }
+            return;
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 6; i++) param[i] = P.pose[(long)b * 6 + i];
+    }
 
-    const bool enough = P.use_guess ? n_used >= 3 : n_used >= 6;
+    const bool enough = use_guess ? n_used >= 3 : n_used >= 6;
     if (!enough) {
         if (lane == 0 && P.info) {
             P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
@@ -172,7 +285,7 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
     }
 
     // ---- initialisation without a guess: cvFindExtrinsicCameraParams2, DLT branch
-    if (!P.use_guess) {
+    if (!use_guess) {
         double c4[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int q = 0; q < PPL; q++) if (use[q]) { c4[0] += X[q]; c4[1] += Y[q]; c4[2] += Z[q]; }
@@ -195,6 +308,14 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
                 P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_PLANAR;
             }
             if (lane == 0 && P.err) P.err[b] = 0.0;
+            if (lane == 0 && ts) {
+                ts->has_guess = 0; ts->frame++;
+                if (P.state_out) {
+                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+                    for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
+                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_PLANAR;
+                }
+            }
             return;
         }
         // L^T L has only 40 distinct sums: sum w * Mt Mt^T with w in {1, x, y, x^2+y^2}
@@ -342,6 +463,14 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
         e2 = evaluate(true);
     }
 
+    // cv2 writes the result INTO the guess arrays: a float32 guess tvec (from the motion model)
+    // yields a float32-rounded tvec (solvepnp.cpp convertTo(tvec, tvec.depth()))
+    const bool tvec_f32 = ts && use_guess && guess_f32;
+    if (tvec_f32) {
+#pragma unroll
+        for (int i = 3; i < 6; i++) param[i] = (double)(float)param[i];
+    }
+
     // ---- epilogue: mean reprojection error (transform_helper.py:98-121) at the solution
     double esum = 0.0;
     {
@@ -355,6 +484,52 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
             esum += sqrt(ex * ex + ey * ey);
         }
         esum = wave_sum_f64(esum) / n_used;
+    }
+    if (ts) {
+        // ---- PoseDetector._estimate_pose state update, detect_pose.py:528-574
+        const bool accepted = esum < P.gate_px;
+        if (lane == 0) {
+            int tflags = flags;
+            if (use_guess) {                    // in-place result: the guess arrays now hold the pose
+                for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
+            }
+            if (accepted) {
+                if (!had_guess || !P.enhance_ape) {
+                    for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
+                    ts->guess_t_f32 = 0; ts->has_guess = 1;
+                } else {
+                    tflags |= motion_model_update(*ts, param, tvec_f32, unchanged_prev, prev_f32 != 0);
+                }
+                if (!(tflags & AGT_TRK_ZERO_VELOCITY)) {
+                    for (int i = 0; i < 6; i++) ts->prev[i] = param[i];
+                    ts->prev_t_f32 = tvec_f32 ? 1 : 0; ts->has_prev = 1;
+                }
+            } else {
+                ts->has_guess = 0;
+            }
+            ts->frame++;
+            if (P.state_out) {
+                double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+                for (int i = 0; i < 6; i++) so[i] = param[i];
+                so[AGT_ST_OK] = accepted ? 1.0 : 0.0; so[AGT_ST_ERR] = esum; so[AGT_ST_NTRACK] = n_used;
+                so[AGT_ST_ITERS] = iters; so[AGT_ST_GUESS] = use_guess ? 1.0 : 0.0; so[AGT_ST_FLAGS] = tflags;
+                so[AGT_ST_TVEC_F32] = tvec_f32 ? 1.0 : 0.0;
+                for (int i = AGT_ST_TVEC_F32 + 1; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
+            }
+        }
+        if (accepted && P.reproject && P.corners_rw) {
+            // refresh the whole corner set with projectPoints(all_objpts) (detect_pose.py:455-461)
+            double R[9], dRdr[27];
+            agt_rodrigues<false>(param, R, dRdr);
+            float* cw = P.corners_rw + (long)b * n * 2;
+            for (int i = lane; i < n; i += AGT_WAVE) {
+                double u, v;
+                agt_project<false>(cam, R, dRdr, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2],
+                                   u, v, nullptr, nullptr);
+                cw[i * 2] = (float)u; cw[i * 2 + 1] = (float)v;
+            }
+        }
+        return;
     }
     if (lane == 0) {
 #pragma unroll

@@ -218,8 +218,13 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
 
 def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None,
              useExtrinsicGuess=False, flags=SOLVEPNP_ITERATIVE):
-    """cv2.solvePnP(flags=SOLVEPNP_ITERATIVE) -> (ok, rvec (3,1) f64, tvec (3,1) f64).
-    Fresh arrays are returned; a supplied guess is NOT overwritten (SURVEY.md 8b 'Ownership')."""
+    """cv2.solvePnP(flags=SOLVEPNP_ITERATIVE) -> (ok, rvec (3,1), tvec (3,1)).
+
+    Without a guess the outputs are fresh float64 arrays.  With useExtrinsicGuess the result
+    is written INTO the supplied rvec/tvec ndarrays, in their own dtype, and those same
+    objects are returned -- cv2's observable behaviour, which the reference works around
+    with a deepcopy (detect_pose.py:487-490) and which makes a float32 guess tvec
+    (transform_helper.py:158-159) yield a float32 pose tvec."""
     _require_gpu()
     if flags != SOLVEPNP_ITERATIVE:
         raise error("solvePnP: only SOLVEPNP_ITERATIVE is built")
@@ -235,6 +240,8 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
     m = torch.from_numpy(np.ascontiguousarray(img, dtype=dt)).to(dev).reshape(1, n, 2)
     pose = torch.zeros((1, 6), dtype=torch.float64, device=dev)
     if useExtrinsicGuess:
+        if rvec is None or tvec is None or np.size(rvec) != 3 or np.size(tvec) != 3:
+            raise error("solvePnP: useExtrinsicGuess needs 3-element rvec and tvec")
         g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
         pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
     try:
@@ -247,6 +254,11 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
         if inf[H.INFO_FLAGS] & H.PNP_PLANAR:
             raise error("solvePnP: un-guessed solve on a planar point set is not built yet")
         raise error("solvePnP: not enough usable points")
+    if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
+            and rvec.dtype in (np.float32, np.float64) and tvec.dtype in (np.float32, np.float64):
+        rvec.reshape(-1)[:] = p[:3]
+        tvec.reshape(-1)[:] = p[3:]
+        return True, rvec, tvec
     return True, p[:3].reshape(3, 1).copy(), p[3:].reshape(3, 1).copy()
 
 

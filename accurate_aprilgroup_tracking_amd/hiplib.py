@@ -20,7 +20,7 @@ F32, F64 = 0, 1
 INFO_OK, INFO_ITERS, INFO_NUSED, INFO_FLAGS = 0, 1, 2, 3
 PNP_SINGULAR, PNP_PLANAR, PNP_TOO_FEW = 1, 2, 4
 STATE_STRIDE = 16
-ST_RVEC, ST_TVEC, ST_OK, ST_ERR, ST_NTRACK, ST_ITERS, ST_GUESS, ST_FLAGS = 0, 3, 6, 7, 8, 9, 10, 11
+ST_RVEC, ST_TVEC, ST_OK, ST_ERR, ST_NTRACK, ST_ITERS, ST_GUESS, ST_FLAGS, ST_TVEC_F32 = 0, 3, 6, 7, 8, 9, 10, 11, 12
 TRK_ZERO_VELOCITY = 256
 
 # every symbol include/agt_hip.h declares (tests check the .so exports all of them)
@@ -28,8 +28,8 @@ SYMBOLS = [
     "agt_version", "agt_error_string", "agt_create", "agt_destroy", "agt_set_stream",
     "agt_last_hip_error", "agt_synchronize", "agt_pyr_down_u8", "agt_pyramid_build",
     "agt_pyramid_level", "agt_pyramid_max_level", "agt_lk_track", "agt_solve_pnp",
-    "agt_project_points", "agt_tracker_reset", "agt_tracker_set_pose", "agt_track_frame",
-    "agt_tracker_buffers",
+    "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
+    "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
 ]
 
 
@@ -82,7 +82,10 @@ def lib():
     L.agt_solve_pnp.argtypes = [vp, vp, sz, vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp]
     L.agt_project_points.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, i32, vp, vp]
     L.agt_tracker_reset.argtypes = [vp, i32, vp, vp, i32, i32, vp, vp, i32, i32]
-    L.agt_tracker_set_pose.argtypes = [vp, vp, i32]
+    L.agt_tracker_options.argtypes = [vp, i32, i32, f64]
+    L.agt_estimate_pose.argtypes = [vp, vp, vp, i32, vp]
+    L.agt_tracker_state_size.restype = i32
+    L.agt_tracker_state_read.argtypes = [vp, vp, i32]
     L.agt_track_frame.argtypes = [vp, vp, sz, sz, i32, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     _lib = L

@@ -1,0 +1,92 @@
+"""StreamTracker: B independent streams tracked entirely on the device.
+
+One `step(frames)` = pyramid(new frames) -> LK(previous corners) -> solvePnP(guess) ->
+reprojection gate -> motion-model guess update, i.e. PoseDetector._estimate_pose
+(detect_pose.py:467-574) fed by LK-tracked corners, with the PoseDetector state
+(extrinsic_guess, prev_transform, velocity buffers) resident in HBM.  Four kernel launches
+per step, no host<->device copy and no synchronisation; read `state` back when convenient.
+"""
+import ctypes as C
+import numpy as np
+import torch
+
+from . import hiplib as H
+from .cv_hip import Context, _ptr, _host_f64
+
+
+class TrackState(C.Structure):
+    """Mirror of csrc/agt_kernels.h AgtTrackState (tests read it back)."""
+    _fields_ = [("guess", C.c_double * 6), ("prev", C.c_double * 6), ("rot_vel", (C.c_double * 9) * 2),
+                ("tran_vel", (C.c_double * 3) * 2), ("has_guess", C.c_int), ("has_prev", C.c_int),
+                ("n_vel", C.c_int), ("frame", C.c_int), ("guess_t_f32", C.c_int), ("prev_t_f32", C.c_int),
+                ("pad", C.c_int * 2)]
+
+
+class StreamTracker:
+    def __init__(self, width, height, obj_points, K, dist=None, n_streams=1, max_level=2, win=21,
+                 enhance_ape=True, reproject=False, min_points=8, gate_px=2.0, device=None):
+        obj = np.ascontiguousarray(np.asarray(obj_points, np.float32).reshape(-1, 3))
+        self.n = obj.shape[0]
+        self.B = n_streams
+        self.ctx = Context(width, height, max_level=max_level, win=win, max_points=max(self.n, 8),
+                           max_streams=n_streams, device=device)
+        self.dev = torch.device("cuda", self.ctx.device)
+        self.obj = torch.from_numpy(obj).to(self.dev)
+        self.K, _ = _host_f64(K)
+        self.dist, self.ndist = _host_f64(dist)
+        self.enhance_ape = bool(enhance_ape)
+        assert H.lib().agt_tracker_state_size() == C.sizeof(TrackState)
+        H.check(self.ctx.L.agt_tracker_options(self.ctx.h, int(reproject), int(min_points), float(gate_px)),
+                "agt_tracker_options")
+        self._frames = None
+        self._slot = 0
+
+    def _dist_ptr(self):
+        return self.dist.ctypes.data_as(C.c_void_p) if self.ndist else None
+
+    def reset(self, frames=None, corners=None):
+        """frames: cuda u8 [B,H,W] in which `corners` (cuda f32 [B,n,2]) were seen.  With both None
+        only `estimate_pose` (detector-supplied corners) can be used afterwards."""
+        self.ctx.use_current_stream()
+        if frames is not None:
+            self.ctx.pyramid_build(0, frames)
+            assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)
+        H.check(self.ctx.L.agt_tracker_reset(self.ctx.h, 0, _ptr(corners), _ptr(self.obj), self.n, self.B,
+                                             self.K.ctypes.data_as(C.c_void_p), self._dist_ptr(), self.ndist,
+                                             int(self.enhance_ape)), "agt_tracker_reset")
+        self._frames = frames
+        self._slot = 0
+
+    def step(self, frames, state_out=None):
+        """frames: cuda u8 [B,H,W] (kept alive until the following step).  state_out: cuda f64
+        [B, STATE_STRIDE] or None.  Enqueues only."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
+        H.check(self.ctx.L.agt_track_frame(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
+                                           _ptr(state_out)), "agt_track_frame")
+        self._prev_frames, self._frames = self._frames, frames     # level 0 of both slots aliases these
+        return state_out
+
+    def estimate_pose(self, corners, mask=None, state_out=None):
+        """PoseDetector._estimate_pose on device state with supplied corners (cuda f32 [B,n,2])."""
+        assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (self.B, self.n)
+        H.check(self.ctx.L.agt_estimate_pose(self.ctx.h, _ptr(corners), _ptr(mask), self.B, _ptr(state_out)),
+                "agt_estimate_pose")
+        return state_out
+
+    def new_state_buffer(self, frames=1):
+        shape = (frames, self.B, H.STATE_STRIDE) if frames > 1 else (self.B, H.STATE_STRIDE)
+        return torch.zeros(shape, dtype=torch.float64, device=self.dev)
+
+    def read_state(self):
+        """-> list of TrackState (synchronises)."""
+        buf = (TrackState * self.B)()
+        H.check(self.ctx.L.agt_tracker_state_read(self.ctx.h, C.byref(buf), self.B), "agt_tracker_state_read")
+        return list(buf)
+
+    def corners(self):
+        """current corner set and LK status as torch views are not exposed by pointer; copy out"""
+        cp, sp = C.c_void_p(), C.c_void_p()
+        H.check(self.ctx.L.agt_tracker_buffers(self.ctx.h, C.byref(cp), C.byref(sp)), "agt_tracker_buffers")
+        return cp.value, sp.value

@@ -10,7 +10,7 @@
  *                           /root/reference/aprilgroup_tracking/aprilgroup_pose_estimation/detect_pose.py:509-515 (no guess)
  *                           detect_pose.py:517-526 (useExtrinsicGuess=True)
  *   agt_project_points   <- cv.projectPoints      transform_helper.py:106-111, detect_pose.py:455-461
- *   agt_reproj_error     <- TransformHelper.get_reprojection_error   transform_helper.py:98-121
+ *   (d_err of agt_solve_pnp) <- TransformHelper.get_reprojection_error   transform_helper.py:98-121
  *   agt_pyramid_build /
  *   agt_lk_track         <- cv.calcOpticalFlowPyrLK (north-star step; no call site in the
  *                           reference, belongs at the hole detect_pose.py:573-574)
@@ -76,6 +76,7 @@ extern "C" {
 #define AGT_ST_ITERS   9    /* LM iterations */
 #define AGT_ST_GUESS   10   /* 1.0 = an extrinsic guess was used for this frame */
 #define AGT_ST_FLAGS   11   /* AGT_PNP_* bits | AGT_TRK_* bits */
+#define AGT_ST_TVEC_F32 12  /* 1.0 = tvec carries float32 precision (cv2 wrote it into the f32 guess array) */
 #define AGT_TRK_ZERO_VELOCITY 256  /* a velocity element was exactly 0: reference raises ValueError (detect_pose.py:236-237) */
 
 typedef struct agt_ctx agt_ctx;
@@ -148,11 +149,23 @@ int agt_project_points(agt_ctx* ctx, const void* d_obj, size_t obj_batch_stride,
  * extrinsic guess, prev_transform and the two-deep velocity buffers of
  * detect_pose.py:74-83, 229-349. */
 /* (Re)initialise streams [0,B): corners [B][n][2] f32 seen in the frames of `slot`
- * (already built), shared object points n x 3 f32, camera; clears guess and buffers. */
+ * (already built; NULL when only agt_estimate_pose will be used), shared object points
+ * n x 3 f32, camera; clears guess, prev_transform and the velocity buffers. */
 int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const float* d_obj, int n, int B,
                       const double* K, const double* dist, int ndist, int enhance_ape);
-/* Optionally seed the guess / prev_transform (e.g. from a detector-based solve). */
-int agt_tracker_set_pose(agt_ctx* ctx, const double* d_pose /* [B][6] */, int B);
+/* Tracker options: reproject != 0 -> after an accepted pose the corner set is refreshed with
+ * projectPoints(all object points) (the projection the reference draws, detect_pose.py:441-465),
+ * which revives lost corners and stops LK drift; 0 (default) chains raw LK outputs.
+ * min_points: corners needed to attempt a pose (default 8 = the reference's >= 2 tags, detect_pose.py:494-496).
+ * gate_px: reprojection gate (default 2.0, detect_pose.py:539). */
+int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate_px);
+/* PoseDetector._estimate_pose (detect_pose.py:467-574) for B streams with device-resident
+ * state: d_img [B][n][2] f32 corners (detector- or LK-supplied), d_mask [B][n] u8 or NULL.
+ * Needs agt_tracker_reset first (its corners argument may be NULL when only this entry is used). */
+int agt_estimate_pose(agt_ctx* ctx, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out);
+/* copy of the raw per-stream state records (AgtTrackState, see csrc/agt_kernels.h) for tests */
+int agt_tracker_state_size(void);
+int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronises the stream */
 /* One frame for B streams: pyramid(new frames) -> LK(prev corners) -> solvePnP(guess) ->
  * reprojection gate -> motion-model guess update.  d_state_out: [B][AGT_STATE_STRIDE] f64 or NULL
  * (device memory; read it back whenever convenient).  No host synchronisation. */

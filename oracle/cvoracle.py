@@ -230,7 +230,14 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
                                        1 if useExtrinsicGuess else 0, C.byref(it))
     if rc:
         raise ValueError("solvePnP oracle error %d" % rc)
-    out = (True, r.reshape(3, 1).copy(), t.reshape(3, 1).copy())
+    if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
+            and rvec.dtype in (np.float32, np.float64) and tvec.dtype in (np.float32, np.float64):
+        # cv2 writes the result into the guess arrays, in their dtype, and returns them
+        rvec.reshape(-1)[:] = r
+        tvec.reshape(-1)[:] = t
+        out = (True, rvec, tvec)
+    else:
+        out = (True, r.reshape(3, 1).copy(), t.reshape(3, 1).copy())
     return out + (it.value,) if return_iters else out
 
 

@@ -135,9 +135,11 @@ def test_solve_pnp_guess_and_dlt(cvh, oracle, seq640, seq640_dist, use_dist):
         assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
         # guess
         g_r = s.rvecs[k] + 0.02; g_t = (s.tvecs[k] + 0.003).astype(np.float32)
-        ok_o, r_o, t_o = oracle.solvePnP(obj32, img32, s.K, s.dist, g_r, g_t, True)
-        ok_g, r_g, t_g = cvh.solvePnP(obj32, img32, s.K, s.dist, g_r, g_t, True)
-        assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
+        ok_o, r_o, t_o = oracle.solvePnP(obj32, img32, s.K, s.dist, g_r.copy(), g_t.copy(), True)
+        gr2, gt2 = g_r.copy(), g_t.copy()
+        ok_g, r_g, t_g = cvh.solvePnP(obj32, img32, s.K, s.dist, gr2, gt2, True)
+        assert r_g is gr2 and t_g is gt2 and t_g.dtype == np.float32        # cv2 writes into the guess arrays
+        assert np.abs(r_o.ravel() - r_g.ravel()).max() < POSE_TOL and np.abs(t_o.ravel() - t_g.ravel()).max() < POSE_TOL
         # ground truth on the clean points
         assert np.abs(r_g.ravel() - s.rvecs[k]).max() < 5e-3
 
@@ -179,6 +181,7 @@ def test_solve_pnp_large_n(cvh, oracle):
     assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
     ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, syn.MILD_DIST, r + 0.03, t + 0.01, True)
     ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, syn.MILD_DIST, r + 0.03, t + 0.01, True)
+    r_o, t_o, r_g, t_g = r_o.ravel(), t_o.ravel(), r_g.ravel(), t_g.ravel()
     assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
 
 

@@ -1,0 +1,177 @@
+"""-m gpu: the device-resident _estimate_pose state machine and the fused per-frame step.
+
+  * agt_estimate_pose vs the fixtures produced by the REFERENCE's own Python state machine
+  * the PoseDetector mirror running on the HIP backend vs the same fixtures
+  * agt_track_frame (pyramid + LK + PnP + motion model, no host round trip) vs the same chain
+    assembled from oracle pieces
+Tolerance: POSE_TOL on poses/guesses (north_star bound 1e-4); LK corners bit-exact.
+"""
+import json
+import logging
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+POSE_TOL = 1e-8
+LOG = logging.getLogger("test"); LOG.setLevel(logging.CRITICAL)
+
+
+@pytest.fixture(scope="module")
+def torch_cuda():
+    import torch
+    assert torch.cuda.is_available()
+    return torch
+
+
+@pytest.mark.parametrize("name", ["reference_state_machine_enhanced.npz", "reference_state_machine_plain.npz"])
+def test_device_state_machine_matches_reference(torch_cuda, name):
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    fx = np.load(os.path.join(GOLD, name))
+    F, T = fx["tagmask"].shape
+    B = 3                                    # same stream replicated: exercises batching
+    trk = StreamTracker(1280, 720, fx["all_objpts"], fx["K"], fx["dist"], n_streams=B,
+                        enhance_ape=bool(int(fx["enhance_ape"])))
+    trk.reset()
+    so = trk.new_state_buffer()
+    for k in range(F):
+        img = torch.from_numpy(np.repeat(fx["corners"][k][None].astype(np.float32), B, 0)).cuda().contiguous()
+        mask = torch.from_numpy(np.repeat(np.repeat(fx["tagmask"][k], 4)[None].astype(np.uint8), B, 0)).cuda().contiguous()
+        trk.estimate_pose(img, mask, so)
+        st = so.cpu().numpy()
+        states = trk.read_state()
+        for b in range(B):
+            ok = int(st[b, H.ST_OK])
+            assert ok == fx["pose_valid"][k], "frame %d acceptance" % k
+            if ok:
+                assert np.abs(st[b, :6] - fx["pose"][k]).max() < POSE_TOL, "frame %d pose" % k
+                assert int(st[b, H.ST_TVEC_F32]) == fx["tvec_f32"][k]
+            s = states[b]
+            assert s.has_guess == fx["guess_valid"][k], "frame %d guess presence" % k
+            if s.has_guess:
+                assert np.abs(np.array(s.guess[:]) - fx["guess"][k]).max() < POSE_TOL, "frame %d guess" % k
+                assert s.guess_t_f32 == fx["guess_t_f32"][k]
+            assert s.n_vel == fx["n_vel"][k]
+            for i in range(s.n_vel):
+                assert np.abs(np.array(s.rot_vel[i][:]) - fx["rot_vel"][k][i]).max() < POSE_TOL
+                assert np.abs(np.array(s.tran_vel[i][:]) - fx["tran_vel"][k][i]).max() < POSE_TOL
+            if fx["prev_valid"][k]:
+                assert s.has_prev and np.abs(np.array(s.prev[:]) - fx["prev"][k]).max() < POSE_TOL
+
+
+@pytest.mark.parametrize("name", ["reference_state_machine_enhanced.npz"])
+def test_pose_detector_mirror_on_hip_backend(tmp_path, name):
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    fx = np.load(os.path.join(GOLD, name))
+    (tmp_path / "april_group.json").write_text(json.dumps(json.loads(str(fx["group_json"]))))
+
+    class Det(PoseDetector):
+        DIRPATH = str(tmp_path)
+    det = Det(LOG, fx["K"], fx["dist"], bool(int(fx["enhance_ape"])))      # default backend = cv_hip
+    assert det.cv.__name__.endswith("cv_hip")
+    tag_ids = sorted(det.extrinsics)
+    F, T = fx["tagmask"].shape
+    for k in range(F):
+        img_list, obj_list = [], []
+        for t, tid in enumerate(tag_ids):
+            if fx["tagmask"][k, t]:
+                size, tvec, rvec = det.extrinsics[tid][:3]
+                img_list.append(fx["corners"][k, 4 * t:4 * t + 4].reshape(1, 4, 2))
+                obj_list.append(det.transform_marker_corners(det.get_initial_pts(size), (rvec, tvec)))
+        before = det.prev_transform
+        det._estimate_pose(img_list, obj_list)
+        accepted = det.prev_transform is not before
+        assert int(accepted) == fx["pose_valid"][k]
+        if accepted:
+            pose = np.concatenate([det.prev_transform[0].ravel(), det.prev_transform[1].ravel()]).astype(np.float64)
+            assert np.abs(pose - fx["pose"][k]).max() < POSE_TOL
+            assert int(det.prev_transform[1].dtype == np.float32) == fx["tvec_f32"][k]
+        if det.extrinsic_guess[0] is not None:
+            g = np.concatenate([det.extrinsic_guess[0].ravel(), det.extrinsic_guess[1].ravel()]).astype(np.float64)
+            assert np.abs(g - fx["guess"][k]).max() < POSE_TOL
+
+
+@pytest.mark.parametrize("reproject", [False, True])
+def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, reproject):
+    """GPU: StreamTracker.step over rendered frames.  CPU: oracle LK + the (reference-validated)
+    PoseDetector mirror on the oracle backend, fed per-corner."""
+    torch = torch_cuda
+    from oracle import cv2_shim
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    F = len(s)
+    # reproject=True rounds the re-projected corners to float32: a 1e-10 pose difference can flip
+    # a corner by one float32 ulp (6e-5 px), which LK+PnP turn into ~1e-7 on the next pose.
+    tol = 1e-6 if reproject else POSE_TOL
+    frames = torch.from_numpy(s.frames()).cuda()                      # [F,H,W]
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2, reproject=reproject)
+    c0 = torch.from_numpy(np.stack([s.corners(0), s.corners(0)])).cuda().contiguous()
+    two = lambda k: torch.stack([frames[k], frames[k]]).contiguous()
+    f_prev = two(0)
+    trk.reset(f_prev, c0)
+    so = trk.new_state_buffer()
+
+    import tempfile
+    tmp = tempfile.mkdtemp()
+    open(os.path.join(tmp, "april_group.json"), "w").write(json.dumps(s.group))
+
+    class Det(PoseDetector):
+        DIRPATH = tmp
+    det = Det(LOG, s.K, None, True, cv=cv2_shim.make_cv2())
+    obj32 = s.obj.astype(np.float32)
+    pts = s.corners(0)
+    pyr = oracle.Pyramid(s.frame(0))
+    keep = [f_prev]
+    for k in range(1, F):
+        f = two(k); keep.append(f)
+        trk.step(f, so)
+        st = so.cpu().numpy()
+        npyr = oracle.Pyramid(s.frame(k))
+        nx, status, _ = oracle.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
+        nx = nx.reshape(-1, 2); status = status.ravel()
+        img_list = [nx[i].reshape(1, 1, 2) for i in range(48) if status[i]]
+        obj_list = [obj32[i].reshape(1, 3) for i in range(48) if status[i]]
+        det._estimate_pose(img_list if len(img_list) >= 8 else [], obj_list if len(img_list) >= 8 else [])
+        for b in range(2):
+            assert int(st[b, H.ST_NTRACK]) == int(status.sum())
+            assert int(st[b, H.ST_OK]) == int(det.last_error is not None and det.last_error < 2)
+            ref = np.concatenate([det.last_pose[0].ravel(), det.last_pose[1].ravel()]).astype(np.float64)
+            assert np.abs(st[b, :6] - ref).max() < tol, "frame %d" % k
+            assert abs(st[b, H.ST_ERR] - det.last_error) < 1e-4          # reference sums float32 norms
+            assert np.abs(st[b, :3] - s.rvecs[k]).max() < 3e-3 and np.abs(st[b, 3:6] - s.tvecs[k]).max() < 3e-3
+        if reproject and det.last_error is not None and det.last_error < 2:
+            pp, _ = oracle.projectPoints(s.obj, det.last_pose[0], det.last_pose[1], s.K, None)
+            pts = pp.reshape(-1, 2).astype(np.float32)
+        else:
+            pts = nx.astype(np.float32)
+        pyr = npyr
+    states = trk.read_state()
+    assert states[0].frame == F - 1 and states[0].has_guess == 1
+    g = np.concatenate([det.extrinsic_guess[0].ravel(), det.extrinsic_guess[1].ravel()]).astype(np.float64)
+    assert np.abs(np.array(states[1].guess[:]) - g).max() < 10 * tol
+
+
+def test_track_frame_argument_and_state_errors(torch_cuda):
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    obj = np.random.default_rng(0).uniform(-0.05, 0.05, (48, 3))
+    trk = StreamTracker(640, 480, obj, np.array([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]]), None, n_streams=1)
+    f = torch.zeros((1, 480, 640), dtype=torch.uint8, device="cuda")
+    with pytest.raises(H.AgtError):
+        trk.step(f)                                   # not reset
+    trk.reset()
+    with pytest.raises(H.AgtError):
+        trk.step(f)                                   # reset without corners: only estimate_pose allowed
+    # fewer than two tags' worth of corners -> guess cleared, no pose
+    so = trk.new_state_buffer()
+    m = torch.zeros((1, 48), dtype=torch.uint8, device="cuda"); m[0, :4] = 1
+    trk.estimate_pose(torch.zeros((1, 48, 2), dtype=torch.float32, device="cuda"), m, so)
+    st = so.cpu().numpy()
+    assert st[0, H.ST_OK] == 0 and int(st[0, H.ST_FLAGS]) & H.PNP_TOO_FEW and st[0, H.ST_NTRACK] == 4
