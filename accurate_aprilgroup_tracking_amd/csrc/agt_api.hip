@@ -29,6 +29,9 @@ struct agt_ctx {
     double gate_px;
     // LK parameters of the fused step (COUNT+EPS (30, 0.01), minEig 1e-4, flags 0)
     int lk_max_count; double lk_eps; double lk_min_eig;
+    // optional per-kernel timing (agt_profile_begin/end)
+    hipEvent_t* prof_ev;
+    int prof_cap, prof_n;
 };
 
 namespace {
@@ -131,6 +134,10 @@ int agt_destroy(agt_ctx* c)
     if (c->obj) (void)hipFree(c->obj);
     if (c->pose) (void)hipFree(c->pose);
     if (c->tstate) (void)hipFree(c->tstate);
+    if (c->prof_ev) {
+        for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
+        delete[] c->prof_ev;
+    }
     delete c;
     return AGT_OK;
 }
@@ -318,16 +325,57 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     if (c->trk_ready != 2) return AGT_ERR_STATE;
     if (B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
     const int prev_slot = c->trk_slot, next_slot = 1 - prev_slot;
+    hipEvent_t* ev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
+    if (ev) (void)hipEventRecord(ev[0], c->stream);
     int rc = agt_pyramid_build(c, next_slot, d_frames, pitch, batch_stride, B);
     if (rc) return rc;
+    if (ev) (void)hipEventRecord(ev[1], c->stream);
     const int cur = c->trk_cur, nxt = 1 - cur;
     rc = agt_lk_track(c, prev_slot, next_slot, c->corners[cur], c->corners[nxt], c->status, nullptr,
                       c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
+    if (ev) (void)hipEventRecord(ev[2], c->stream);
     rc = launch_estimate(c, c->corners[nxt], c->status, B, d_state_out, c->corners[nxt]);
     if (rc) return rc;
+    if (ev) { (void)hipEventRecord(ev[3], c->stream); c->prof_n++; }
     c->trk_slot = next_slot; c->trk_cur = nxt;
     return AGT_OK;
+}
+
+int agt_profile_begin(agt_ctx* c, int max_frames)
+{
+    if (!c || max_frames <= 0 || max_frames > (1 << 20) || c->prof_ev) return AGT_ERR_ARG;
+    const size_t n = (size_t)max_frames * AGT_PROF_EVENTS;
+    c->prof_ev = new (std::nothrow) hipEvent_t[n];
+    if (!c->prof_ev) return AGT_ERR_ALLOC;
+    for (size_t i = 0; i < n; i++) {
+        hipError_t e = hipEventCreate(&c->prof_ev[i]);
+        if (e != hipSuccess) {
+            for (size_t j = 0; j < i; j++) (void)hipEventDestroy(c->prof_ev[j]);
+            delete[] c->prof_ev; c->prof_ev = nullptr;
+            return hip_fail(c, e);
+        }
+    }
+    c->prof_cap = max_frames; c->prof_n = 0;
+    return AGT_OK;
+}
+
+int agt_profile_end(agt_ctx* c, float* ms_out, int* n_frames)
+{
+    if (!c || !c->prof_ev) return AGT_ERR_ARG;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    int rc = e == hipSuccess ? AGT_OK : hip_fail(c, e);
+    if (rc == AGT_OK && ms_out)
+        for (int f = 0; f < c->prof_n && rc == AGT_OK; f++)
+            for (int k = 0; k < AGT_PROF_SPANS; k++) {
+                hipEvent_t* ev = c->prof_ev + (size_t)f * AGT_PROF_EVENTS;
+                e = hipEventElapsedTime(&ms_out[f * AGT_PROF_SPANS + k], ev[k], ev[k + 1]);
+                if (e != hipSuccess) { rc = hip_fail(c, e); break; }
+            }
+    if (n_frames) *n_frames = c->prof_n;
+    for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
+    delete[] c->prof_ev; c->prof_ev = nullptr; c->prof_cap = c->prof_n = 0;
+    return rc;
 }
 
 int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }

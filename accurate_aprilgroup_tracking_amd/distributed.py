@@ -1,0 +1,59 @@
+"""Multi-GPU layout: streams are independent, so they shard across ranks with no data-path
+collective.  One process per GPU; rank r owns streams
+[r*S/W, (r+1)*S/W).  The only exchange is the gather of the 6-DoF poses, once per chunk of
+frames (64 B per stream-frame -> latency-bound; never per frame): one all_gather over
+RCCL/xGMI (backend "nccl" on ROCm), or gloo in the CPU tests.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank():
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def init(backend=None):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+    rank, local_rank, world = env_rank()
+    if world > 1 and not dist.is_initialized():
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_streams(n_streams, rank, world):
+    """Contiguous block of stream indices owned by `rank` (sizes differ by at most one)."""
+    base, rem = divmod(n_streams, world)
+    lo = rank * base + min(rank, rem)
+    return range(lo, lo + base + (1 if rank < rem else 0))
+
+
+def gather_poses(local, world=None):
+    """local: [frames, streams_local, 8] f64 (rvec 3, tvec 3, ok, frame index).  Returns
+    [world, frames, streams_local, 8] on every rank (equal shard sizes required), or
+    local[None] when not distributed."""
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return local.unsqueeze(0)
+    world = dist.get_world_size()
+    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous())
+    return out
+
+
+def barrier():
+    if dist.is_initialized() and dist.get_world_size() > 1:
+        dist.barrier()
+
+
+def max_over_ranks(value, device):
+    if not dist.is_initialized() or dist.get_world_size() == 1:
+        return value
+    t = torch.tensor([value], dtype=torch.float64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    return float(t.item())

@@ -22,6 +22,7 @@ PNP_SINGULAR, PNP_PLANAR, PNP_TOO_FEW = 1, 2, 4
 STATE_STRIDE = 16
 ST_RVEC, ST_TVEC, ST_OK, ST_ERR, ST_NTRACK, ST_ITERS, ST_GUESS, ST_FLAGS, ST_TVEC_F32 = 0, 3, 6, 7, 8, 9, 10, 11, 12
 TRK_ZERO_VELOCITY = 256
+PROF_SPANS = 3
 
 # every symbol include/agt_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -30,6 +31,7 @@ SYMBOLS = [
     "agt_pyramid_level", "agt_pyramid_max_level", "agt_lk_track", "agt_solve_pnp",
     "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
+    "agt_profile_begin", "agt_profile_end",
 ]
 
 
@@ -88,6 +90,8 @@ def lib():
     L.agt_tracker_state_read.argtypes = [vp, vp, i32]
     L.agt_track_frame.argtypes = [vp, vp, sz, sz, i32, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.agt_profile_begin.argtypes = [vp, i32]
+    L.agt_profile_end.argtypes = [vp, vp, C.POINTER(i32)]
     _lib = L
     return L
 

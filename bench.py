@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of the LK + iterative-PnP hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "c2"): ONE 1280x720 synthetic dodeca stream per GPU,
+12 tags / 48 corners, 3-level LK pyramid (maxLevel=2), 21x21 window, COUNT+EPS (30, 0.01),
+iterative PnP with the motion-model extrinsic guess.  A step = one frame of the stream:
+pyramid(new frame) -> LK(prev corners) -> solvePnP(guess) -> gate -> motion model, all on
+the device (agt_track_frame), frames already resident in HBM.
+
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3]
+    N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (contract: task prompt, section 4).
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+W, H, NTAGS, NPTS, LEVELS, WIN = 1280, 720, 12, 48, 3, 21
+
+
+def algorithmic_bytes():
+    """SURVEY.md 8d per-unit figures (1280x720, L=3, N=48), per launch of each kernel."""
+    pyr = sum((W >> l) * (H >> l) + (W >> (l + 1)) * (H >> (l + 1)) for l in range(LEVELS - 1))   # read l, write l+1
+    lk = NPTS * LEVELS * (24 * 24 + 32 * 32) + NPTS * (8 + 8 + 1 + 4)
+    pnp = NPTS * 20 + 48
+    return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + NPTS * LEVELS * 1600 + NPTS * 21}
+
+
+def pingpong(i, nf):
+    j = i % (2 * nf - 2)
+    return j if j < nf else 2 * nf - 2 - j
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=300)
+    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
+    ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (c2: 1, c3: 64)")
+    ap.add_argument("--render-frames", type=int, default=24)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from accurate_aprilgroup_tracking_amd import distributed as D
+    rank, local_rank, world = D.init()
+    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from accurate_aprilgroup_tracking_amd import hiplib as HL, synthetic as syn
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+
+    B = args.streams or (1 if args.workload == "c2" else 64)
+    K, Wm = args.steps, args.warmup
+    NF = args.render_frames
+
+    # ---- synthetic stream(s): render NF frames, lay a ping-pong sequence over an HBM ring
+    # that exceeds the 256 MiB Infinity Cache so every step reads cold addresses
+    t_r = time.time()
+    nseq = min(B, 4)
+    seqs = [syn.Sequence(W, H, n_tags=NTAGS, n_frames=NF, seed=1000 * rank + s, supersample=3) for s in range(nseq)]
+    rendered = np.stack([sq.frames() for sq in seqs], axis=1)          # [NF, nseq, H, W]
+    period = 2 * NF - 2
+    ring_slots = period * max(1, -(-(300 << 20) // (period * B * W * H)))
+    ring_slots = max(ring_slots, period)
+    ring = torch.empty((ring_slots, B, H, W), dtype=torch.uint8, device=dev)
+    src = torch.from_numpy(rendered).to(dev)
+    shifts = [(0, 0)] + [((7 * b) % 23 - 11, (5 * b) % 17 - 8) for b in range(1, B)]   # distinct streams from few renders
+    for i in range(ring_slots):
+        f = src[pingpong(i, NF)]
+        for b in range(B):
+            sq = b % nseq
+            dx, dy = shifts[b] if b >= nseq else (0, 0)
+            ring[i, b] = torch.roll(f[sq], shifts=(dy, dx), dims=(0, 1)) if (dx or dy) else f[sq]
+    corners0 = np.stack([seqs[b % nseq].corners(0) + (np.array(shifts[b], np.float32) if b >= nseq else 0) for b in range(B)])
+    render_s = time.time() - t_r
+
+    sq0 = seqs[0]
+    trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+
+    def run(n_steps, first, state):
+        for k in range(n_steps):
+            trk.step(ring[(first + k) % ring_slots], state[k] if state is not None else None)
+
+    total = Wm + K
+    state = torch.zeros((total, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
+    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+    run(Wm, 1, state[:Wm])
+    D.gather_poses(state[:Wm])                    # warm the communicator outside the timed region
+    torch.cuda.synchronize(); D.barrier()
+    t0 = time.perf_counter()
+    run(K, 1 + Wm, state[Wm:])
+    # the only collective: the per-frame state records (128 B per stream-frame), once per chunk of
+    # K frames.  state[Wm:] is already contiguous: no torch kernel runs inside the timed region.
+    gathered = D.gather_poses(state[Wm:])
+    torch.cuda.synchronize(); D.barrier()
+    dt = time.perf_counter() - t0
+    dt = D.max_over_ranks(dt, dev)
+    fps = world * B * K / dt
+
+    st = state.cpu().numpy()
+    accepted = float(st[Wm:, :, HL.ST_OK].mean())
+    iters = float(st[Wm:, :, HL.ST_ITERS].mean())
+
+    out = None
+    if rank == 0:
+        # ---- per-kernel durations with HIP events on the launch stream (second, instrumented pass)
+        M = min(K, 200)
+        trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+        run(Wm, 1, None)
+        HL.check(trk.ctx.L.agt_profile_begin(trk.ctx.h, M), "agt_profile_begin")
+        run(M, 1 + Wm, None)
+        ms = np.zeros((M, HL.PROF_SPANS), np.float32); nrec = C.c_int(0)
+        HL.check(trk.ctx.L.agt_profile_end(trk.ctx.h, ms.ctypes.data_as(C.c_void_p), C.byref(nrec)), "agt_profile_end")
+        span_us = ms[:nrec.value].mean(axis=0) * 1e3
+        ab = algorithmic_bytes()
+        names = ["pyramid", "lk", "pnp"]
+        dom = int(np.argmax(span_us))
+        launches = {"pyramid": LEVELS - 1, "lk": 1, "pnp": 1}[names[dom]]
+        kernel_us = float(span_us[dom]) / launches
+        achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
+        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down_kernel", "lk": "lk_kernel<21>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
+                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                "traffic": None, "avg_launch_us": round(kernel_us, 3),
+                "span_us": {n: round(float(v), 3) for n, v in zip(names, span_us)},
+                "frame_gbs": round(B * ab["frame"] * fps / (world * B) / 1e9, 3)}
+
+        cpu = None
+        pose_err = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu, pose_err = cpu_baseline(seqs[0], rendered[:, 0], st[:, 0], Wm, K, NF)
+        out = {"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(fps, 2), "unit": "frames/s",
+               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 5),
+               "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP)",
+               "data": "synthetic",
+               "config": {"workload": "%s: %d x 1280x720 stream(s) per GPU, 12 tags/48 corners, 3-level LK 21x21, "
+                                      "iterative PnP with motion-model guess" % (args.workload, B),
+                          "streams_per_gpu": B, "frames_resident": "HBM ring %d slots (%.0f MiB)" % (ring_slots, ring.numel() / 2**20),
+                          "parallelism": "stream-per-GPU x%d, RCCL all_gather of poses once" % world},
+               "roofline": roof, "cpu_baseline": cpu,
+               "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
+               "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape)}
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
+    """Reference CPU path stand-in ("port"): the oracle's cvo_track_frame (full padded pyramids,
+    full-frame Scharr image per level, per-point LK, FP64 LM) on ONE host core, on a bounded
+    sample of the same stream; plus the pose difference HIP vs CPU chain on identical frames."""
+    import logging, tempfile
+    from oracle import cvoracle as cvo, cv2_shim
+    from accurate_aprilgroup_tracking_amd import hiplib as HL
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    cvo.build()
+    # -- timing: ~10 s of CPU work
+    pyr = cvo.Pyramid(frames[0]); pts = seq.corners(0)
+    r, t = seq.rvecs[0].copy(), seq.tvecs[0].copy()
+    n = 0; t0 = time.perf_counter()
+    while True:
+        k = pingpong(n + 1, NF)
+        pyr, pts, stt, er, cnt, r, t = cvo.track_frame(pyr, frames[k], pts, seq.obj, seq.K, None, r, t, nthreads=1)
+        n += 1
+        if time.perf_counter() - t0 > 10.0 or n >= 4000:
+            break
+    dt = time.perf_counter() - t0
+    cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
+           "sample": "%d frames of the same 1280x720 stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores"
+                     % (n, dt, os.cpu_count())}
+    # -- parity: reference-validated state machine on the oracle backend over the first frames
+    tmp = tempfile.mkdtemp()
+    open(os.path.join(tmp, "april_group.json"), "w").write(json.dumps(seq.group))
+
+    class Det(PoseDetector):
+        DIRPATH = tmp
+    log = logging.getLogger("bench"); log.setLevel(logging.CRITICAL)
+    det = Det(log, seq.K, None, True, cv=cv2_shim.make_cv2())
+    obj32 = seq.obj.astype(np.float32)
+    pyr = cvo.Pyramid(frames[0]); pts = seq.corners(0)
+    nchk = min(Wm + K, 60)
+    dr = dtv = 0.0
+    for i in range(nchk):
+        npyr = cvo.Pyramid(frames[pingpong(i + 1, NF)])
+        nx, status, _ = cvo.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
+        nx = nx.reshape(-1, 2); status = status.ravel()
+        il = [nx[j].reshape(1, 1, 2) for j in range(len(nx)) if status[j]]
+        ol = [obj32[j].reshape(1, 3) for j in range(len(nx)) if status[j]]
+        det._estimate_pose(il if len(il) >= 8 else [], ol if len(il) >= 8 else [])
+        if det.last_pose[0] is not None and gpu_state[i, HL.ST_OK]:
+            dr = max(dr, float(np.linalg.norm(gpu_state[i, :3] - det.last_pose[0].ravel())))
+            dtv = max(dtv, float(np.linalg.norm(gpu_state[i, 3:6] - det.last_pose[1].ravel().astype(np.float64))))
+        pts = nx.astype(np.float32); pyr = npyr
+    return cpu, {"max_l2_drvec": dr, "max_l2_dtvec": dtv, "frames": nchk, "tolerance": 1e-4}
+
+
+if __name__ == "__main__":
+    main()

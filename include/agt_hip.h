@@ -171,6 +171,17 @@ int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronis
  * (device memory; read it back whenever convenient).  No host synchronisation. */
 int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out);
+/* ---- per-kernel timing of agt_track_frame with HIP events on the context's stream ---- */
+/* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its
+ * four launches (pyrDown L0->L1, pyrDown L1->L2.., LK, PnP) into the next of max_frames
+ * slots.  agt_profile_end synchronises, writes ms[frame][AGT_PROF_SPANS] and the number of
+ * frames recorded, and releases the events.  Recording perturbs timing: never leave it on
+ * in a throughput measurement. */
+#define AGT_PROF_EVENTS 4
+#define AGT_PROF_SPANS  3          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine */
+int agt_profile_begin(agt_ctx* ctx, int max_frames);
+int agt_profile_end(agt_ctx* ctx, float* ms_out, int* n_frames);
+
 /* device pointers to the live tracker buffers (corners [B][n][2] f32, status [B][n] u8) */
 int agt_tracker_buffers(const agt_ctx* ctx, const float** d_corners, const uint8_t** d_status);
 
