@@ -41,9 +41,11 @@ def gather_poses(local, world=None):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return local.unsqueeze(0)
     world = dist.get_world_size()
-    out = torch.empty((world,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-    dist.all_gather_into_tensor(out, local.contiguous())
-    return out
+    local = local.contiguous()
+    # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, ...]
+    out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local)
+    return out.view((world,) + tuple(local.shape))
 
 
 def barrier():
