@@ -31,20 +31,32 @@ __global__ __launch_bounds__(NT) void pyr_down_kernel(const uint8_t* __restrict_
     uint8_t* out = dst + (long)blockIdx.z * dbatch;
     const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
 
-    // ---- stage the source tile (aligned dwords; per-byte reflect only at the image edge)
-    for (int i = tid; i < SH * (SW / 4); i += NT) {
-        const int r = i / (SW / 4), c4 = i - r * (SW / 4);
-        const int gy = agt_reflect101(sy0 + r, sh);
-        const int gx = sx0 + 4 * c4;
-        const uint8_t* row = img + (long)gy * spitch;
-        uint32_t v;
-        if (gx >= 0 && gx + 3 < sw) {
-            v = *reinterpret_cast<const uint32_t*>(row + gx);
-        } else {
-            v = (uint32_t)row[agt_reflect101(gx, sw)] | ((uint32_t)row[agt_reflect101(gx + 1, sw)] << 8) |
-                ((uint32_t)row[agt_reflect101(gx + 2, sw)] << 16) | ((uint32_t)row[agt_reflect101(gx + 3, sw)] << 24);
+    // ---- stage the source tile: all of a thread's loads are issued before any is consumed
+    // (aligned dwords; per-byte reflect only at the image edge)
+    constexpr int NLD = (SH * (SW / 4) + NT - 1) / NT;
+    uint32_t regs[NLD];
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = tid + k * NT;
+        uint32_t v = 0;
+        if (i < SH * (SW / 4)) {
+            const int r = i / (SW / 4), c4 = i - r * (SW / 4);
+            const int gy = agt_reflect101(sy0 + r, sh);
+            const int gx = sx0 + 4 * c4;
+            const uint8_t* row = img + (long)gy * spitch;
+            if (gx >= 0 && gx + 3 < sw) {
+                v = *reinterpret_cast<const uint32_t*>(row + gx);
+            } else {
+                v = (uint32_t)row[agt_reflect101(gx, sw)] | ((uint32_t)row[agt_reflect101(gx + 1, sw)] << 8) |
+                    ((uint32_t)row[agt_reflect101(gx + 2, sw)] << 16) | ((uint32_t)row[agt_reflect101(gx + 3, sw)] << 24);
+            }
         }
-        *reinterpret_cast<uint32_t*>(&s_src[r * SW + 4 * c4]) = v;
+        regs[k] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NLD; k++) {
+        const int i = tid + k * NT;
+        if (i < SH * (SW / 4)) *reinterpret_cast<uint32_t*>(&s_src[4 * i]) = regs[k];
     }
     __syncthreads();
 

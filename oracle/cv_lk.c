@@ -228,6 +228,10 @@ struct lk_level_ctx {
     int acc_mode;
 };
 
+/* development counters (not thread-safe; read with nthreads=1): iterations and points per level */
+long cvo_dbg_iters[CVO_MAX_LEVELS], cvo_dbg_points[CVO_MAX_LEVELS];
+void cvo_dbg_reset(void) { memset(cvo_dbg_iters, 0, sizeof(cvo_dbg_iters)); memset(cvo_dbg_points, 0, sizeof(cvo_dbg_points)); }
+
 /* LKTrackerInvoker::operator() for one point */
 static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, float* next_pts,
                            uint8_t* status, float* err, int ptidx, int16_t* patch /* 3*win area */)
@@ -304,7 +308,9 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
 
     nextx -= halfx; nexty -= halfy;
     float pdx = 0, pdy = 0;
+    cvo_dbg_points[level]++;
     for (int j = 0; j < c->max_count; j++) {
+        cvo_dbg_iters[level]++;
         int inx = cv_floor_f(nextx), iny = cv_floor_f(nexty);
         if (inx < -ww || inx >= Jcols || iny < -wh || iny >= Jrows) {
             if (level == 0) status[ptidx] = 0;

@@ -110,6 +110,25 @@ def test_lk_random_texture_other_sizes(cvh, oracle):
         assert np.abs(np.median(d, axis=0) - np.array([-2.1, 1.3])).max() < 0.1
 
 
+def test_lk_large_batch_single_wave_path(torch_cuda, cvh, oracle, seq640):
+    """n*B > 1024 selects the one-wave-per-corner kernel; every stream must still be bit-exact"""
+    torch = torch_cuda
+    s = seq640
+    B, n = 24, 48
+    ks = [(b % 4, b % 4 + 1 + (b // 4) % 2) for b in range(B)]          # frame pairs (k0 -> k1), 1- and 2-frame gaps
+    f0 = torch.from_numpy(np.stack([s.frame(a) for a, _ in ks])).cuda().contiguous()
+    f1 = torch.from_numpy(np.stack([s.frame(min(c, len(s) - 1)) for _, c in ks])).cuda().contiguous()
+    pts = np.stack([s.corners(a) for a, _ in ks])
+    pts[:, 40:] += np.random.default_rng(1).uniform(-300, 300, (B, 8, 2)).astype(np.float32)   # some points off the tags / off the image
+    ctx = cvh.Context(s.width, s.height, max_level=2, max_points=n, max_streams=B)
+    ctx.pyramid_build(0, f0); ctx.pyramid_build(1, f1)
+    nx, st, er = ctx.lk_track(0, 1, torch.from_numpy(pts).cuda().contiguous())
+    nx, st, er = nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+    for b, (a, c) in enumerate(ks):
+        o = oracle.calcOpticalFlowPyrLK(s.frame(a), s.frame(min(c, len(s) - 1)), pts[b], maxLevel=2)
+        _assert_lk_equal(o, (nx[b].reshape(-1, 1, 2), st[b].reshape(-1, 1), er[b].reshape(-1, 1)))
+
+
 def test_project_points(cvh, oracle, seq640_dist):
     s = seq640_dist
     for dt in (np.float64, np.float32):
