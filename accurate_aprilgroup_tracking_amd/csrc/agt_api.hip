@@ -5,6 +5,8 @@
 #include <new>
 #include <string.h>
 
+#define AGT_SLOTS 4
+
 struct agt_ctx {
     agt_config cfg;
     hipStream_t stream;
@@ -12,19 +14,25 @@ struct agt_ctx {
     int eff_max_level;                       // after OpenCV's early stop
     int lw[AGT_MAX_LEVELS], lh[AGT_MAX_LEVELS];
     long lpitch[AGT_MAX_LEVELS];             // levels >= 1 (context-owned)
-    uint8_t* lmem[2][AGT_MAX_LEVELS];
-    const uint8_t* l0_ptr[2];
-    long l0_pitch[2], l0_bstride[2];
-    int built_B[2];
-    // tracker
-    float* corners[2];                       // ping-pong [B][n][2]
-    uint8_t* status;                         // [B][n]
+    uint8_t* lmem[AGT_SLOTS][AGT_MAX_LEVELS];
+    const uint8_t* l0_ptr[AGT_SLOTS];
+    long l0_pitch[AGT_SLOTS], l0_bstride[AGT_SLOTS];
+    int built_B[AGT_SLOTS];
+    // tracker: rings of 4 (frame t lives in entry t % 4) so that one fused launch can work on
+    // pyramid stage s of frame t-s, LK of frame t-(L-1) and PnP of frame t-L at once
+    float* corners[AGT_SLOTS];               // [B][n][2]
+    uint8_t* status[AGT_SLOTS];              // [B][n]
+    double* so_ring[AGT_SLOTS];              // caller's state_out of the frames in flight
+    int pipeline;                            // 1 = software-pipelined fused step (agt_step.hip)
+    long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
+    long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
+    long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
     float* lkerr;                            // [B][n]
     float* obj;                              // [n][3]
     double* pose;                            // [B][6]
     AgtTrackState* tstate;                   // [B]
     AgtCameraHost cam;
-    int trk_n, trk_B, trk_slot, trk_cur, enhance_ape, trk_ready;
+    int trk_n, trk_B, enhance_ape, trk_ready;
     int reproject, min_points;
     double gate_px;
     // LK parameters of the fused step (COUNT+EPS (30, 0.01), minEig 1e-4, flags 0)
@@ -104,18 +112,18 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     }
     const size_t B = (size_t)cfg->max_streams, N = (size_t)cfg->max_points;
     bool ok = true;
-    for (int s = 0; s < 2 && ok; s++)
+    for (int s = 0; s < AGT_SLOTS && ok; s++) {
         for (int l = 1; l <= c->eff_max_level && ok; l++)
             ok = hipMalloc((void**)&c->lmem[s][l], B * (size_t)c->lh[l] * (size_t)c->lpitch[l]) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->corners[0], B * N * 2 * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->corners[1], B * N * 2 * sizeof(float)) == hipSuccess;
-    ok = ok && hipMalloc((void**)&c->status, B * N) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->corners[s], B * N * 2 * sizeof(float)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->status[s], B * N) == hipSuccess;
+    }
     ok = ok && hipMalloc((void**)&c->lkerr, B * N * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->obj, N * 3 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
-    c->built_B[0] = c->built_B[1] = 0;
+    c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
     *out = c;
@@ -125,11 +133,12 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
 int agt_destroy(agt_ctx* c)
 {
     if (!c) return AGT_OK;
-    for (int s = 0; s < 2; s++)
+    (void)hipStreamSynchronize(c->stream);
+    for (int s = 0; s < AGT_SLOTS; s++) {
         for (int l = 1; l < AGT_MAX_LEVELS; l++) if (c->lmem[s][l]) (void)hipFree(c->lmem[s][l]);
-    if (c->corners[0]) (void)hipFree(c->corners[0]);
-    if (c->corners[1]) (void)hipFree(c->corners[1]);
-    if (c->status) (void)hipFree(c->status);
+        if (c->corners[s]) (void)hipFree(c->corners[s]);
+        if (c->status[s]) (void)hipFree(c->status[s]);
+    }
     if (c->lkerr) (void)hipFree(c->lkerr);
     if (c->obj) (void)hipFree(c->obj);
     if (c->pose) (void)hipFree(c->pose);
@@ -154,6 +163,8 @@ int agt_last_hip_error(const agt_ctx* c) { return c ? c->last_hip : g_last_hip; 
 int agt_synchronize(agt_ctx* c)
 {
     if (!c) return AGT_ERR_ARG;
+    int rc = agt_tracker_join(c);            // flush frames still inside the software pipeline
+    if (rc) return rc;
     hipError_t e = hipStreamSynchronize(c->stream);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
@@ -168,15 +179,15 @@ int agt_pyr_down_u8(agt_ctx* c, const uint8_t* d_src, int sw, int sh, size_t spi
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
-int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
+static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
 {
-    if (!c || !d_frames || slot < 0 || slot > 1 || B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
+    if (!c || !d_frames || slot < 0 || slot >= AGT_SLOTS || B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
     if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
     for (int l = 1; l <= c->eff_max_level; l++) {
         const long db = (long)c->lh[l] * c->lpitch[l];
-        hipError_t e = agt_launch_pyr_down(c->stream, src, c->lw[l - 1], c->lh[l - 1], sp, sb, c->lmem[slot][l], c->lpitch[l], db, B);
+        hipError_t e = agt_launch_pyr_down(stream, src, c->lw[l - 1], c->lh[l - 1], sp, sb, c->lmem[slot][l], c->lpitch[l], db, B);
         if (e != hipSuccess) return hip_fail(c, e);
         src = c->lmem[slot][l]; sp = c->lpitch[l]; sb = db;
     }
@@ -184,12 +195,18 @@ int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitc
     return AGT_OK;
 }
 
+int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
+{
+    if (!c || slot < 0 || slot > 1) return AGT_ERR_ARG;
+    return pyramid_build_on(c, c->stream, slot, d_frames, pitch, batch_stride, B);
+}
+
 int agt_pyramid_max_level(const agt_ctx* c) { return c ? c->eff_max_level : AGT_ERR_ARG; }
 
 int agt_pyramid_level(const agt_ctx* c, int slot, int level, const uint8_t** d_ptr,
                       int* w, int* h, size_t* pitch, size_t* batch_stride)
 {
-    if (!c || slot < 0 || slot > 1 || level < 0 || level > c->eff_max_level) return AGT_ERR_ARG;
+    if (!c || slot < 0 || slot >= AGT_SLOTS || level < 0 || level > c->eff_max_level) return AGT_ERR_ARG;
     if (c->built_B[slot] <= 0) return AGT_ERR_STATE;
     if (d_ptr) *d_ptr = level == 0 ? c->l0_ptr[slot] : c->lmem[slot][level];
     if (w) *w = c->lw[level];
@@ -208,13 +225,13 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
     }
 }
 
-int agt_lk_track(agt_ctx* c, int prev_slot, int next_slot,
-                 const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
-                 int n, int B, int crit_type, int crit_max_count, double crit_eps,
-                 int flags, double min_eig_threshold)
+static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
+                       const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                       int n, int B, int crit_type, int crit_max_count, double crit_eps,
+                       int flags, double min_eig_threshold)
 {
     if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
-    if (prev_slot < 0 || prev_slot > 1 || next_slot < 0 || next_slot > 1) return AGT_ERR_ARG;
+    if (prev_slot < 0 || prev_slot >= AGT_SLOTS || next_slot < 0 || next_slot >= AGT_SLOTS) return AGT_ERR_ARG;
     if (n < 0 || B <= 0) return AGT_ERR_ARG;
     if (n == 0) return AGT_OK;
     if (c->built_B[prev_slot] < B || c->built_B[next_slot] < B) return AGT_ERR_STATE;
@@ -231,8 +248,18 @@ int agt_lk_track(agt_ctx* c, int prev_slot, int next_slot,
     p.flags = flags;
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
-    hipError_t e = agt_launch_lk(c->stream, p, c->cfg.win, B);
+    hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_lk_track(agt_ctx* c, int prev_slot, int next_slot,
+                 const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                 int n, int B, int crit_type, int crit_max_count, double crit_eps,
+                 int flags, double min_eig_threshold)
+{
+    if (!c || prev_slot < 0 || prev_slot > 1 || next_slot < 0 || next_slot > 1) return AGT_ERR_ARG;
+    return lk_track_on(c, c->stream, prev_slot, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, B,
+                       crit_type, crit_max_count, crit_eps, flags, min_eig_threshold);
 }
 
 int agt_solve_pnp(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, const void* d_img, int dtype,
@@ -281,12 +308,19 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     int rc = fill_camera(K, dist, ndist, &c->cam);
     if (rc) return rc;
     hipError_t e = hipSuccess;
+    // the tracker's frame 0 lives in ring entry 0: adopt the caller's slot as pyramid slot 0
+    if (d_corners && slot != 0) {
+        for (int l = 1; l <= c->eff_max_level; l++) { uint8_t* t = c->lmem[0][l]; c->lmem[0][l] = c->lmem[slot][l]; c->lmem[slot][l] = t; }
+        c->l0_ptr[0] = c->l0_ptr[slot]; c->l0_pitch[0] = c->l0_pitch[slot]; c->l0_bstride[0] = c->l0_bstride[slot];
+        c->built_B[0] = c->built_B[slot]; c->built_B[slot] = 0;
+    }
     if (d_corners) e = hipMemcpyAsync(c->corners[0], d_corners, (size_t)B * n * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
-    if (e == hipSuccess) e = hipMemsetAsync(c->status, 1, (size_t)B * n, c->stream);
+    for (int s = 0; s < AGT_SLOTS && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
     if (e != hipSuccess) return hip_fail(c, e);
-    c->trk_n = n; c->trk_B = B; c->trk_slot = slot; c->trk_cur = 0; c->enhance_ape = enhance_ape ? 1 : 0;
+    c->trk_n = n; c->trk_B = B; c->trk_frame = 0; c->n_lk = c->n_pnp = 0; c->enhance_ape = enhance_ape ? 1 : 0;
+    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = 0;
     c->trk_ready = d_corners ? 2 : 1;
     return AGT_OK;
 }
@@ -294,20 +328,122 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
 int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_px)
 {
     if (!c || min_points < 6 || min_points > 256 || !(gate_px > 0.0)) return AGT_ERR_ARG;
+    int rc = agt_tracker_join(c);
+    if (rc) return rc;
     c->reproject = reproject ? 1 : 0; c->min_points = min_points; c->gate_px = gate_px;
     return AGT_OK;
 }
 
-static int launch_estimate(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out, float* corners_rw)
+int agt_tracker_pipeline(agt_ctx* c, int enable)
 {
-    AgtPnpParams p;
-    memset(&p, 0, sizeof(p));
-    p.obj = c->obj; p.obj_bstride = 0; p.img = d_img; p.mask = d_mask; p.dtype = AGT_F32;
-    p.n = c->trk_n; p.cam = c->cam; p.pose = c->pose;
-    p.track = c->tstate; p.state_out = d_state_out; p.corners_rw = corners_rw;
-    p.enhance_ape = c->enhance_ape; p.reproject = c->reproject; p.min_points = c->min_points; p.gate_px = c->gate_px;
-    hipError_t e = agt_launch_pnp(c->stream, p, B);
+    if (!c) return AGT_ERR_ARG;
+    if (enable && !agt_step_supported(c->cfg.win)) return AGT_ERR_UNSUPPORTED;
+    int rc = agt_tracker_join(c);
+    if (rc) return rc;
+    c->pipeline = enable ? 1 : 0;
+    return AGT_OK;
+}
+
+static void fill_estimate(const agt_ctx* c, AgtPnpParams* p, const float* d_img, const uint8_t* d_mask,
+                          double* d_state_out, float* corners_rw)
+{
+    memset(p, 0, sizeof(*p));
+    p->obj = c->obj; p->obj_bstride = 0; p->img = d_img; p->mask = d_mask; p->dtype = AGT_F32;
+    p->n = c->trk_n; p->cam = c->cam; p->pose = c->pose;
+    p->track = c->tstate; p->state_out = d_state_out; p->corners_rw = corners_rw;
+    p->enhance_ape = c->enhance_ape; p->reproject = c->reproject; p->min_points = c->min_points; p->gate_px = c->gate_px;
+}
+
+static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slot, const float* d_prev, float* d_next,
+                   uint8_t* d_status, float* d_err, int n, int crit_type, int crit_max_count, double crit_eps,
+                   int flags, double min_eig_threshold)
+{
+    memset(p, 0, sizeof(*p));
+    fill_levels(c, prev_slot, p->prev);
+    fill_levels(c, next_slot, p->next);
+    p->max_level = c->eff_max_level;
+    p->n = n;
+    // SparsePyrLKOpticalFlowImpl::calc criteria normalisation
+    p->max_count = (crit_type & AGT_TERM_COUNT) ? (crit_max_count < 0 ? 0 : crit_max_count > 100 ? 100 : crit_max_count) : 30;
+    double eps = (crit_type & AGT_TERM_EPS) ? (crit_eps < 0. ? 0. : crit_eps > 10. ? 10. : crit_eps) : 0.01;
+    p->eps2 = eps * eps;
+    p->flags = flags;
+    p->min_eig_threshold = min_eig_threshold;
+    p->prev_pts = d_prev; p->next_pts = d_next; p->status = d_status; p->err = d_err;
+    return AGT_OK;
+}
+
+// One fused launch: every pipeline stage advances by one frame if its input is complete.
+// d_frames != NULL supplies frame T+1 (its L0->L1 stage runs in this launch).
+static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+{
+    const int L = c->eff_max_level;              // pyramid stages 0..L-1 (stage s: level s -> s+1)
+    AgtStepParams S;
+    memset(&S, 0, sizeof(S));
+    long done_before[AGT_MAX_LEVELS + 1];        // [s] = frames available as input of stage s (s = L: input of LK)
+    done_before[0] = c->trk_frame;
+    for (int s = 0; s < L; s++) done_before[s + 1] = c->n_stage[s];
+    const long lk_before = c->n_lk;
+    bool any = false;
+    if (d_frames) {
+        const long t = c->trk_frame + 1;
+        const int slot = (int)(t % AGT_SLOTS);
+        c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
+        c->built_B[slot] = B;
+        c->so_ring[slot] = d_state_out;
+        c->trk_frame = t;
+        done_before[0] = t;                      // the new frame is stage 0's input in this very launch
+        any = true;
+    }
+    for (int s = 0; s < L; s++) {
+        if (c->n_stage[s] >= done_before[s]) continue;
+        const long f = c->n_stage[s] + 1;
+        const int slot = (int)(f % AGT_SLOTS);
+        AgtPyrArgs& A = S.pyr[s];
+        if (s == 0) { A.src = c->l0_ptr[slot]; A.spitch = c->l0_pitch[slot]; A.sbatch = c->l0_bstride[slot]; }
+        else { A.src = c->lmem[slot][s]; A.spitch = c->lpitch[s]; A.sbatch = (long)c->lh[s] * c->lpitch[s]; }
+        A.sw = c->lw[s]; A.sh = c->lh[s];
+        A.dst = c->lmem[slot][s + 1]; A.dw = c->lw[s + 1]; A.dh = c->lh[s + 1];
+        A.dpitch = c->lpitch[s + 1]; A.dbatch = (long)c->lh[s + 1] * c->lpitch[s + 1];
+        agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
+        A.B = B;
+        S.n_pyr[s] = A.gx * A.gy * B;
+        c->n_stage[s] = f;
+        any = true;
+    }
+    if (c->n_lk < done_before[L]) {
+        const long f = c->n_lk + 1;
+        const int slot = (int)(f % AGT_SLOTS), pslot = (int)((f - 1) % AGT_SLOTS);
+        fill_lk(c, &S.lk, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr, c->trk_n,
+                AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+        S.n_lk = 1; S.lk_B = B;
+        c->n_lk = f;
+        any = true;
+    }
+    if (c->n_pnp < lk_before) {
+        const long f = c->n_pnp + 1;
+        const int slot = (int)(f % AGT_SLOTS);
+        fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
+        S.n_pnp = B;
+        c->n_pnp = f;
+        any = true;
+    }
+    if (!any) return AGT_OK;
+    hipError_t e = agt_launch_step(c->stream, S, c->cfg.win);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// Drain the software pipeline: enqueue the remaining stages of every frame supplied so far.
+// (Enqueue only; the results are ordered on the context's stream like any other work.)
+int agt_tracker_join(agt_ctx* c)
+{
+    if (!c) return AGT_ERR_ARG;
+    if (c->trk_ready != 2) return AGT_OK;
+    while (c->n_pnp < c->trk_frame) {
+        int rc = step_pipelined(c, nullptr, 0, 0, c->trk_B, nullptr);
+        if (rc) return rc;
+    }
+    return AGT_OK;
 }
 
 int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out)
@@ -315,30 +451,72 @@ int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int
     if (!c || !d_img) return AGT_ERR_ARG;
     if (!c->trk_ready) return AGT_ERR_STATE;
     if (B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
-    return launch_estimate(c, d_img, d_mask, B, d_state_out, nullptr);
+    int rc = agt_tracker_join(c);            // state updates of frames in flight come first
+    if (rc) return rc;
+    AgtPnpParams p;
+    fill_estimate(c, &p, d_img, d_mask, d_state_out, nullptr);
+    hipError_t e = agt_launch_pnp(c->stream, p, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
+// One frame for B streams.
+//   pipeline on  (default, needs reproject == 0): ONE fused launch; frame t's pose is produced
+//                 L+1 launches later (or by agt_tracker_join / agt_synchronize).
+//   pipeline off : pyrDown.. -> LK -> PnP as separate launches, pose complete in stream order.
 int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out)
 {
     if (!c || !d_frames) return AGT_ERR_ARG;
     if (c->trk_ready != 2) return AGT_ERR_STATE;
-    if (B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
-    const int prev_slot = c->trk_slot, next_slot = 1 - prev_slot;
-    hipEvent_t* ev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
-    if (ev) (void)hipEventRecord(ev[0], c->stream);
-    int rc = agt_pyramid_build(c, next_slot, d_frames, pitch, batch_stride, B);
+    if (B <= 0 || B != c->trk_B) return AGT_ERR_ARG;
+    if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
+    hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
+    // the fused launch pays off while the stages are latency-bound (few streams); big batches fill
+    // the chip per stage and run faster as separate launches with their own register budgets
+    if (c->pipeline && !c->reproject && !c->prof_ev && (long)c->trk_n * B <= 128)
+        return step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);
+
+    int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first
     if (rc) return rc;
-    if (ev) (void)hipEventRecord(ev[1], c->stream);
-    const int cur = c->trk_cur, nxt = 1 - cur;
-    rc = agt_lk_track(c, prev_slot, next_slot, c->corners[cur], c->corners[nxt], c->status, nullptr,
-                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+    const long t = c->trk_frame + 1;
+    const int slot = (int)(t % AGT_SLOTS), pslot = (int)((t - 1) % AGT_SLOTS);
+    hipStream_t M = c->stream;
+    if (pev) (void)hipEventRecord(pev[0], M);
+    rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
     if (rc) return rc;
-    if (ev) (void)hipEventRecord(ev[2], c->stream);
-    rc = launch_estimate(c, c->corners[nxt], c->status, B, d_state_out, c->corners[nxt]);
+    if (pev) (void)hipEventRecord(pev[1], M);
+    rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr,
+                     c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
-    if (ev) { (void)hipEventRecord(ev[3], c->stream); c->prof_n++; }
-    c->trk_slot = next_slot; c->trk_cur = nxt;
+    if (pev) (void)hipEventRecord(pev[2], M);
+    AgtPnpParams p;
+    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot]);
+    hipError_t e = agt_launch_pnp(M, p, B);
+    if (e != hipSuccess) return hip_fail(c, e);
+    if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
+    c->trk_frame = t; c->n_lk = c->n_pnp = t;
+    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
+    return AGT_OK;
+}
+
+int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }
+
+int agt_tracker_state_read(agt_ctx* c, void* host_dst, int B)
+{
+    if (!c || !host_dst || !c->trk_ready || B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
+    int rc = agt_tracker_join(c);
+    if (rc) return rc;
+    hipError_t e = hipMemcpyAsync(host_dst, c->tstate, (size_t)B * sizeof(AgtTrackState), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// valid after agt_tracker_join: the newest frame's corner set and LK status
+int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t** d_status)
+{
+    if (!c || !c->trk_ready) return AGT_ERR_STATE;
+    if (d_corners) *d_corners = c->corners[c->trk_frame % AGT_SLOTS];
+    if (d_status) *d_status = c->status[c->trk_frame % AGT_SLOTS];
     return AGT_OK;
 }
 
@@ -376,24 +554,6 @@ int agt_profile_end(agt_ctx* c, float* ms_out, int* n_frames)
     for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
     delete[] c->prof_ev; c->prof_ev = nullptr; c->prof_cap = c->prof_n = 0;
     return rc;
-}
-
-int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }
-
-int agt_tracker_state_read(agt_ctx* c, void* host_dst, int B)
-{
-    if (!c || !host_dst || !c->trk_ready || B <= 0 || B > c->trk_B) return AGT_ERR_ARG;
-    hipError_t e = hipMemcpyAsync(host_dst, c->tstate, (size_t)B * sizeof(AgtTrackState), hipMemcpyDeviceToHost, c->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
-}
-
-int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t** d_status)
-{
-    if (!c || !c->trk_ready) return AGT_ERR_STATE;
-    if (d_corners) *d_corners = c->corners[c->trk_cur];
-    if (d_status) *d_status = c->status;
-    return AGT_OK;
 }
 
 }  // extern "C"

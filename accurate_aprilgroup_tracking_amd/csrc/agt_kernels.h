@@ -11,6 +11,14 @@ struct AgtLevel {
     int w, h;
 };
 
+struct AgtPyrArgs {
+    const uint8_t* src; uint8_t* dst;
+    long spitch, sbatch, dpitch, dbatch;
+    int sw, sh, dw, dh;
+    int gx, gy, B;            // tile grid (x, y) and images
+    int pad;
+};
+
 struct AgtLkParams {
     AgtLevel prev[AGT_MAX_LEVELS];
     AgtLevel next[AGT_MAX_LEVELS];
@@ -70,6 +78,17 @@ struct AgtTrackState {
     int pad[2];
 };
 
+// one fused per-frame launch (agt_step.hip): block ranges [pyr stage 0 | stage 1 | .. | LK | PnP]
+struct AgtStepParams {
+    AgtPyrArgs pyr[AGT_MAX_LEVELS - 1];
+    int n_pyr[AGT_MAX_LEVELS - 1];    // blocks of each pyramid stage (0 = stage idle this step)
+    AgtLkParams lk;
+    int n_lk;                         // != 0: LK role active (block count is derived at launch)
+    int lk_B;                         // streams of the LK role
+    AgtPnpParams pnp;
+    int n_pnp;                        // blocks of the PnP role (= streams) or 0
+};
+
 struct AgtProjParams {
     const void* obj; long obj_bstride; int dtype; int n;
     const double* pose;       // [B][6]
@@ -78,9 +97,13 @@ struct AgtProjParams {
     double* jac;              // [B][2n][6] or null
 };
 
+void agt_pyr_grid(int dw, int dh, int* gx, int* gy);
 hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
                                uint8_t* dst, long dpitch, long dbatch, int B);
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B);
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B);
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
 bool agt_lk_window_supported(int win);
+bool agt_lk_wide(int n, int B);
+bool agt_step_supported(int win);
+hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win);

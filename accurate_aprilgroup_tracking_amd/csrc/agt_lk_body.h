@@ -1,0 +1,412 @@
+// agt_lk_body.h -- device body of the cv::calcOpticalFlowPyrLK per-point tracker for gfx950 (north-star step;
+// no call site in the reference, belongs at the hole detect_pose.py:573-574).
+// Semantics: OpenCV modules/video/src/lkpyramid.cpp LKTrackerInvoker + calcSharrDeriv,
+// restated on the CPU in oracle/cv_lk.c; this kernel is bit-identical to that oracle
+// (CVO_ACC_EXACT mode) on nextPts, status and err.
+//
+// Mapping: one workgroup of NW waves per corner (NW = 4 when few corners are in flight and
+// latency matters, NW = 1 for big batches where throughput matters), all pyramid levels and
+// all iterations inside one launch.  Thread t owns window pixels t, t + 64*NW, ... and keeps
+// their patch values (I, Ix, Iy) in registers.  A single wave issues ~1 instruction per 10
+// cycles here, so the per-iteration critical path is cut by spreading the 441 pixels over
+// more lanes; sums cross waves through 8-byte LDS slots and one barrier per iteration.
+//   * the 24x24 I neighbourhood is staged in LDS with aligned dword loads (reflect-101 at
+//     the image edge), Scharr is evaluated on the fly from that tile (no full-frame
+//     derivative image is ever written to HBM -- the CPU path writes 4 B/px/level);
+//   * the J search tile (40x40) is re-staged only if the window leaves it;
+//   * ALL levels' I and J tiles are requested at kernel entry (every global load in flight at
+//     once, then written to per-level LDS slots), so the kernel pays one HBM latency instead
+//     of one per staging-loop trip; J tiles are centred on the initial guess;
+//   * the 2x2 normal equations are EXACT integer sums: int32 while provably safe (DPP row
+//     ops), then 64-bit scalars (v_readlane + SALU) and LDS slots across waves, so the result
+//     is independent of the reduction order and uniform; every OpenCV build approximates this
+//     sum with float adds in its own SIMD order.
+// Algorithmic bytes per point per level: 24*24 (I) + 40*40 (J tile) u8.
+#pragma once
+#include "agt_device.h"
+#include "agt_kernels.h"
+
+// In-kernel cycle stamps (diagnostic builds only: make dbg; never in the shipped library).
+#ifdef AGT_LK_STAMPS
+__device__ unsigned long long agt_lk_stamps[64];
+#define STAMP(i) do { if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int agt_debug_lk_stamps(unsigned long long* host64)
+{
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(agt_lk_stamps), sizeof(agt_lk_stamps));
+}
+#else
+#define STAMP(i)
+#endif
+
+namespace agt_lk {
+
+template <int WIN, int NW>
+struct LkCfg {
+    static constexpr int T = AGT_WAVE * NW;             // threads per corner
+    static constexpr int NPX = (WIN * WIN + T - 1) / T; // window pixels per thread
+    static constexpr int IW = WIN + 3;                  // I tile: window + bilinear + Scharr halo
+    static constexpr int INDW = (IW + 6) / 4;           // aligned dwords per I-tile row (incl. <=3 B shift)
+    static constexpr int IP = INDW * 4;                 // LDS pitch
+    static constexpr int DW = WIN + 1;                  // derivative tile
+    static constexpr int MARGIN = 9;
+    static constexpr int JT = WIN + 1 + 2 * MARGIN;     // J search tile
+    static constexpr int JNDW = (JT + 6) / 4;
+    static constexpr int JP = JNDW * 4;
+    static constexpr int LEVEL_LDS = IW * IP + JT * JP; // per-level LDS slot (I tile + J tile)
+    static constexpr int ILD = (IW * INDW + T - 1) / T; // I-tile dwords per thread
+    static constexpr int JLD = (JT * JNDW + T - 1) / T; // J-tile dwords per thread
+    static constexpr int NSD = (DW * DW + T - 1) / T;   // derivative positions per thread
+    // int32 partial sums stay exact over 2^SUM_STEPS lanes: NPX * 8160 * 4080 * 2^S < 2^31
+    static constexpr int SUM_STEPS = NPX <= 2 ? 4 : (NPX <= 8 ? 3 : 2);
+    static_assert((long long)NPX * 8160 * 4080 * (1 << SUM_STEPS) < (1LL << 31), "int32 partial sums could overflow");
+    static_assert(LEVEL_LDS % 16 == 0, "keep per-level slots 16-byte aligned");
+};
+
+// NW > 1: workgroup barrier.  NW == 1: the corner is one wave (possibly sharing its workgroup
+// with other corners), LDS ops of a wave execute in issue order, so only the compiler must be
+// kept from reordering across the point.
+template <int NW>
+__device__ __forceinline__ void block_sync()
+{
+    if (NW > 1) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); }
+}
+
+constexpr int W_BITS = 14;
+__device__ __forceinline__ int descale(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+
+// border path of the tile loads: one dword assembled from four reflect-101 bytes (rare; kept
+// out of line so the common path stays small)
+__device__ __noinline__ uint32_t load_dword_reflect(const uint8_t* __restrict__ row, int gx, int w)
+{
+    uint32_t v = 0;
+    for (int k = 0; k < 4; k++) v |= (uint32_t)row[agt_reflect101(gx + k, w)] << (8 * k);
+    return v;
+}
+
+// Tile = rows [ty0, ty0+TH) x the NDW aligned dwords starting at (tx0 & ~3); pixel (x, y) lands at
+// s[(y - ty0) * (4*NDW) + (x - (tx0 & ~3))].  Loads and LDS stores are split so that every
+// level's loads are in flight together.
+template <int TH, int NDW, int T, int N>
+__device__ __forceinline__ void tile_load(const uint8_t* __restrict__ img, int w, int h, long pitch,
+                                          int tx0, int ty0, int tid, uint32_t (&v)[N])
+{
+    const int ax0 = tx0 & ~3;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int i = tid + k * T;
+        v[k] = 0;
+        if (i < TH * NDW) {
+            const int r = i / NDW, c4 = i - r * NDW;
+            const int gy = agt_reflect101(ty0 + r, h);
+            const int gx = ax0 + 4 * c4;
+            const uint8_t* row = img + (long)gy * pitch;
+            v[k] = (gx >= 0 && gx + 3 < w) ? *reinterpret_cast<const uint32_t*>(row + gx) : load_dword_reflect(row, gx, w);
+        }
+    }
+}
+
+template <int TH, int NDW, int T, int N>
+__device__ __forceinline__ void tile_store(uint8_t* s, int tid, const uint32_t (&v)[N])
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+        const int i = tid + k * T;
+        if (i < TH * NDW) *reinterpret_cast<uint32_t*>(s + 4 * i) = v[k];
+    }
+}
+
+__device__ __forceinline__ void bilinear_weights(float a, float b, int& iw00, int& iw01, int& iw10, int& iw11)
+{
+    iw00 = __float2int_rn((1.f - a) * (1.f - b) * (float)(1 << W_BITS));
+    iw01 = __float2int_rn(a * (1.f - b) * (float)(1 << W_BITS));
+    iw10 = __float2int_rn((1.f - a) * b * (float)(1 << W_BITS));
+    iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
+}
+
+// all operands of the fixed-point products fit 24 bits (pixels 8, weights 15, patch values 14,
+// derivatives 13): v_mul_i32_i24 / v_mad_i32_i24 are full rate, v_mul_lo_u32 is not
+__device__ __forceinline__ int bil4(int v00, int v01, int v10, int v11, int iw00, int iw01, int iw10, int iw11)
+{
+    return __mul24(v00, iw00) + __mul24(v01, iw01) + __mul24(v10, iw10) + __mul24(v11, iw11);
+}
+
+// Exact 64-lane sum of one int per lane; identical (wave-uniform) in every lane.
+// STEPS DPP steps in int32 (proved not to overflow), the rest in 64-bit scalars.
+template <int STEPS>
+__device__ __forceinline__ long long wave_sum_exact(int v)
+{
+    v += agt_dpp_i32<0xB1>(v);                         // quad_perm [1,0,3,2]
+    v += agt_dpp_i32<0x4E>(v);                         // quad_perm [2,3,0,1]
+    if (STEPS >= 3) v += agt_dpp_i32<0x141>(v);        // row_half_mirror: 8-lane sums
+    if (STEPS >= 4) v += agt_dpp_i32<0x140>(v);        // row_mirror: 16-lane sums
+    constexpr int G = 1 << STEPS;
+    long long t = 0;
+#pragma unroll
+    for (int l = 0; l < AGT_WAVE; l += G) t += (long long)__builtin_amdgcn_readlane(v, l);
+    return t;
+}
+
+// Exact sum over the whole workgroup of NV ints per thread; identical in every thread.
+template <int NW, int STEPS, int NV>
+__device__ __forceinline__ void block_sum_exact(const int (&v)[NV], long long (&out)[NV], long long* slots, int& phase,
+                                                int wave, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < NV; i++) out[i] = wave_sum_exact<STEPS>(v[i]);
+    if (NW > 1) {
+        long long* s = slots + phase * (NW * 4);
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < NV; i++) s[wave * 4 + i] = out[i];
+        }
+        block_sync<NW>();
+#pragma unroll
+        for (int i = 0; i < NV; i++) {
+            long long t = 0;
+#pragma unroll
+            for (int w = 0; w < NW; w++) t += s[w * 4 + i];
+            out[i] = t;
+        }
+        phase ^= 1;          // double-buffered: the next sum may start before slow waves have read this one
+    }
+}
+
+// LDS bytes one corner needs: [levels] x { I tile | J tile }, derivative tile, reduction slots
+template <int WIN, int NW>
+__host__ __device__ constexpr size_t lk_lds_bytes(int levels)
+{
+    using C = LkCfg<WIN, NW>;
+    return (size_t)levels * C::LEVEL_LDS + (size_t)((C::DW * C::DW + 3) & ~3) * sizeof(int) + (size_t)2 * NW * 4 * sizeof(long long);
+}
+
+// Track corner `pt` of stream `b`.  Called by all 64*NW threads of a workgroup; lds: lk_lds_bytes, 16-B aligned.
+template <int WIN, int NW, int NLEV>
+__device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uint8_t* lds)
+{
+    using C = LkCfg<WIN, NW>;
+    constexpr int T = C::T;
+    int* sD = reinterpret_cast<int*>(lds + (P.max_level + 1) * C::LEVEL_LDS);
+    long long* slots = reinterpret_cast<long long*>(sD + ((C::DW * C::DW + 3) & ~3));
+    int phase = 0;
+
+    const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;   // thread index within the corner
+    const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
+    const long pidx = (long)b * P.n + pt;
+
+    // window pixels of this thread
+    int px[C::NPX], py[C::NPX];
+    bool pv[C::NPX];
+#pragma unroll
+    for (int k = 0; k < C::NPX; k++) {
+        const int p = tid + k * T;
+        pv[k] = p < WIN * WIN;
+        py[k] = pv[k] ? p / WIN : 0;
+        px[k] = pv[k] ? p - py[k] * WIN : 0;
+    }
+
+    const float halfw = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
+    float outx = 0.f, outy = 0.f;              // nextPts[ptidx]
+    if (P.flags & AGT_LK_USE_INITIAL_FLOW) { outx = P.next_pts[pidx * 2]; outy = P.next_pts[pidx * 2 + 1]; }
+    const float gsx = (P.flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;     // where the search is expected to start
+    const float gsy = (P.flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
+
+    STAMP(0);
+    // ---- prologue: request every level's tiles before touching any of them
+    {
+        uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            if (l <= P.max_level) {
+                const float scale = 1.f / (float)(1 << l);
+                const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
+                const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+                const AgtLevel LI = P.prev[l];
+                const AgtLevel LJ = P.next[l];
+                if (!(ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h)) {
+                    tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti[l]);
+                    tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj[l]);
+                }
+            }
+        }
+        STAMP(1);
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            if (l <= P.max_level) {
+                tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, tid, ti[l]);
+                tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, tid, tj[l]);
+            }
+        }
+    }
+    block_sync<NW>();
+    STAMP(2);
+
+    int st = 1;
+    float errv = 0.f;
+
+    for (int level = P.max_level; level >= 0; level--) {
+        const AgtLevel LI = P.prev[level];
+        const AgtLevel LJ = P.next[level];
+        const uint8_t* imgJ = LJ.ptr + (long)b * LJ.bstride;
+        const uint8_t* sI = lds + level * C::LEVEL_LDS;
+        uint8_t* sJ = lds + level * C::LEVEL_LDS + C::IW * C::IP;
+        const float scale = 1.f / (float)(1 << level);
+        float prevx = ppx * scale, prevy = ppy * scale;
+        float nextx, nexty;
+        if (level == P.max_level) {
+            if (P.flags & AGT_LK_USE_INITIAL_FLOW) { nextx = outx * scale; nexty = outy * scale; }
+            else { nextx = prevx; nexty = prevy; }
+        } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+        STAMP(8 + level * 8 + 0);
+
+        prevx -= halfw; prevy -= halfw;
+        const int ipx = agt_uniform((int)floorf(prevx)), ipy = agt_uniform((int)floorf(prevy));
+        if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
+            if (level == 0) { st = 0; errv = 0.f; }
+            continue;
+        }
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
+
+        // ---- Scharr on the fly from the prefetched I tile -> LDS derivative tile
+        const int offI = (ipx - 1) - ((ipx - 1) & ~3);
+        block_sync<NW>();                      // previous level's readers of sD are done
+#pragma unroll
+        for (int k = 0; k < C::NSD; k++) {
+            const int idx = tid + k * T;
+            if (idx < C::DW * C::DW) {
+                const int dyy = idx / C::DW, dxx = idx - dyy * C::DW;
+                const int gx = ipx + dxx, gy = ipy + dyy;
+                int val = 0;      // derivative image has a ZERO (BORDER_CONSTANT) border
+                if (gx >= 0 && gx < LI.w && gy >= 0 && gy < LI.h) {
+                    const uint8_t* c = sI + (dyy + 1) * C::IP + (dxx + 1) + offI;
+                    const int v00 = c[-C::IP - 1], v01 = c[-C::IP], v02 = c[-C::IP + 1];
+                    const int v10 = c[-1], v12 = c[1];
+                    const int v20 = c[C::IP - 1], v21 = c[C::IP], v22 = c[C::IP + 1];
+                    const int dx = (3 * (v02 + v22) + 10 * v12) - (3 * (v00 + v20) + 10 * v10);
+                    const int dy = 3 * ((v20 - v00) + (v22 - v02)) + 10 * (v21 - v01);
+                    val = (dx & 0xffff) | (dy << 16);
+                }
+                sD[idx] = val;
+            }
+        }
+        block_sync<NW>();
+        STAMP(8 + level * 8 + 1);
+
+        // ---- per-thread patch (registers) + exact covariance sums
+        int Iv[C::NPX], Ix[C::NPX], Iy[C::NPX];
+        int asum[3] = { 0, 0, 0 };
+#pragma unroll
+        for (int k = 0; k < C::NPX; k++) {
+            Iv[k] = 0; Ix[k] = 0; Iy[k] = 0;
+            if (pv[k]) {
+                const uint8_t* p = sI + (py[k] + 1) * C::IP + (px[k] + 1) + offI;
+                Iv[k] = descale(bil4(p[0], p[1], p[C::IP], p[C::IP + 1], iw00, iw01, iw10, iw11), W_BITS - 5);
+                const int* d = sD + py[k] * C::DW + px[k];
+                const int d00 = d[0], d01 = d[1], d10 = d[C::DW], d11 = d[C::DW + 1];
+                Ix[k] = descale(bil4((short)d00, (short)d01, (short)d10, (short)d11, iw00, iw01, iw10, iw11), W_BITS);
+                Iy[k] = descale(bil4(d00 >> 16, d01 >> 16, d10 >> 16, d11 >> 16, iw00, iw01, iw10, iw11), W_BITS);
+                asum[0] += __mul24(Ix[k], Ix[k]); asum[1] += __mul24(Ix[k], Iy[k]); asum[2] += __mul24(Iy[k], Iy[k]);
+            }
+        }
+        long long at[3];
+        block_sum_exact<NW, C::SUM_STEPS, 3>(asum, at, slots, phase, wave, lane);
+        const float A11 = (float)(double)at[0] * FLT_SCALE;
+        const float A12 = (float)(double)at[1] * FLT_SCALE;
+        const float A22 = (float)(double)at[2] * FLT_SCALE;
+
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if (P.flags & AGT_LK_GET_MIN_EIGENVALS) errv = minEig;
+        if (agt_uniform((int)((double)minEig < P.min_eig_threshold || D < FLT_EPSILON))) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        STAMP(8 + level * 8 + 2);
+
+        nextx -= halfw; nexty -= halfw;
+        float pdx = 0.f, pdy = 0.f;
+        // the prefetched J tile of this level
+        int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+        auto restage_j = [&](int inx, int iny) {
+            jx0 = inx - C::MARGIN; jy0 = iny - C::MARGIN;
+            uint32_t t[C::JLD];
+            block_sync<NW>();
+            tile_load<C::JT, C::JNDW, T>(imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, t);
+            tile_store<C::JT, C::JNDW, T>(sJ, tid, t);
+            block_sync<NW>();
+        };
+        // sum of the window's temporal differences against the patch: {diff*Ix, diff*Iy} or {|diff|}
+        auto window_pass = [&](int inx, int iny, bool want_abs, int (&acc)[2]) {
+            acc[0] = 0; acc[1] = 0;
+            const uint8_t* q0 = sJ + (iny - jy0) * C::JP + (inx - jx0) + (jx0 - (jx0 & ~3));
+#pragma unroll
+            for (int k = 0; k < C::NPX; k++) {
+                if (pv[k]) {
+                    const uint8_t* q = q0 + py[k] * C::JP + px[k];
+                    const int diff = descale(bil4(q[0], q[1], q[C::JP], q[C::JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5) - Iv[k];
+                    if (want_abs) acc[0] += diff < 0 ? -diff : diff;
+                    else { acc[0] += __mul24(diff, Ix[k]); acc[1] += __mul24(diff, Iy[k]); }
+                }
+            }
+        };
+        for (int j = 0; j < P.max_count; j++) {
+            const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
+            if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
+            bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
+            int bsum[2];
+            window_pass(inx, iny, false, bsum);
+            long long bt[2];
+            block_sum_exact<NW, C::SUM_STEPS, 2>(bsum, bt, slots, phase, wave, lane);
+            const float fb1 = (float)(double)bt[0] * FLT_SCALE;
+            const float fb2 = (float)(double)bt[1] * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            nextx += dx; nexty += dy;
+            outx = nextx + halfw; outy = nexty + halfw;
+            if (j == 0) STAMP(8 + level * 8 + 3);
+#ifdef AGT_LK_STAMPS
+            if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
+#endif
+            if (agt_uniform((int)((double)dx * dx + (double)dy * dy <= P.eps2))) break;
+            if (j > 0 && agt_uniform((int)(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01))) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        STAMP(8 + level * 8 + 4);
+        if (st && P.err && level == 0 && !(P.flags & AGT_LK_GET_MIN_EIGENVALS)) {
+            const float npx = outx - halfw, npy = outy - halfw;
+            const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
+            if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) { st = 0; continue; }
+            if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
+            bilinear_weights(npx - (float)inx, npy - (float)iny, iw00, iw01, iw10, iw11);
+            int esum[2];
+            window_pass(inx, iny, true, esum);
+            int e1[1] = { esum[0] };
+            long long et[1];
+            block_sum_exact<NW, C::SUM_STEPS, 1>(e1, et, slots, phase, wave, lane);
+            errv = (float)(double)et[0] * 1.f / (float)(32 * WIN * WIN);
+        }
+    }
+
+    STAMP(3);
+    if (tid == 0) {
+        P.next_pts[pidx * 2] = outx;
+        P.next_pts[pidx * 2 + 1] = outy;
+        P.status[pidx] = (uint8_t)st;
+        if (P.err) P.err[pidx] = errv;
+    }
+}
+
+}  // namespace agt_lk

@@ -1,545 +1,16 @@
-// agt_pnp.hip -- cv::solvePnP(SOLVEPNP_ITERATIVE) + cv::projectPoints for gfx950.
-//
-// Replaces the reference's calls at
-//   /root/reference/aprilgroup_tracking/aprilgroup_pose_estimation/detect_pose.py:509-515 (no guess: DLT init + LM)
-//   detect_pose.py:517-526 (useExtrinsicGuess=True: LM only)
-//   transform_helper.py:106-111 / detect_pose.py:455-461 (projectPoints)
-//   transform_helper.py:98-121 (mean reprojection error, fused into the solve's epilogue)
-// Semantics: OpenCV calibration.cpp cvFindExtrinsicCameraParams2 + compat_ptsetreg.cpp
-// CvLevMarq (<= 20 iterations, eps = FLT_EPSILON, lambda = 10^-3 initially), all FP64;
-// restated on the CPU in oracle/cv_pnp.c.
-//
-// Mapping: ONE 64-lane wave per problem; lane l owns correspondences l, l+64, ... and
-// evaluates residual + 2x6 Jacobian in FP64.  The 21 + 6 + 1 partial sums
-// (upper J^T J, J^T e, |e|^2) cross lanes through a transposed LDS slab (two lanes per
-// sum, 32 adds each) -- no MFMA: the contraction is 6x6.  The whole LM loop, the
-// damped LDL^T solve and the termination test run inside the launch; the host sees one
-// kernel per batch of B independent problems.
-#include "agt_device.h"
-#include "agt_kernels.h"
+// agt_pnp.hip -- stand-alone cv::solvePnP(SOLVEPNP_ITERATIVE) / cv::projectPoints launches
+// (solver body and design notes: agt_pnp_body.h).
+#include "agt_pnp_body.h"
 
 namespace {
 
-constexpr int NACC = 28;            // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
-constexpr int SLAB = 65;            // padded lane stride of the reduction slab (doubles)
-constexpr int MAX_PPL = 4;          // points per lane -> n <= 256
-
-struct PnpShared {
-    double part[NACC * SLAB];
-    double tot[NACC + 4];
-    double LL[144];
-    double vec[48];
-};
-
-// sum K per-lane partials across the wave; totals come back in vals[] of every lane
-template <int K>
-__device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& sh, int lane)
-{
-    static_assert(K <= 32, "one pass handles at most 32 sums");
-    __syncthreads();
-#pragma unroll
-    for (int k = 0; k < K; k++) sh.part[k * SLAB + lane] = vals[k];
-    __syncthreads();
-    const int k = lane & 31, h = lane >> 5;
-    double s = 0.0;
-    if (k < K) {
-        const double* p = &sh.part[k * SLAB + 32 * h];
-#pragma unroll 8
-        for (int i = 0; i < 32; i++) s += p[i];
-    }
-    s += __shfl_xor(s, 32);
-    if (lane < K) sh.tot[lane] = s;
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < K; i++) vals[i] = sh.tot[i];
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
-}
-
-template <typename T>
-__device__ __forceinline__ void load_cam(const AgtCameraHost& h, AgtCamera& c)
-{
-    c.fx = h.fx; c.fy = h.fy; c.cx = h.cx; c.cy = h.cy;
-#pragma unroll
-    for (int i = 0; i < 12; i++) c.k[i] = h.k[i];
-}
-
-// cvUndistortPointsInternal, criteria (COUNT, 5), R = I, no P
-__device__ __forceinline__ void undistort5(const AgtCamera& cam, double u, double v, double& xo, double& yo)
-{
-    const double* k = cam.k;
-    double x = (u - cam.cx) * (1.0 / cam.fx), y = (v - cam.cy) * (1.0 / cam.fy);
-    const double x0 = x, y0 = y;
-    for (int j = 0; j < 5; j++) {
-        double r2 = x * x + y * y;
-        double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
-        if (icdist < 0) { x = x0; y = y0; break; }
-        double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
-        double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
-        x = (x0 - deltaX) * icdist;
-        y = (y0 - deltaY) * icdist;
-    }
-    xo = x; yo = y;
-}
-
-// Smallest eigenvector of the symmetric PSD n x n matrix in A (row-major, LDS), by
-// shifted inverse iteration on a Cholesky factor.  Serial: call from ONE lane.
-// Gives the same vector (up to sign) as the last row of V^T in OpenCV's SVD of A.
-__device__ void smallest_eigvec(double* A, int n, double* v, double* tmp)
-{
-    double dmax = 0;
-    for (int i = 0; i < n; i++) dmax = fmax(dmax, A[i * n + i]);
-    const double mu = dmax * 1e-11 + DBL_MIN;
-    for (int j = 0; j < n; j++) {
-        double d = A[j * n + j] + mu;
-        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
-        d = d > mu * 1e-3 ? d : mu * 1e-3;
-        d = sqrt(d);
-        A[j * n + j] = d;
-        const double id = 1.0 / d;
-        for (int i = j + 1; i < n; i++) {
-            double s = A[i * n + j];
-            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
-            A[i * n + j] = s * id;
-        }
-    }
-    for (int i = 0; i < n; i++) v[i] = 1.0 / sqrt((double)n) * ((i & 1) ? 0.9 : 1.1);
-    for (int it = 0; it < 12; it++) {
-        for (int i = 0; i < n; i++) {
-            double s = v[i];
-            for (int k = 0; k < i; k++) s -= A[i * n + k] * tmp[k];
-            tmp[i] = s / A[i * n + i];
-        }
-        for (int i = n - 1; i >= 0; i--) {
-            double s = tmp[i];
-            for (int k = i + 1; k < n; k++) s -= A[k * n + i] * v[k];
-            v[i] = s / A[i * n + i];
-        }
-        double nn = 0;
-        for (int i = 0; i < n; i++) nn += v[i] * v[i];
-        nn = 1.0 / sqrt(nn);
-        for (int i = 0; i < n; i++) v[i] *= nn;
-    }
-}
-
-// ---- motion model of PoseDetector (serial, one lane) ------------------------------------
-// transform_helper.py:239-259 rotation_matrix_to_euler_angles
-__device__ inline void rot_to_euler(const double R[9], double e[3])
-{
-    const double sy = sqrt(R[0] * R[0] + R[3] * R[3]);
-    if (!(sy < 1e-6)) { e[0] = atan2(R[7], R[8]); e[1] = atan2(-R[6], sy); e[2] = atan2(R[3], R[0]); }
-    else { e[0] = atan2(-R[5], R[4]); e[1] = atan2(-R[6], sy); e[2] = 0.0; }
-}
-// transform_helper.py:215-236 euler_angles_to_rotation_matrix: R = Rz * Ry * Rx
-__device__ inline void euler_to_rot(const double e[3], double R[9])
-{
-    double sx, cx, sy, cy, sz, cz;
-    sincos(e[0], &sx, &cx); sincos(e[1], &sy, &cy); sincos(e[2], &sz, &cz);
-    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx };
-    const double Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy };
-    const double Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
-    double T[9];
-    agt_mat3_mul(Ry, Rx, T);
-    agt_mat3_mul(Rz, T, R);
-}
-// A^T B
-__device__ inline void mat3_tmul(const double A[9], const double B[9], double C[9])
-{
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-#pragma unroll
-        for (int j = 0; j < 3; j++) C[i * 3 + j] = A[i] * B[j] + A[3 + i] * B[3 + j] + A[6 + i] * B[6 + j];
-}
-// A^T v
-__device__ inline void mat3_tvec(const double A[9], const double v[3], double o[3])
-{
-#pragma unroll
-    for (int i = 0; i < 3; i++) o[i] = A[i] * v[0] + A[3 + i] * v[1] + A[6 + i] * v[2];
-}
-
-// detect_pose.py:553-566: get_pose_vel_acc (245-301) + _update_buffers (229-243) +
-// apply_vel_acc (303-349).  curr/prev = (rvec, tvec).  Returns AGT_TRK_* flags.
-__device__ inline int motion_model_update(AgtTrackState& ts, const double curr[6], bool curr_t_f32,
-                                          const double prev[6], bool prev_t_f32)
-{
-    double Rp[9], Rc[9];
-    agt_rodrigues<false>(prev, Rp, nullptr);
-    agt_rodrigues<false>(curr, Rc, nullptr);
-    // get_relative_trans (transform_helper.py:184): rot_mat.T @ (tvec0 - tvec1); numpy subtracts in
-    // float32 when both operands are float32 arrays
-    double d[3], tran_vel[3], rot_vel[9];
-#pragma unroll
-    for (int i = 0; i < 3; i++)
-        d[i] = (curr_t_f32 && prev_t_f32) ? (double)((float)prev[3 + i] - (float)curr[3 + i]) : prev[3 + i] - curr[3 + i];
-    mat3_tvec(Rc, d, tran_vel);
-    mat3_tmul(Rc, Rp, rot_vel);                  // get_relative_rot: rmat1.T @ rmat0
-    bool any_zero = false;
-#pragma unroll
-    for (int i = 0; i < 9; i++) any_zero |= rot_vel[i] == 0.0;
-#pragma unroll
-    for (int i = 0; i < 3; i++) any_zero |= tran_vel[i] == 0.0;
-    if (any_zero) return AGT_TRK_ZERO_VELOCITY;  // reference raises ValueError here
-    if (ts.n_vel >= 2) {
-        for (int i = 0; i < 9; i++) ts.rot_vel[0][i] = ts.rot_vel[1][i];
-        for (int i = 0; i < 3; i++) ts.tran_vel[0][i] = ts.tran_vel[1][i];
-        ts.n_vel = 1;
-    }
-    const int slot = ts.n_vel;
-    for (int i = 0; i < 9; i++) ts.rot_vel[slot][i] = rot_vel[i];
-    for (int i = 0; i < 3; i++) ts.tran_vel[slot][i] = tran_vel[i];
-    ts.n_vel = slot + 1;
-    if (ts.n_vel < 2) return 0;                  // success = False: the guess is left as is
-    double dv[3], tran_acc[3], rot_acc[9], old_rv[9];
-    for (int i = 0; i < 3; i++) dv[i] = ts.tran_vel[0][i] - tran_vel[i];
-    for (int i = 0; i < 9; i++) old_rv[i] = ts.rot_vel[0][i];
-    mat3_tvec(rot_vel, dv, tran_acc);
-    mat3_tmul(rot_vel, old_rv, rot_acc);
-    // apply_vel_acc on the PREVIOUS pose
-    double e[3], RA[9], M[9], Rpred[9], tp[3], tpred[3];
-    rot_to_euler(rot_acc, e);
-    e[0] *= 0.5; e[1] *= 0.5; e[2] *= 0.5;
-    euler_to_rot(e, RA);
-    agt_mat3_mul(RA, rot_vel, M);                // (acc @ vel) @ pose
-    agt_mat3_mul(M, Rp, Rpred);
-    for (int i = 0; i < 3; i++) tp[i] = prev[3 + i];
-    for (int i = 0; i < 3; i++)
-        tpred[i] = (M[i * 3] * tp[0] + M[i * 3 + 1] * tp[1] + M[i * 3 + 2] * tp[2]) +
-                   (RA[i * 3] * tran_vel[0] + RA[i * 3 + 1] * tran_vel[1] + RA[i * 3 + 2] * tran_vel[2] + 0.5 * tran_acc[i]);
-    double rpred[3];
-    agt_rodrigues_inv(Rpred, rpred);
-    for (int i = 0; i < 3; i++) { ts.guess[i] = rpred[i]; ts.guess[3 + i] = (double)(float)tpred[i]; }
-    ts.guess_t_f32 = 1;                          // get_rmat_tvec casts to float32 (transform_helper.py:158-159)
-    return 0;
-}
+using agt_pnp::load_cam;
 
 template <typename T, int PPL>
 __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 {
-    __shared__ PnpShared sh;
-    const int lane = threadIdx.x;
-    const int b = blockIdx.x;
-    const int n = P.n;
-    AgtCamera cam;
-    load_cam<T>(P.cam, cam);
-
-    // ---- this lane's correspondences
-    double X[PPL], Y[PPL], Z[PPL], mu_[PPL], mv_[PPL];
-    bool use[PPL];
-    const T* obj = reinterpret_cast<const T*>(P.obj) + (long)b * P.obj_bstride;
-    const T* img = reinterpret_cast<const T*>(P.img) + (long)b * n * 2;
-    const uint8_t* mask = P.mask ? P.mask + (long)b * n : nullptr;
-    int cnt = 0;
-#pragma unroll
-    for (int q = 0; q < PPL; q++) {
-        const int i = lane + q * AGT_WAVE;
-        use[q] = i < n && (!mask || mask[i] != 0);
-        X[q] = Y[q] = Z[q] = mu_[q] = mv_[q] = 0.0;
-        if (use[q]) {
-            X[q] = (double)obj[i * 3]; Y[q] = (double)obj[i * 3 + 1]; Z[q] = (double)obj[i * 3 + 2];
-            mu_[q] = (double)img[i * 2]; mv_[q] = (double)img[i * 2 + 1];
-            cnt++;
-        }
-    }
-    const int n_used = (int)agt_wave_sum_i64(cnt);
-    int flags = 0;
-    double param[6];
-    AgtTrackState* ts = P.track ? P.track + b : nullptr;
-    bool use_guess = P.use_guess != 0;
-    double unchanged_prev[6] = { 0, 0, 0, 0, 0, 0 };
-    int had_guess = 0, guess_f32 = 0, prev_f32 = 0;
-    if (ts) {
-        // detect_pose.py:490 deepcopy(prev_transform); :508 guess selection
-        had_guess = ts->has_guess; guess_f32 = ts->guess_t_f32; prev_f32 = ts->prev_t_f32;
-        use_guess = had_guess && P.enhance_ape;
-#pragma unroll
-        for (int i = 0; i < 6; i++) { unchanged_prev[i] = ts->prev[i]; param[i] = ts->guess[i]; }
-        if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
-            if (lane == 0) {
-                ts->has_guess = 0; ts->frame++;
-                if (P.state_out) {
-                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
-                    for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
-                }
-            }
-            return;
-        }
-    } else {
-#pragma unroll
-        for (int i = 0; i < 6; i++) param[i] = P.pose[(long)b * 6 + i];
-    }
-
-    const bool enough = use_guess ? n_used >= 3 : n_used >= 6;
-    if (!enough) {
-        if (lane == 0 && P.info) {
-            P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
-            P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_TOO_FEW;
-        }
-        if (lane == 0 && P.err) P.err[b] = 0.0;
-        return;
-    }
-
-    // ---- initialisation without a guess: cvFindExtrinsicCameraParams2, DLT branch
-    if (!use_guess) {
-        double c4[4] = { 0, 0, 0, 0 };
-#pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) { c4[0] += X[q]; c4[1] += Y[q]; c4[2] += Z[q]; }
-        wave_reduce_slab<4>(c4, sh, lane);
-        const double mcx = c4[0] / n_used, mcy = c4[1] / n_used, mcz = c4[2] / n_used;
-        double m6[6] = { 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) {
-            const double dx = X[q] - mcx, dy = Y[q] - mcy, dz = Z[q] - mcz;
-            m6[0] += dx * dx; m6[1] += dx * dy; m6[2] += dx * dz; m6[3] += dy * dy; m6[4] += dy * dz; m6[5] += dz * dz;
-        }
-        wave_reduce_slab<6>(m6, sh, lane);
-        const double MM[9] = { m6[0], m6[1], m6[2], m6[1], m6[3], m6[4], m6[2], m6[4], m6[5] };
-        double Wm[3], Um[9], Vm[9];
-        agt_svd3(MM, Wm, Um, Vm);
-        if (Wm[2] / Wm[1] < 1e-3) {
-            // planar structure: homography initialisation is not built yet
-            if (lane == 0 && P.info) {
-                P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
-                P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_PLANAR;
-            }
-            if (lane == 0 && P.err) P.err[b] = 0.0;
-            if (lane == 0 && ts) {
-                ts->has_guess = 0; ts->frame++;
-                if (P.state_out) {
-                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
-                    for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_PLANAR;
-                }
-            }
-            return;
-        }
-        // L^T L has only 40 distinct sums: sum w * Mt Mt^T with w in {1, x, y, x^2+y^2}
-        double s0[10], sx[10], sy[10], sq[10];
-#pragma unroll
-        for (int i = 0; i < 10; i++) s0[i] = sx[i] = sy[i] = sq[i] = 0.0;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) {
-            double xn, yn;
-            undistort5(cam, mu_[q], mv_[q], xn, yn);
-            const double x = -xn, y = -yn, w2 = x * x + y * y;
-            const double pr[10] = { X[q] * X[q], X[q] * Y[q], X[q] * Z[q], X[q], Y[q] * Y[q], Y[q] * Z[q], Y[q], Z[q] * Z[q], Z[q], 1.0 };
-#pragma unroll
-            for (int i = 0; i < 10; i++) { s0[i] += pr[i]; sx[i] += x * pr[i]; sy[i] += y * pr[i]; sq[i] += w2 * pr[i]; }
-        }
-        wave_reduce_slab<10>(s0, sh, lane);
-        wave_reduce_slab<10>(sx, sh, lane);
-        wave_reduce_slab<10>(sy, sh, lane);
-        wave_reduce_slab<10>(sq, sh, lane);
-        __syncthreads();
-        if (lane == 0) {
-            const int ui[4][4] = { { 0, 1, 2, 3 }, { 1, 4, 5, 6 }, { 2, 5, 7, 8 }, { 3, 6, 8, 9 } };
-            for (int a = 0; a < 4; a++)
-                for (int c = 0; c < 4; c++) {
-                    const int u = ui[a][c];
-                    sh.LL[a * 12 + c] = s0[u];           sh.LL[a * 12 + 4 + c] = 0.0;          sh.LL[a * 12 + 8 + c] = sx[u];
-                    sh.LL[(4 + a) * 12 + c] = 0.0;       sh.LL[(4 + a) * 12 + 4 + c] = s0[u];  sh.LL[(4 + a) * 12 + 8 + c] = sy[u];
-                    sh.LL[(8 + a) * 12 + c] = sx[u];     sh.LL[(8 + a) * 12 + 4 + c] = sy[u];  sh.LL[(8 + a) * 12 + 8 + c] = sq[u];
-                }
-            double* v = sh.vec;
-            smallest_eigvec(sh.LL, 12, v, sh.vec + 16);
-            double RR[9] = { v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10] };
-            double tt[3] = { v[3], v[7], v[11] };
-            if (agt_det3(RR) < 0) {
-                for (int i = 0; i < 9; i++) RR[i] = -RR[i];
-                for (int i = 0; i < 3; i++) tt[i] = -tt[i];
-            }
-            double sc = 0;
-            for (int i = 0; i < 9; i++) sc += RR[i] * RR[i];
-            sc = sqrt(sc);
-            double Wr[3], U[9], Vt[9], Rm[9];
-            agt_svd3(RR, Wr, U, Vt);
-            agt_mat3_mul(U, Vt, Rm);
-            double nr = 0;
-            for (int i = 0; i < 9; i++) nr += Rm[i] * Rm[i];
-            nr = sqrt(nr);
-            double rv[3];
-            agt_rodrigues_inv(Rm, rv);
-            sh.vec[32] = rv[0]; sh.vec[33] = rv[1]; sh.vec[34] = rv[2];
-            sh.vec[35] = tt[0] * nr / sc; sh.vec[36] = tt[1] * nr / sc; sh.vec[37] = tt[2] * nr / sc;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int i = 0; i < 6; i++) param[i] = sh.vec[32 + i];
-    }
-
-    // ---- CvLevMarq
-    double JtJ[21], JtErr[6];
-    double prevParam[6];
-    double prevErrNorm = DBL_MAX, errNorm = 0.0;
-    int lambdaLg10 = -3, iters = 0;
-    const int max_iter = 20;
-    const double epsilon = (double)FLT_EPSILON;
-    const double LOG10 = log(10.0);
-
-    // residual (+ Jacobian) at `param`; returns |err|^2
-    auto evaluate = [&](bool needJ) -> double {
-        double R[9], dRdr[27];
-        if (needJ) agt_rodrigues<true>(param, R, dRdr); else agt_rodrigues<false>(param, R, dRdr);
-        if (needJ) {
-            double acc[NACC];
-#pragma unroll
-            for (int i = 0; i < NACC; i++) acc[i] = 0.0;
-#pragma unroll
-            for (int q = 0; q < PPL; q++) if (use[q]) {
-                double u, v, jr[6], jt[6];
-                agt_project<true>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, jr, jt);
-                const double ex = u - mu_[q], ey = v - mv_[q];
-                const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
-                const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };
-                int idx = 0;
-#pragma unroll
-                for (int a = 0; a < 6; a++) {
-#pragma unroll
-                    for (int c = a; c < 6; c++) acc[idx++] += Jx[a] * Jx[c] + Jy[a] * Jy[c];
-                    acc[21 + a] += Jx[a] * ex + Jy[a] * ey;
-                }
-                acc[27] += ex * ex + ey * ey;
-            }
-            wave_reduce_slab<NACC>(acc, sh, lane);
-#pragma unroll
-            for (int i = 0; i < 21; i++) JtJ[i] = acc[i];
-#pragma unroll
-            for (int i = 0; i < 6; i++) JtErr[i] = acc[21 + i];
-            return acc[27];
-        }
-        double e2 = 0.0;
-#pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) {
-            double u, v;
-            agt_project<false>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
-            const double ex = u - mu_[q], ey = v - mv_[q];
-            e2 += ex * ex + ey * ey;
-        }
-        return wave_sum_f64(e2);
-    };
-
-    auto step = [&]() {
-        const double lambda = exp(lambdaLg10 * LOG10);
-        double A[36], dx[6];
-        int idx = 0;
-#pragma unroll
-        for (int a = 0; a < 6; a++)
-#pragma unroll
-            for (int c = a; c < 6; c++) { A[a * 6 + c] = JtJ[idx]; A[c * 6 + a] = JtJ[idx]; idx++; }
-#pragma unroll
-        for (int a = 0; a < 6; a++) A[a * 7] *= 1.0 + lambda;
-        if (!agt_solve6(A, JtErr, dx)) {
-            flags |= AGT_PNP_SINGULAR;
-#pragma unroll
-            for (int a = 0; a < 6; a++) dx[a] = 0.0;
-        }
-#pragma unroll
-        for (int a = 0; a < 6; a++) param[a] = prevParam[a] - dx[a];
-    };
-
-    double e2 = evaluate(true);
-    for (;;) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) prevParam[i] = param[i];
-        if (iters == 0) prevErrNorm = sqrt(e2);
-        for (;;) {
-            step();
-            errNorm = sqrt(evaluate(false));
-            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) continue;
-            break;
-        }
-        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
-        double dn = 0.0, pn = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) { const double d = param[i] - prevParam[i]; dn += d * d; pn += prevParam[i] * prevParam[i]; }
-        const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
-        if (++iters >= max_iter || rel < epsilon) break;
-        prevErrNorm = errNorm;
-        e2 = evaluate(true);
-    }
-
-    // cv2 writes the result INTO the guess arrays: a float32 guess tvec (from the motion model)
-    // yields a float32-rounded tvec (solvepnp.cpp convertTo(tvec, tvec.depth()))
-    const bool tvec_f32 = ts && use_guess && guess_f32;
-    if (tvec_f32) {
-#pragma unroll
-        for (int i = 3; i < 6; i++) param[i] = (double)(float)param[i];
-    }
-
-    // ---- epilogue: mean reprojection error (transform_helper.py:98-121) at the solution
-    double esum = 0.0;
-    {
-        double R[9], dRdr[27];
-        agt_rodrigues<false>(param, R, dRdr);
-#pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) {
-            double u, v;
-            agt_project<false>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
-            const double ex = u - mu_[q], ey = v - mv_[q];
-            esum += sqrt(ex * ex + ey * ey);
-        }
-        esum = wave_sum_f64(esum) / n_used;
-    }
-    if (ts) {
-        // ---- PoseDetector._estimate_pose state update, detect_pose.py:528-574
-        const bool accepted = esum < P.gate_px;
-        if (lane == 0) {
-            int tflags = flags;
-            if (use_guess) {                    // in-place result: the guess arrays now hold the pose
-                for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
-            }
-            if (accepted) {
-                if (!had_guess || !P.enhance_ape) {
-                    for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
-                    ts->guess_t_f32 = 0; ts->has_guess = 1;
-                } else {
-                    tflags |= motion_model_update(*ts, param, tvec_f32, unchanged_prev, prev_f32 != 0);
-                }
-                if (!(tflags & AGT_TRK_ZERO_VELOCITY)) {
-                    for (int i = 0; i < 6; i++) ts->prev[i] = param[i];
-                    ts->prev_t_f32 = tvec_f32 ? 1 : 0; ts->has_prev = 1;
-                }
-            } else {
-                ts->has_guess = 0;
-            }
-            ts->frame++;
-            if (P.state_out) {
-                double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
-                for (int i = 0; i < 6; i++) so[i] = param[i];
-                so[AGT_ST_OK] = accepted ? 1.0 : 0.0; so[AGT_ST_ERR] = esum; so[AGT_ST_NTRACK] = n_used;
-                so[AGT_ST_ITERS] = iters; so[AGT_ST_GUESS] = use_guess ? 1.0 : 0.0; so[AGT_ST_FLAGS] = tflags;
-                so[AGT_ST_TVEC_F32] = tvec_f32 ? 1.0 : 0.0;
-                for (int i = AGT_ST_TVEC_F32 + 1; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-            }
-        }
-        if (accepted && P.reproject && P.corners_rw) {
-            // refresh the whole corner set with projectPoints(all_objpts) (detect_pose.py:455-461)
-            double R[9], dRdr[27];
-            agt_rodrigues<false>(param, R, dRdr);
-            float* cw = P.corners_rw + (long)b * n * 2;
-            for (int i = lane; i < n; i += AGT_WAVE) {
-                double u, v;
-                agt_project<false>(cam, R, dRdr, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2],
-                                   u, v, nullptr, nullptr);
-                cw[i * 2] = (float)u; cw[i * 2 + 1] = (float)v;
-            }
-        }
-        return;
-    }
-    if (lane == 0) {
-#pragma unroll
-        for (int i = 0; i < 6; i++) P.pose[(long)b * 6 + i] = param[i];
-        if (P.info) {
-            P.info[b * 4 + AGT_INFO_OK] = 1; P.info[b * 4 + AGT_INFO_ITERS] = iters;
-            P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = flags;
-        }
-        if (P.err) P.err[b] = esum;
-    }
+    __shared__ agt_pnp::PnpShared sh;
+    agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh);
 }
 
 template <typename T>
@@ -575,7 +46,7 @@ hipError_t launch_pnp_t(hipStream_t stream, const AgtPnpParams& p, int B)
 {
     dim3 grid(B), block(AGT_WAVE);
     if (p.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_kernel<T, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((pnp_kernel<T, MAX_PPL>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((pnp_kernel<T, agt_pnp::MAX_PPL>), grid, block, 0, stream, p);
     return hipGetLastError();
 }
 
@@ -583,7 +54,7 @@ hipError_t launch_pnp_t(hipStream_t stream, const AgtPnpParams& p, int B)
 
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B)
 {
-    if (p.n > AGT_WAVE * MAX_PPL) return hipErrorInvalidValue;
+    if (p.n > AGT_WAVE * agt_pnp::MAX_PPL) return hipErrorInvalidValue;
     return p.dtype == AGT_F64 ? launch_pnp_t<double>(stream, p, B) : launch_pnp_t<float>(stream, p, B);
 }
 

@@ -31,7 +31,7 @@ SYMBOLS = [
     "agt_pyramid_level", "agt_pyramid_max_level", "agt_lk_track", "agt_solve_pnp",
     "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
-    "agt_profile_begin", "agt_profile_end",
+    "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
 ]
 
 
@@ -90,6 +90,8 @@ def lib():
     L.agt_tracker_state_read.argtypes = [vp, vp, i32]
     L.agt_track_frame.argtypes = [vp, vp, sz, sz, i32, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
+    L.agt_tracker_pipeline.argtypes = [vp, i32]
+    L.agt_tracker_join.argtypes = [vp]
     L.agt_profile_begin.argtypes = [vp, i32]
     L.agt_profile_end.argtypes = [vp, vp, C.POINTER(i32)]
     _lib = L

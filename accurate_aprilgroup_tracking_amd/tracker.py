@@ -38,8 +38,7 @@ class StreamTracker:
         assert H.lib().agt_tracker_state_size() == C.sizeof(TrackState)
         H.check(self.ctx.L.agt_tracker_options(self.ctx.h, int(reproject), int(min_points), float(gate_px)),
                 "agt_tracker_options")
-        self._frames = None
-        self._slot = 0
+        self._alive = []            # frames aliased by pyramid level 0 of the three ring slots
 
     def _dist_ptr(self):
         return self.dist.ctypes.data_as(C.c_void_p) if self.ndist else None
@@ -54,17 +53,27 @@ class StreamTracker:
         H.check(self.ctx.L.agt_tracker_reset(self.ctx.h, 0, _ptr(corners), _ptr(self.obj), self.n, self.B,
                                              self.K.ctypes.data_as(C.c_void_p), self._dist_ptr(), self.ndist,
                                              int(self.enhance_ape)), "agt_tracker_reset")
-        self._frames = frames
-        self._slot = 0
+        self._alive = [frames]
+
+    def pipeline(self, enable):
+        """Software-pipelined fused step (default on): one launch per frame, poses L+1 steps late."""
+        H.check(self.ctx.L.agt_tracker_pipeline(self.ctx.h, int(bool(enable))), "agt_tracker_pipeline")
 
     def step(self, frames, state_out=None):
-        """frames: cuda u8 [B,H,W] (kept alive until the following step).  state_out: cuda f64
-        [B, STATE_STRIDE] or None.  Enqueues only."""
+        """frames: cuda u8 [B,H,W] (a reference is kept while the frame is in flight: level 0 of the
+        pyramid ring aliases it).  state_out: cuda f64 [B, STATE_STRIDE] or None; with the pipeline on
+        it is written a few steps later -- call join() before consuming it.  Enqueues only."""
         assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
         H.check(self.ctx.L.agt_track_frame(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
                                            _ptr(state_out)), "agt_track_frame")
-        self._prev_frames, self._frames = self._frames, frames     # level 0 of both slots aliases these
+        self._alive.append(frames)
+        if len(self._alive) > 6:
+            del self._alive[0]
         return state_out
+
+    def join(self):
+        """Enqueue the remaining pipeline stages of every supplied frame (no host synchronisation)."""
+        H.check(self.ctx.L.agt_tracker_join(self.ctx.h), "agt_tracker_join")
 
     def estimate_pose(self, corners, mask=None, state_out=None):
         """PoseDetector._estimate_pose on device state with supplied corners (cuda f32 [B,n,2])."""

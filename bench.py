@@ -98,10 +98,12 @@ def main():
     state = torch.zeros((total, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
     trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
     run(Wm, 1, state[:Wm])
+    trk.join()
     D.gather_poses(state[:Wm])                    # warm the communicator outside the timed region
     torch.cuda.synchronize(); D.barrier()
     t0 = time.perf_counter()
     run(K, 1 + Wm, state[Wm:])
+    trk.join()                                    # current stream waits for the frames in flight
     # the only collective: the per-frame state records (128 B per stream-frame), once per chunk of
     # K frames.  state[Wm:] is already contiguous: no torch kernel runs inside the timed region.
     gathered = D.gather_poses(state[Wm:])

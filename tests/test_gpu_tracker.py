@@ -95,8 +95,8 @@ def test_pose_detector_mirror_on_hip_backend(tmp_path, name):
             assert np.abs(g - fx["guess"][k]).max() < POSE_TOL
 
 
-@pytest.mark.parametrize("reproject", [False, True])
-def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, reproject):
+@pytest.mark.parametrize("reproject,pipeline", [(False, True), (True, True), (False, False)])
+def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, reproject, pipeline):
     """GPU: StreamTracker.step over rendered frames.  CPU: oracle LK + the (reference-validated)
     PoseDetector mirror on the oracle backend, fed per-corner."""
     torch = torch_cuda
@@ -111,6 +111,7 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
     tol = 1e-6 if reproject else POSE_TOL
     frames = torch.from_numpy(s.frames()).cuda()                      # [F,H,W]
     trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2, reproject=reproject)
+    trk.pipeline(pipeline)
     c0 = torch.from_numpy(np.stack([s.corners(0), s.corners(0)])).cuda().contiguous()
     two = lambda k: torch.stack([frames[k], frames[k]]).contiguous()
     f_prev = two(0)
@@ -131,6 +132,7 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
     for k in range(1, F):
         f = two(k); keep.append(f)
         trk.step(f, so)
+        trk.join()
         st = so.cpu().numpy()
         npyr = oracle.Pyramid(s.frame(k))
         nx, status, _ = oracle.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
@@ -155,6 +157,31 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
     assert states[0].frame == F - 1 and states[0].has_guess == 1
     g = np.concatenate([det.extrinsic_guess[0].ravel(), det.extrinsic_guess[1].ravel()]).astype(np.float64)
     assert np.abs(np.array(states[1].guess[:]) - g).max() < 10 * tol
+
+
+def test_pipelined_stream_equals_serial(torch_cuda, seq640):
+    """many frames enqueued back-to-back with NO host sync: the three-stream overlap must give
+    bit-identical state records to the serial order (dependencies are exact, not heuristic)"""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    F = len(s)
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0] * 3
+    outs = []
+    for mode in (False, True):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+        trk.pipeline(mode)
+        trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+        so = trk.new_state_buffer(len(order))
+        for i, k in enumerate(order):
+            trk.step(frames[k:k + 1], so[i])
+        trk.join()
+        outs.append(so.cpu().numpy())
+        assert trk.read_state()[0].frame == len(order)
+    assert np.array_equal(outs[0], outs[1])
+    assert outs[0][:, 0, H.ST_OK].all()
 
 
 def test_track_frame_argument_and_state_errors(torch_cuda):

@@ -10,9 +10,10 @@ from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
 W, H = 1280, 720
 seq = syn.Sequence(W, H, n_frames=8, seed=0, supersample=2)
 fr = torch.from_numpy(seq.frames()).cuda()
-for B in (1, 8, 64):
+for B, pipe in ((1, 0), (1, 1), (8, 0), (8, 1), (64, 0), (64, 1)):
     ring = torch.stack([fr[(i % 8) if (i // 8) % 2 == 0 else 7 - (i % 8)].unsqueeze(0).expand(B, H, W) for i in range(32)]).contiguous()
     trk = StreamTracker(W, H, seq.obj, seq.K, None, n_streams=B)
+    trk.pipeline(pipe)
     c0 = torch.from_numpy(np.repeat(seq.corners(0)[None], B, 0)).cuda().contiguous()
     trk.reset(ring[0], c0)
     for k in range(20):
@@ -23,9 +24,10 @@ for B in (1, 8, 64):
     for k in range(K):
         trk.step(ring[(k + 21) % 32])
     t1 = time.perf_counter()
-    torch.cuda.synchronize()
+    trk.join(); torch.cuda.synchronize()
     t2 = time.perf_counter()
-    print("B=%d enqueue %.1f us/step, total %.1f us/step, %.0f frames/s" % (B, (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6, B * K / (t2 - t0)))
+    print("B=%d pipe=%d enqueue %.1f us/step, total %.1f us/step, %.0f frames/s" % (B, pipe, (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6, B * K / (t2 - t0)))
+    continue
     # raw ctypes call cost with prebuilt pointers
     L = trk.ctx.L; h = trk.ctx.h
     ptrs = [ring[i].data_ptr() for i in range(32)]
