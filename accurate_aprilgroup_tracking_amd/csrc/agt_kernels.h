@@ -106,4 +106,5 @@ hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B)
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
+bool agt_step_fits(int n, int B);   // the fused launch is used for small, latency-bound launches only
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win);

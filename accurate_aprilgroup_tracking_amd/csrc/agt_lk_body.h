@@ -194,15 +194,18 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
     const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
     const long pidx = (long)b * P.n + pt;
 
-    // window pixels of this thread
-    int px[C::NPX], py[C::NPX];
+    // window pixels of this thread, as byte / element offsets into the three LDS tiles (computed once;
+    // threads without a k-th pixel point at offset 0 and are masked arithmetically, not by branches)
+    int oI[C::NPX], oD[C::NPX], oJ[C::NPX];
     bool pv[C::NPX];
 #pragma unroll
     for (int k = 0; k < C::NPX; k++) {
         const int p = tid + k * T;
         pv[k] = p < WIN * WIN;
-        py[k] = pv[k] ? p / WIN : 0;
-        px[k] = pv[k] ? p - py[k] * WIN : 0;
+        const int y = pv[k] ? p / WIN : 0, x = pv[k] ? p - y * WIN : 0;
+        oI[k] = (y + 1) * C::IP + (x + 1);
+        oD[k] = y * C::DW + x;
+        oJ[k] = y * C::JP + x;
     }
 
     const float halfw = (WIN - 1) * 0.5f;
@@ -301,16 +304,14 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
         int asum[3] = { 0, 0, 0 };
 #pragma unroll
         for (int k = 0; k < C::NPX; k++) {
-            Iv[k] = 0; Ix[k] = 0; Iy[k] = 0;
-            if (pv[k]) {
-                const uint8_t* p = sI + (py[k] + 1) * C::IP + (px[k] + 1) + offI;
-                Iv[k] = descale(bil4(p[0], p[1], p[C::IP], p[C::IP + 1], iw00, iw01, iw10, iw11), W_BITS - 5);
-                const int* d = sD + py[k] * C::DW + px[k];
-                const int d00 = d[0], d01 = d[1], d10 = d[C::DW], d11 = d[C::DW + 1];
-                Ix[k] = descale(bil4((short)d00, (short)d01, (short)d10, (short)d11, iw00, iw01, iw10, iw11), W_BITS);
-                Iy[k] = descale(bil4(d00 >> 16, d01 >> 16, d10 >> 16, d11 >> 16, iw00, iw01, iw10, iw11), W_BITS);
-                asum[0] += __mul24(Ix[k], Ix[k]); asum[1] += __mul24(Ix[k], Iy[k]); asum[2] += __mul24(Iy[k], Iy[k]);
-            }
+            const uint8_t* p = sI + oI[k] + offI;
+            const int iv = descale(bil4(p[0], p[1], p[C::IP], p[C::IP + 1], iw00, iw01, iw10, iw11), W_BITS - 5);
+            const int* d = sD + oD[k];
+            const int d00 = d[0], d01 = d[1], d10 = d[C::DW], d11 = d[C::DW + 1];
+            const int ix = descale(bil4((short)d00, (short)d01, (short)d10, (short)d11, iw00, iw01, iw10, iw11), W_BITS);
+            const int iy = descale(bil4(d00 >> 16, d01 >> 16, d10 >> 16, d11 >> 16, iw00, iw01, iw10, iw11), W_BITS);
+            Iv[k] = pv[k] ? iv : 0; Ix[k] = pv[k] ? ix : 0; Iy[k] = pv[k] ? iy : 0;
+            asum[0] += __mul24(Ix[k], Ix[k]); asum[1] += __mul24(Ix[k], Iy[k]); asum[2] += __mul24(Iy[k], Iy[k]);
         }
         long long at[3];
         block_sum_exact<NW, C::SUM_STEPS, 3>(asum, at, slots, phase, wave, lane);
@@ -346,32 +347,36 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
             const uint8_t* q0 = sJ + (iny - jy0) * C::JP + (inx - jx0) + (jx0 - (jx0 & ~3));
 #pragma unroll
             for (int k = 0; k < C::NPX; k++) {
-                if (pv[k]) {
-                    const uint8_t* q = q0 + py[k] * C::JP + px[k];
-                    const int diff = descale(bil4(q[0], q[1], q[C::JP], q[C::JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5) - Iv[k];
-                    if (want_abs) acc[0] += diff < 0 ? -diff : diff;
-                    else { acc[0] += __mul24(diff, Ix[k]); acc[1] += __mul24(diff, Iy[k]); }
-                }
+                const uint8_t* q = q0 + oJ[k];
+                const int diff = descale(bil4(q[0], q[1], q[C::JP], q[C::JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5) - Iv[k];
+                if (want_abs) acc[0] += pv[k] ? (diff < 0 ? -diff : diff) : 0;
+                else { acc[0] += __mul24(diff, Ix[k]); acc[1] += __mul24(diff, Iy[k]); }   // Ix = Iy = 0 where !pv
             }
         };
         for (int j = 0; j < P.max_count; j++) {
+            if (j == 1) STAMP(39);
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
                 if (level == 0) st = 0;
                 break;
             }
+            if (j == 1) STAMP(40);
             if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
             bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
+            if (j == 1) STAMP(41);
             int bsum[2];
             window_pass(inx, iny, false, bsum);
+            if (j == 1) STAMP(42);
             long long bt[2];
             block_sum_exact<NW, C::SUM_STEPS, 2>(bsum, bt, slots, phase, wave, lane);
+            if (j == 1) STAMP(43);
             const float fb1 = (float)(double)bt[0] * FLT_SCALE;
             const float fb2 = (float)(double)bt[1] * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nextx += dx; nexty += dy;
             outx = nextx + halfw; outy = nexty + halfw;
+            if (j == 1) STAMP(44);
             if (j == 0) STAMP(8 + level * 8 + 3);
 #ifdef AGT_LK_STAMPS
             if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
@@ -382,6 +387,7 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
                 break;
             }
             pdx = dx; pdy = dy;
+            if (j == 1) STAMP(45);
         }
 
         STAMP(8 + level * 8 + 4);

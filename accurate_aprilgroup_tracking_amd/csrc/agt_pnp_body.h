@@ -16,8 +16,21 @@
 // damped LDL^T solve and the termination test run inside the launch; the host sees one
 // kernel per batch of B independent problems.
 #pragma once
+#include <type_traits>
 #include "agt_device.h"
 #include "agt_kernels.h"
+
+// In-kernel cycle stamps (diagnostic builds only: make dbg; never in the shipped library).
+#ifdef AGT_PNP_STAMPS
+__device__ unsigned long long agt_pnp_stamps[64];
+#define PSTAMP(i) do { if (b == 0 && threadIdx.x == 0) agt_pnp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int agt_debug_pnp_stamps(unsigned long long* host64)
+{
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(agt_pnp_stamps), sizeof(agt_pnp_stamps));
+}
+#else
+#define PSTAMP(i)
+#endif
 
 namespace agt_pnp {
 
@@ -32,8 +45,9 @@ struct PnpShared {
     double vec[48];
 };
 
-// sum K per-lane partials across the wave; totals come back in vals[] of every lane
-template <int K>
+// sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
+// vals[] of every lane
+template <int K, bool READBACK = true>
 __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& sh, int lane)
 {
     static_assert(K <= 32, "one pass handles at most 32 sums");
@@ -51,8 +65,10 @@ __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& s
     s += __shfl_xor(s, 32);
     if (lane < K) sh.tot[lane] = s;
     __syncthreads();
+    if (READBACK) {
 #pragma unroll
-    for (int i = 0; i < K; i++) vals[i] = sh.tot[i];
+        for (int i = 0; i < K; i++) vals[i] = sh.tot[i];
+    }
 }
 
 __device__ __forceinline__ double wave_sum_f64(double v)
@@ -128,26 +144,15 @@ __device__ void smallest_eigvec(double* A, int n, double* v, double* tmp)
     }
 }
 
-// ---- motion model of PoseDetector (serial, one lane) ------------------------------------
-// transform_helper.py:239-259 rotation_matrix_to_euler_angles
-__device__ inline void rot_to_euler(const double R[9], double e[3])
+// broadcast lane `src`'s double to the whole wave through SGPRs (no LDS)
+__device__ __forceinline__ double lane_bcast(double v, int src)
 {
-    const double sy = sqrt(R[0] * R[0] + R[3] * R[3]);
-    if (!(sy < 1e-6)) { e[0] = atan2(R[7], R[8]); e[1] = atan2(-R[6], sy); e[2] = atan2(R[3], R[0]); }
-    else { e[0] = atan2(-R[5], R[4]); e[1] = atan2(-R[6], sy); e[2] = 0.0; }
+    const long long bits = __double_as_longlong(v);
+    const int lo = __builtin_amdgcn_readlane((int)bits, src), hi = __builtin_amdgcn_readlane((int)(bits >> 32), src);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
-// transform_helper.py:215-236 euler_angles_to_rotation_matrix: R = Rz * Ry * Rx
-__device__ inline void euler_to_rot(const double e[3], double R[9])
-{
-    double sx, cx, sy, cy, sz, cz;
-    sincos(e[0], &sx, &cx); sincos(e[1], &sy, &cy); sincos(e[2], &sz, &cz);
-    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx };
-    const double Ry[9] = { cy, 0, sy, 0, 1, 0, -sy, 0, cy };
-    const double Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
-    double T[9];
-    agt_mat3_mul(Ry, Rx, T);
-    agt_mat3_mul(Rz, T, R);
-}
+
+// ---- motion model of PoseDetector (wave-cooperative: independent trig runs on separate lanes) ------------------------------------
 // A^T B
 __device__ inline void mat3_tmul(const double A[9], const double B[9], double C[9])
 {
@@ -164,13 +169,19 @@ __device__ inline void mat3_tvec(const double A[9], const double v[3], double o[
 }
 
 // detect_pose.py:553-566: get_pose_vel_acc (245-301) + _update_buffers (229-243) +
-// apply_vel_acc (303-349).  curr/prev = (rvec, tvec).  Returns AGT_TRK_* flags.
-__device__ inline int motion_model_update(AgtTrackState& ts, const double curr[6], bool curr_t_f32,
+// apply_vel_acc (303-349).  curr/prev = (rvec, tvec).  Called by EVERY lane of the wave with
+// uniform arguments (ts_in = the state as read before this frame); lane 0 stores the result.
+// Returns AGT_TRK_* flags (uniform).
+__device__ inline int motion_model_update(AgtTrackState* ts, int lane, const double curr[6], bool curr_t_f32,
                                           const double prev[6], bool prev_t_f32)
 {
-    double Rp[9], Rc[9];
-    agt_rodrigues<false>(prev, Rp, nullptr);
-    agt_rodrigues<false>(curr, Rc, nullptr);
+    // Rodrigues(prev) on lane 0, Rodrigues(curr) elsewhere: one pass for both
+    double rin[3], Rl[9], Rp[9], Rc[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) rin[i] = lane == 0 ? prev[i] : curr[i];
+    agt_rodrigues<false>(rin, Rl, nullptr);
+#pragma unroll
+    for (int i = 0; i < 9; i++) { Rp[i] = lane_bcast(Rl[i], 0); Rc[i] = lane_bcast(Rl[i], 1); }
     // get_relative_trans (transform_helper.py:184): rot_mat.T @ (tvec0 - tvec1); numpy subtracts in
     // float32 when both operands are float32 arrays
     double d[3], tran_vel[3], rot_vel[9];
@@ -185,36 +196,65 @@ __device__ inline int motion_model_update(AgtTrackState& ts, const double curr[6
 #pragma unroll
     for (int i = 0; i < 3; i++) any_zero |= tran_vel[i] == 0.0;
     if (any_zero) return AGT_TRK_ZERO_VELOCITY;  // reference raises ValueError here
-    if (ts.n_vel >= 2) {
-        for (int i = 0; i < 9; i++) ts.rot_vel[0][i] = ts.rot_vel[1][i];
-        for (int i = 0; i < 3; i++) ts.tran_vel[0][i] = ts.tran_vel[1][i];
-        ts.n_vel = 1;
+    // _update_buffers: keep the last two velocities
+    const int n_before = ts->n_vel;
+    double old_rv[9], old_tv[3];
+    const int old_slot = n_before >= 2 ? 1 : 0;  // the entry that becomes "previous velocity"
+#pragma unroll
+    for (int i = 0; i < 9; i++) old_rv[i] = ts->rot_vel[old_slot][i];
+#pragma unroll
+    for (int i = 0; i < 3; i++) old_tv[i] = ts->tran_vel[old_slot][i];
+    const int n_after = n_before >= 2 ? 2 : n_before + 1;
+    if (lane == 0) {
+        if (n_before >= 2) {
+            for (int i = 0; i < 9; i++) ts->rot_vel[0][i] = old_rv[i];
+            for (int i = 0; i < 3; i++) ts->tran_vel[0][i] = old_tv[i];
+        }
+        const int slot = n_after - 1;
+        for (int i = 0; i < 9; i++) ts->rot_vel[slot][i] = rot_vel[i];
+        for (int i = 0; i < 3; i++) ts->tran_vel[slot][i] = tran_vel[i];
+        ts->n_vel = n_after;
     }
-    const int slot = ts.n_vel;
-    for (int i = 0; i < 9; i++) ts.rot_vel[slot][i] = rot_vel[i];
-    for (int i = 0; i < 3; i++) ts.tran_vel[slot][i] = tran_vel[i];
-    ts.n_vel = slot + 1;
-    if (ts.n_vel < 2) return 0;                  // success = False: the guess is left as is
-    double dv[3], tran_acc[3], rot_acc[9], old_rv[9];
-    for (int i = 0; i < 3; i++) dv[i] = ts.tran_vel[0][i] - tran_vel[i];
-    for (int i = 0; i < 9; i++) old_rv[i] = ts.rot_vel[0][i];
+    if (n_after < 2) return 0;                   // success = False: the guess is left as is
+    double dv[3], tran_acc[3], rot_acc[9];
+#pragma unroll
+    for (int i = 0; i < 3; i++) dv[i] = old_tv[i] - tran_vel[i];
     mat3_tvec(rot_vel, dv, tran_acc);
     mat3_tmul(rot_vel, old_rv, rot_acc);
-    // apply_vel_acc on the PREVIOUS pose
-    double e[3], RA[9], M[9], Rpred[9], tp[3], tpred[3];
-    rot_to_euler(rot_acc, e);
-    e[0] *= 0.5; e[1] *= 0.5; e[2] *= 0.5;
-    euler_to_rot(e, RA);
-    agt_mat3_mul(RA, rot_vel, M);                // (acc @ vel) @ pose
+    // rotation_matrix_to_euler_angles (transform_helper.py:239-259), three atan2 on three lanes
+    const double sy = sqrt(rot_acc[0] * rot_acc[0] + rot_acc[3] * rot_acc[3]);
+    const bool sing = sy < 1e-6;
+    double ay, ax;
+    if (lane == 0) { ay = sing ? -rot_acc[5] : rot_acc[7]; ax = sing ? rot_acc[4] : rot_acc[8]; }
+    else if (lane == 1) { ay = -rot_acc[6]; ax = sy; }
+    else { ay = sing ? 0.0 : rot_acc[3]; ax = sing ? 1.0 : rot_acc[0]; }
+    const double ang = atan2(ay, ax) * 0.5;      // apply_vel_acc halves the Euler angles
+    // euler_angles_to_rotation_matrix (transform_helper.py:215-236): R = Rz Ry Rx, three sincos on three lanes
+    double sn, cs;
+    sincos(ang, &sn, &cs);
+    const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0);
+    const double sy2 = lane_bcast(sn, 1), cy = lane_bcast(cs, 1);
+    const double sz = lane_bcast(sn, 2), cz = lane_bcast(cs, 2);
+    const double Rx[9] = { 1, 0, 0, 0, cx, -sx, 0, sx, cx };
+    const double Ry[9] = { cy, 0, sy2, 0, 1, 0, -sy2, 0, cy };
+    const double Rz[9] = { cz, -sz, 0, sz, cz, 0, 0, 0, 1 };
+    double Tm[9], RA[9], M[9], Rpred[9], tp[3], tpred[3];
+    agt_mat3_mul(Ry, Rx, Tm);
+    agt_mat3_mul(Rz, Tm, RA);
+    agt_mat3_mul(RA, rot_vel, M);                // (acc @ vel) @ pose, on the PREVIOUS pose
     agt_mat3_mul(M, Rp, Rpred);
+#pragma unroll
     for (int i = 0; i < 3; i++) tp[i] = prev[3 + i];
+#pragma unroll
     for (int i = 0; i < 3; i++)
         tpred[i] = (M[i * 3] * tp[0] + M[i * 3 + 1] * tp[1] + M[i * 3 + 2] * tp[2]) +
                    (RA[i * 3] * tran_vel[0] + RA[i * 3 + 1] * tran_vel[1] + RA[i * 3 + 2] * tran_vel[2] + 0.5 * tran_acc[i]);
     double rpred[3];
     agt_rodrigues_inv(Rpred, rpred);
-    for (int i = 0; i < 3; i++) { ts.guess[i] = rpred[i]; ts.guess[3 + i] = (double)(float)tpred[i]; }
-    ts.guess_t_f32 = 1;                          // get_rmat_tvec casts to float32 (transform_helper.py:158-159)
+    if (lane == 0) {
+        for (int i = 0; i < 3; i++) { ts->guess[i] = rpred[i]; ts->guess[3 + i] = (double)(float)tpred[i]; }
+        ts->guess_t_f32 = 1;                     // get_rmat_tvec casts to float32 (transform_helper.py:158-159)
+    }
     return 0;
 }
 
@@ -224,6 +264,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 {
     const int lane = threadIdx.x;
     const int n = P.n;
+    PSTAMP(0);
     AgtCamera cam;
     load_cam<T>(P.cam, cam);
 
@@ -377,14 +418,29 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     double prevParam[6];
     double prevErrNorm = DBL_MAX, errNorm = 0.0;
     int lambdaLg10 = -3, iters = 0;
+    double lambda = 1e-3;
     const int max_iter = 20;
     const double epsilon = (double)FLT_EPSILON;
-    const double LOG10 = log(10.0);
 
-    // residual (+ Jacobian) at `param`; returns |err|^2
-    auto evaluate = [&](bool needJ) -> double {
+    bool has_dist = false;
+#pragma unroll
+    for (int i = 0; i < 12; i++) has_dist |= cam.k[i] != 0.0;
+    double rex[PPL], rey[PPL];       // residuals of the most recent evaluation (re-used by the epilogue)
+#pragma unroll
+    for (int q = 0; q < PPL; q++) { rex[q] = 0.0; rey[q] = 0.0; }
+
+    // residual (+ Jacobian) at `param`; returns |err|^2.  DIST is a std::integral_constant tag.
+    // mode 0: residuals only.  mode 1: + J^T J / J^T e into the registers.  mode 2: + J^T J / J^T e left in
+    // sh.tot as a CANDIDATE (CvLevMarq asks for J at exactly these parameters next, unless the step
+    // is rejected or the solve terminates; evaluating it now saves a second projection pass).
+    double Rlast[9];
+    auto evaluate_t = [&](int mode, auto DIST) -> double {
+        constexpr bool D = decltype(DIST)::value;
+        const bool needJ = mode != 0;
         double R[9], dRdr[27];
         if (needJ) agt_rodrigues<true>(param, R, dRdr); else agt_rodrigues<false>(param, R, dRdr);
+#pragma unroll
+        for (int i = 0; i < 9; i++) Rlast[i] = R[i];
         if (needJ) {
             double acc[NACC];
 #pragma unroll
@@ -392,8 +448,9 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 #pragma unroll
             for (int q = 0; q < PPL; q++) if (use[q]) {
                 double u, v, jr[6], jt[6];
-                agt_project<true>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, jr, jt);
+                agt_project<true, D>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, jr, jt);
                 const double ex = u - mu_[q], ey = v - mv_[q];
+                rex[q] = ex; rey[q] = ey;
                 const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
                 const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };
                 int idx = 0;
@@ -404,6 +461,10 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                     acc[21 + a] += Jx[a] * ex + Jy[a] * ey;
                 }
                 acc[27] += ex * ex + ey * ey;
+            }
+            if (mode == 2) {
+                wave_reduce_slab<NACC, false>(acc, sh, lane);
+                return sh.tot[27];
             }
             wave_reduce_slab<NACC>(acc, sh, lane);
 #pragma unroll
@@ -416,15 +477,35 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 #pragma unroll
         for (int q = 0; q < PPL; q++) if (use[q]) {
             double u, v;
-            agt_project<false>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
+            agt_project<false, D>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
             const double ex = u - mu_[q], ey = v - mv_[q];
+            rex[q] = ex; rey[q] = ey;
             e2 += ex * ex + ey * ey;
         }
         return wave_sum_f64(e2);
     };
+    auto evaluate = [&](int mode) -> double {
+        return has_dist ? evaluate_t(mode, std::true_type{}) : evaluate_t(mode, std::false_type{});
+    };
+    auto commit_candidate = [&]() {
+#pragma unroll
+        for (int i = 0; i < 21; i++) JtJ[i] = sh.tot[i];
+#pragma unroll
+        for (int i = 0; i < 6; i++) JtErr[i] = sh.tot[21 + i];
+    };
+    // residuals at `param` re-using the rotation of the last evaluation (only tvec changed)
+    auto residuals_same_rotation = [&](auto DIST) {
+        constexpr bool D = decltype(DIST)::value;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) if (use[q]) {
+            double u, v;
+            agt_project<false, D>(cam, Rlast, nullptr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
+            rex[q] = u - mu_[q]; rey[q] = v - mv_[q];
+        }
+    };
 
     auto step = [&]() {
-        const double lambda = exp(lambdaLg10 * LOG10);
+        // lambda tracks 10^lambdaLg10 incrementally (OpenCV: exp(lambdaLg10 * log(10)); equal to ~1 ulp)
         double A[36], dx[6];
         int idx = 0;
 #pragma unroll
@@ -442,26 +523,41 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         for (int a = 0; a < 6; a++) param[a] = prevParam[a] - dx[a];
     };
 
-    double e2 = evaluate(true);
+    PSTAMP(1);
+    double e2 = evaluate(1);
+    PSTAMP(2);
     for (;;) {
 #pragma unroll
         for (int i = 0; i < 6; i++) prevParam[i] = param[i];
         if (iters == 0) prevErrNorm = sqrt(e2);
+        double rel = 0.0, e2cand = 0.0;
+        bool last = false;
         for (;;) {
+            PSTAMP(8 + iters * 4 + 0);
             step();
-            errNorm = sqrt(evaluate(false));
-            if (errNorm > prevErrNorm && ++lambdaLg10 <= 16) continue;
+            PSTAMP(8 + iters * 4 + 1);
+            // CvLevMarq's termination test depends on the parameters only, so it is known before the
+            // residuals are: a terminating step needs no Jacobian, any other one will need it
+            double dn = 0.0, pn = 0.0;
+#pragma unroll
+            for (int i = 0; i < 6; i++) { const double d = param[i] - prevParam[i]; dn += d * d; pn += prevParam[i] * prevParam[i]; }
+            rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
+            last = iters + 1 >= max_iter || rel < epsilon;
+            e2cand = evaluate(last ? 0 : 2);
+            errNorm = sqrt(e2cand);
+            PSTAMP(8 + iters * 4 + 2);
+            if (errNorm > prevErrNorm) { ++lambdaLg10; lambda *= 10.0; if (lambdaLg10 <= 16) continue; }
             break;
         }
-        lambdaLg10 = lambdaLg10 - 1 > -16 ? lambdaLg10 - 1 : -16;
-        double dn = 0.0, pn = 0.0;
-#pragma unroll
-        for (int i = 0; i < 6; i++) { const double d = param[i] - prevParam[i]; dn += d * d; pn += prevParam[i] * prevParam[i]; }
-        const double rel = sqrt(dn) / (sqrt(pn) + DBL_EPSILON);
-        if (++iters >= max_iter || rel < epsilon) break;
+        if (lambdaLg10 - 1 >= -16) { lambdaLg10 -= 1; lambda *= 0.1; } else { lambdaLg10 = -16; lambda = 1e-16; }
+        ++iters;
+        if (last) break;
         prevErrNorm = errNorm;
-        e2 = evaluate(true);
+        commit_candidate();          // J^T J, J^T e at the accepted parameters (was: a fresh evaluate(true))
+        e2 = e2cand;
+        PSTAMP(8 + (iters - 1) * 4 + 3);
     }
+    PSTAMP(3);
 
     // cv2 writes the result INTO the guess arrays: a float32 guess tvec (from the motion model)
     // yields a float32-rounded tvec (solvepnp.cpp convertTo(tvec, tvec.depth()))
@@ -472,33 +568,30 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     }
 
     // ---- epilogue: mean reprojection error (transform_helper.py:98-121) at the solution
+    // The LM loop always ends right after an error evaluation at the final parameters, so the
+    // residuals are already in registers; only the float32 tvec case re-projects.
     double esum = 0.0;
     {
-        double R[9], dRdr[27];
-        agt_rodrigues<false>(param, R, dRdr);
+        if (tvec_f32) { if (has_dist) residuals_same_rotation(std::true_type{}); else residuals_same_rotation(std::false_type{}); }
 #pragma unroll
-        for (int q = 0; q < PPL; q++) if (use[q]) {
-            double u, v;
-            agt_project<false>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
-            const double ex = u - mu_[q], ey = v - mv_[q];
-            esum += sqrt(ex * ex + ey * ey);
-        }
+        for (int q = 0; q < PPL; q++) if (use[q]) esum += sqrt(rex[q] * rex[q] + rey[q] * rey[q]);
         esum = wave_sum_f64(esum) / n_used;
     }
+    PSTAMP(4);
     if (ts) {
         // ---- PoseDetector._estimate_pose state update, detect_pose.py:528-574
         const bool accepted = esum < P.gate_px;
+        int tflags = flags;
+        if (lane == 0 && use_guess) {           // in-place result: the guess arrays now hold the pose
+            for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
+        }
+        if (accepted && had_guess && P.enhance_ape)
+            tflags |= motion_model_update(ts, lane, param, tvec_f32, unchanged_prev, prev_f32 != 0);
         if (lane == 0) {
-            int tflags = flags;
-            if (use_guess) {                    // in-place result: the guess arrays now hold the pose
-                for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
-            }
             if (accepted) {
                 if (!had_guess || !P.enhance_ape) {
                     for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
                     ts->guess_t_f32 = 0; ts->has_guess = 1;
-                } else {
-                    tflags |= motion_model_update(*ts, param, tvec_f32, unchanged_prev, prev_f32 != 0);
                 }
                 if (!(tflags & AGT_TRK_ZERO_VELOCITY)) {
                     for (int i = 0; i < 6; i++) ts->prev[i] = param[i];
@@ -508,6 +601,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 ts->has_guess = 0;
             }
             ts->frame++;
+            PSTAMP(5);
             if (P.state_out) {
                 double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
                 for (int i = 0; i < 6; i++) so[i] = param[i];

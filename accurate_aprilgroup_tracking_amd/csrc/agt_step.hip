@@ -11,6 +11,7 @@
 //
 // Bodies: agt_pyramid_body.h, agt_lk_body.h, agt_pnp_body.h (shared with the stand-alone kernels).
 #undef AGT_LK_STAMPS
+#undef AGT_PNP_STAMPS
 #include "agt_pyramid_body.h"
 #include "agt_lk_body.h"
 #include "agt_pnp_body.h"
@@ -51,8 +52,7 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
     if (blk < S.n_pnp) {
         if (threadIdx.x >= AGT_WAVE) return;
         agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        if (S.pnp.n <= AGT_WAVE) agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh);
-        else agt_pnp::pnp_body<float, agt_pnp::MAX_PPL>(S.pnp, blk, sh);
+        agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh);        // fused path: n <= 64 (agt_step_supported)
     }
 }
 
@@ -82,6 +82,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S)
 }  // namespace
 
 bool agt_step_supported(int win) { return win == 21; }
+bool agt_step_fits(int n, int B) { return n <= AGT_WAVE && (long)n * B <= 128; }
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win)
 {

@@ -24,3 +24,6 @@ for rep in range(3):
         b = 8 + lv * 8
         print("   level %d: start %.2f  scharr+%.2f  patch+sums+%.2f  iter0+%.2f  iters(n=%d)+%.2f" % (
             lv, f(b), f(b + 1) - f(b), f(b + 2) - f(b + 1), f(b + 3) - f(b + 2), st[b + 6], f(b + 4) - f(b + 2)))
+    g = lambda i: st[i] - st[39]
+    print("   iteration j=1 of the last level run (cycles): floor/bounds %d | weights %d | window pass %d | block sum %d | delta %d | conds %d" % (
+        g(40), g(41) - g(40), g(42) - g(41), g(43) - g(42), g(44) - g(43), g(45) - g(44)))
