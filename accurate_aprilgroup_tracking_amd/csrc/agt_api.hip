@@ -473,8 +473,13 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
     // the fused launch pays off while the stages are latency-bound (few streams); big batches fill
     // the chip per stage and run faster as separate launches with their own register budgets
-    if (c->pipeline && !c->reproject && !c->prof_ev && agt_step_fits(c->trk_n, B))
-        return step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);
+    if (c->pipeline && !c->reproject && agt_step_fits(c->trk_n, B)) {
+        // fused launch: the three spans collapse into one (span 2 = the whole step_kernel launch)
+        if (pev) { (void)hipEventRecord(pev[0], c->stream); (void)hipEventRecord(pev[1], c->stream); (void)hipEventRecord(pev[2], c->stream); }
+        int rc = step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);
+        if (pev && rc == AGT_OK) { (void)hipEventRecord(pev[3], c->stream); c->prof_n++; }
+        return rc;
+    }
 
     int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first
     if (rc) return rc;

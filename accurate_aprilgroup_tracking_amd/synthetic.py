@@ -198,10 +198,13 @@ class Sequence:
     """A seeded synthetic stream: model, camera, trajectory, lazily rendered frames."""
 
     def __init__(self, width=1280, height=720, n_tags=12, n_frames=8, seed=0, dist=None,
-                 supersample=4, speed=1.0, z0=0.30):
+                 supersample=4, speed=1.0, z0=0.30, group_seed=None):
+        """seed drives trajectory and background; group_seed (default: seed) the AprilGroup model, so
+        several streams can show the SAME object along different trajectories."""
         self.width, self.height, self.seed = width, height, seed
-        self.group = make_april_group(n_tags=n_tags, seed=seed)
-        self.bits = tag_bits(n_tags, seed)
+        gs = seed if group_seed is None else group_seed
+        self.group = make_april_group(n_tags=n_tags, seed=gs)
+        self.bits = tag_bits(n_tags, gs)
         self.obj = group_object_points(self.group)                 # (4T, 3) f64
         self.K = camera_matrix(width, height)
         self.dist = None if dist is None else np.asarray(dist, np.float64).reshape(1, -1)

@@ -41,15 +41,71 @@ def pingpong(i, nf):
     return j if j < nf else 2 * nf - 2 - j
 
 
+def build_stream_ring(torch, syn, dev, rank, B, NF):
+    """Render NF frames for up to 4 seeds and lay a ping-pong sequence over an HBM ring that exceeds the
+    256 MiB Infinity Cache, so every step reads cold addresses."""
+    nseq = min(B, 4)
+    seqs = [syn.Sequence(W, H, n_tags=NTAGS, n_frames=NF, seed=1000 * rank + s, supersample=3, group_seed=0) for s in range(nseq)]
+    rendered = np.stack([sq.frames() for sq in seqs], axis=1)          # [NF, nseq, H, W]
+    period = 2 * NF - 2
+    ring_slots = period * max(1, -(-(300 << 20) // (period * B * W * H)))
+    ring = torch.empty((ring_slots, B, H, W), dtype=torch.uint8, device=dev)
+    src = torch.from_numpy(rendered).to(dev)
+    for i in range(ring_slots):
+        f = src[pingpong(i, NF)]
+        for b in range(B):
+            ring[i, b] = f[b % nseq]       # streams beyond the rendered seeds are copies at distinct HBM addresses
+    corners0 = np.stack([seqs[b % nseq].corners(0) for b in range(B)])
+    return seqs, rendered, ring, ring_slots, corners0
+
+
+def time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world):
+    """W warm-up + K timed steps between barrier + synchronize pairs; returns (fps, dt, state[K+W,B,16])."""
+    state = torch.zeros((Wm + K, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
+
+    def run(n_steps, first, st):
+        for k in range(n_steps):
+            trk.step(ring[(first + k) % ring_slots], st[k] if st is not None else None)
+    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+    run(Wm, 1, state[:Wm])
+    trk.join()
+    D.gather_poses(state[:Wm])                    # warm the communicator outside the timed region
+    torch.cuda.synchronize(); D.barrier()
+    t0 = time.perf_counter()
+    run(K, 1 + Wm, state[Wm:])
+    trk.join()                                    # enqueue the last pipeline stages of the frames in flight
+    # the only collective: the per-frame state records (128 B per stream-frame), once per chunk of
+    # K frames.  state[Wm:] is already contiguous: no torch kernel runs inside the timed region.
+    gathered = D.gather_poses(state[Wm:])
+    torch.cuda.synchronize(); D.barrier()
+    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
+    return world * B * K / dt, dt, state, gathered, run
+
+
+def event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, pipeline):
+    """average HIP-event spans (us) of M steps, recorded on the launch stream by the library"""
+    trk.pipeline(pipeline)
+    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+    run(Wm, 1, None)
+    trk.join()
+    HL.check(trk.ctx.L.agt_profile_begin(trk.ctx.h, M), "agt_profile_begin")
+    run(M, 1 + Wm, None)
+    ms = np.zeros((M, HL.PROF_SPANS), np.float32); nrec = C.c_int(0)
+    HL.check(trk.ctx.L.agt_profile_end(trk.ctx.h, ms.ctypes.data_as(C.c_void_p), C.byref(nrec)), "agt_profile_end")
+    trk.join()
+    return ms[:nrec.value].mean(axis=0) * 1e3
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=300)
-    ap.add_argument("--warmup", type=int, default=30)
+    ap.add_argument("--steps", type=int, default=400)
+    ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (c2: 1, c3: 64)")
     ap.add_argument("--render-frames", type=int, default=24)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-batch-extra", action="store_true", help="skip the 64-stream HBM-bound side measurement")
     args = ap.parse_args()
 
     import torch
@@ -63,84 +119,54 @@ def main():
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
 
     B = args.streams or (1 if args.workload == "c2" else 64)
-    K, Wm = args.steps, args.warmup
-    NF = args.render_frames
+    K, Wm, NF = args.steps, args.warmup, args.render_frames
 
-    # ---- synthetic stream(s): render NF frames, lay a ping-pong sequence over an HBM ring
-    # that exceeds the 256 MiB Infinity Cache so every step reads cold addresses
     t_r = time.time()
-    nseq = min(B, 4)
-    seqs = [syn.Sequence(W, H, n_tags=NTAGS, n_frames=NF, seed=1000 * rank + s, supersample=3) for s in range(nseq)]
-    rendered = np.stack([sq.frames() for sq in seqs], axis=1)          # [NF, nseq, H, W]
-    period = 2 * NF - 2
-    ring_slots = period * max(1, -(-(300 << 20) // (period * B * W * H)))
-    ring_slots = max(ring_slots, period)
-    ring = torch.empty((ring_slots, B, H, W), dtype=torch.uint8, device=dev)
-    src = torch.from_numpy(rendered).to(dev)
-    shifts = [(0, 0)] + [((7 * b) % 23 - 11, (5 * b) % 17 - 8) for b in range(1, B)]   # distinct streams from few renders
-    for i in range(ring_slots):
-        f = src[pingpong(i, NF)]
-        for b in range(B):
-            sq = b % nseq
-            dx, dy = shifts[b] if b >= nseq else (0, 0)
-            ring[i, b] = torch.roll(f[sq], shifts=(dy, dx), dims=(0, 1)) if (dx or dy) else f[sq]
-    corners0 = np.stack([seqs[b % nseq].corners(0) + (np.array(shifts[b], np.float32) if b >= nseq else 0) for b in range(B)])
+    seqs, rendered, ring, ring_slots, corners0 = build_stream_ring(torch, syn, dev, rank, B, NF)
     render_s = time.time() - t_r
-
     sq0 = seqs[0]
     trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
-
-    def run(n_steps, first, state):
-        for k in range(n_steps):
-            trk.step(ring[(first + k) % ring_slots], state[k] if state is not None else None)
-
-    total = Wm + K
-    state = torch.zeros((total, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
-    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-    run(Wm, 1, state[:Wm])
-    trk.join()
-    D.gather_poses(state[:Wm])                    # warm the communicator outside the timed region
-    torch.cuda.synchronize(); D.barrier()
-    t0 = time.perf_counter()
-    run(K, 1 + Wm, state[Wm:])
-    trk.join()                                    # current stream waits for the frames in flight
-    # the only collective: the per-frame state records (128 B per stream-frame), once per chunk of
-    # K frames.  state[Wm:] is already contiguous: no torch kernel runs inside the timed region.
-    gathered = D.gather_poses(state[Wm:])
-    torch.cuda.synchronize(); D.barrier()
-    dt = time.perf_counter() - t0
-    dt = D.max_over_ranks(dt, dev)
-    fps = world * B * K / dt
-
+    fps, dt, state, gathered, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world)
     st = state.cpu().numpy()
     accepted = float(st[Wm:, :, HL.ST_OK].mean())
     iters = float(st[Wm:, :, HL.ST_ITERS].mean())
 
-    out = None
     if rank == 0:
-        # ---- per-kernel durations with HIP events on the launch stream (second, instrumented pass)
-        M = min(K, 200)
-        trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-        run(Wm, 1, None)
-        HL.check(trk.ctx.L.agt_profile_begin(trk.ctx.h, M), "agt_profile_begin")
-        run(M, 1 + Wm, None)
-        ms = np.zeros((M, HL.PROF_SPANS), np.float32); nrec = C.c_int(0)
-        HL.check(trk.ctx.L.agt_profile_end(trk.ctx.h, ms.ctypes.data_as(C.c_void_p), C.byref(nrec)), "agt_profile_end")
-        span_us = ms[:nrec.value].mean(axis=0) * 1e3
         ab = algorithmic_bytes()
+        M = min(K, 200)
+        fused = B * NPTS <= 128
+        # per-launch durations from HIP events on the launch stream, second (instrumented) pass
+        stage_us = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, False)     # separate kernels
         names = ["pyramid", "lk", "pnp"]
-        dom = int(np.argmax(span_us))
-        launches = {"pyramid": LEVELS - 1, "lk": 1, "pnp": 1}[names[dom]]
-        kernel_us = float(span_us[dom]) / launches
-        achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
-        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down_kernel", "lk": "lk_kernel<21>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
-                "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                "traffic": None, "avg_launch_us": round(kernel_us, 3),
-                "span_us": {n: round(float(v), 3) for n, v in zip(names, span_us)},
-                "frame_gbs": round(B * ab["frame"] * fps / (world * B) / 1e9, 3)}
+        if fused:
+            # one launch per step: average launch period from two HIP events around M launches on the launch stream
+            trk.pipeline(True)
+            trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+            run(Wm, 1, None)
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(); run(M, 1 + Wm, None); e1.record()
+            trk.join(); torch.cuda.synchronize()
+            step_us = e0.elapsed_time(e1) * 1e3 / M
+            achieved = B * ab["frame"] / (step_us * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: pyrDown x2 | LK | PnP of 4 consecutive frames)",
+                    "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None, "avg_launch_us": round(step_us, 3), "bytes_per_launch": int(B * ab["frame"]),
+                    "note": "latency-bound by construction: one 720p stream is a serial chain of ~10 LK and 4 LM iterations"}
+        else:
+            dom = int(np.argmax(stage_us))
+            launches = {"pyramid": LEVELS - 1, "lk": 1, "pnp": 1}[names[dom]]
+            kernel_us = float(stage_us[dom]) / launches
+            achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down_kernel", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
+                    "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
+                    "traffic": None, "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(B * ab[names[dom]] / launches)}
+        roof["separate_kernel_spans_us"] = {n: round(float(v), 3) for n, v in zip(names, stage_us)}
 
-        cpu = None
-        pose_err = None
+        extra = None
+        if args.workload == "c2" and world == 1 and not args.no_batch_extra:
+            extra = batch_extra(torch, D, HL, syn, StreamTracker, dev, rank, NF)
+
+        cpu = pose_err = None
         if not args.no_cpu_baseline and world == 1:
             cpu, pose_err = cpu_baseline(seqs[0], rendered[:, 0], st[:, 0], Wm, K, NF)
         out = {"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(fps, 2), "unit": "frames/s",
@@ -150,12 +176,33 @@ def main():
                "config": {"workload": "%s: %d x 1280x720 stream(s) per GPU, 12 tags/48 corners, 3-level LK 21x21, "
                                       "iterative PnP with motion-model guess" % (args.workload, B),
                           "streams_per_gpu": B, "frames_resident": "HBM ring %d slots (%.0f MiB)" % (ring_slots, ring.numel() / 2**20),
-                          "parallelism": "stream-per-GPU x%d, RCCL all_gather of poses once" % world},
+                          "parallelism": "stream-per-GPU x%d, RCCL all_gather of poses once" % world,
+                          "launch": "fused software-pipelined step" if fused else "separate kernels per stage"},
                "roofline": roof, "cpu_baseline": cpu,
                "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
-               "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape)}
+               "batch64_hbm": extra, "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape)}
         print(json.dumps(out), flush=True)
     D.barrier()
+
+
+def batch_extra(torch, D, HL, syn, StreamTracker, dev, rank, NF):
+    """BASELINE.json configs[2]-style side measurement: 64 independent 1280x720 streams per step
+    (separate kernels, chip-filling).  Reports whole-step frames/s and the pyrDown kernel's HBM rate."""
+    B, K, Wm = 64, 60, 10
+    seqs, rendered, ring, ring_slots, corners0 = build_stream_ring(torch, syn, dev, rank, B, min(NF, 8))
+    trk = StreamTracker(W, H, seqs[0].obj, seqs[0].K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+    fps, dt, state, _, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, 1)
+    spans = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, 40, False)
+    ab = algorithmic_bytes()
+    pyr_gbs = B * ab["pyramid"] / (float(spans[0]) * 1e-6) / 1e9
+    ok = float(state.cpu().numpy()[Wm:, :, HL.ST_OK].mean())
+    del ring
+    torch.cuda.empty_cache()
+    return {"workload": "64 x 1280x720 streams per step, separate kernels", "frames_per_s": round(fps, 1),
+            "ms_per_step": round(dt / K * 1e3, 4), "span_us": {"pyramid(2 launches)": round(float(spans[0]), 2),
+                                                                "lk": round(float(spans[1]), 2), "pnp": round(float(spans[2]), 2)},
+            "pyr_down_algorithmic_GBs": round(pyr_gbs, 1), "pyr_down_frac_of_8TBs": round(pyr_gbs / HBM_PEAK_GBS, 4),
+            "accepted_frac": round(ok, 4)}
 
 
 def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):

@@ -184,8 +184,9 @@ int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t 
 /* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its
  * four launches (pyrDown L0->L1, pyrDown L1->L2.., LK, PnP) into the next of max_frames
  * slots.  agt_profile_end synchronises, writes ms[frame][AGT_PROF_SPANS] and the number of
- * frames recorded, and releases the events.  Recording perturbs timing: never leave it on
- * in a throughput measurement. */
+ * frames recorded, and releases the events.  With the fused software-pipelined step the frame is
+ * ONE launch: spans 0 and 1 are ~0 and span 2 is the step_kernel launch.  Recording perturbs
+ * timing: never leave it on in a throughput measurement. */
 #define AGT_PROF_EVENTS 4
 #define AGT_PROF_SPANS  3          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine */
 int agt_profile_begin(agt_ctx* ctx, int max_frames);
