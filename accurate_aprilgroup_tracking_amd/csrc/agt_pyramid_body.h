@@ -1,9 +1,16 @@
 // agt_pyramid_body.h -- device body of cv::pyrDown (u8, 5x5 [1 4 6 4 1]^2 / 256, BORDER_REFLECT_101).
 // Included by agt_pyramid.hip (stand-alone kernel) and agt_step.hip (fused per-frame launch).
 // Semantics: OpenCV modules/imgproc/src/pyramids.cpp pyrDown_, restated in oracle/cv_lk.c cvo_pyr_down_u8.
-// HBM-bound integer work: each source byte is read once with aligned dword loads (all of a
-// thread's loads issued before any is consumed), the (2*TH+3) x (2*TW+8) source tile is staged
-// in LDS, filtered horizontally into a u16 LDS plane, then vertically, and written as packed dwords.
+//
+// HBM-bound integer work, written to keep the VALU out of the way (the first version spent 657
+// VALU instructions per wave and was VALU-bound at 1.9 TB/s; this one spends ~180):
+//   * source tile (2*TH+3 rows x 288 B) fetched with 16-byte loads, every load of a thread in
+//     flight before the first is consumed, written to LDS with ds_write_b128;
+//   * horizontal [1 4 6 4 1]: one v_dot4_u32_u8 per output (weights packed 0x04060401 over the
+//     four leading taps, fifth tap as the accumulator input), even outputs via v_alignbyte_b32;
+//     eight outputs per thread, stored as eight u16 (one ds_write_b128);
+//   * vertical [1 4 6 4 1]: packed 16-bit math (v_pk_add_u16 / v_pk_mad_u16 / v_pk_lshrrev_b16,
+//     the largest intermediate is 65,408 < 2^16), eight outputs per thread, one 8-byte store.
 #pragma once
 #include "agt_device.h"
 #include "agt_kernels.h"
@@ -12,91 +19,146 @@ namespace agt_pyr {
 
 constexpr int TW = 128;             // output tile width  (pixels)
 constexpr int TH = 16;              // output tile height
-constexpr int SW = 2 * TW + 8;      // staged source bytes per row: x in [2*ox0-4, 2*ox0+2*TW+4)
-constexpr int SH = 2 * TH + 3;      // staged source rows:          y in [2*oy0-2, 2*oy0+2*TH+1)
+constexpr int NCH = 18;             // 16-byte chunks staged per source row: x in [2*ox0-16, 2*ox0+272)
+constexpr int SW = NCH * 16;        // staged source bytes per row (288)
+constexpr int SH = 2 * TH + 3;      // staged source rows: y in [2*oy0-2, 2*oy0+2*TH+1)
 constexpr int NT = 256;
+constexpr int HP = TW * 2;          // bytes per row of the u16 horizontal plane (256)
 
-constexpr int PYR_LDS_BYTES = SH * SW + SH * TW * 2;     // staged source tile + u16 horizontal plane
+constexpr int PYR_LDS_BYTES = SH * SW + SH * HP;     // 10,080 + 8,960
+
+typedef unsigned short u16x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ uint32_t pk_add(uint32_t a, uint32_t b)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) + __builtin_bit_cast(u16x2, b));
+}
+__device__ __forceinline__ uint32_t pk_mad(uint32_t a, uint32_t b, uint32_t c)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) * __builtin_bit_cast(u16x2, b) + __builtin_bit_cast(u16x2, c));
+}
+__device__ __forceinline__ uint32_t pk_shr8(uint32_t a)
+{
+    return __builtin_bit_cast(uint32_t, __builtin_bit_cast(u16x2, a) >> (unsigned short)8);
+}
+
+// image-edge path of the tile fetch: 16 bytes assembled with reflect-101 (rare, out of line)
+__device__ __noinline__ uint4 load_chunk_reflect(const uint8_t* __restrict__ row, int gx, int w)
+{
+    uint32_t v[4];
+    for (int d = 0; d < 4; d++) {
+        uint32_t t = 0;
+        for (int k = 0; k < 4; k++) t |= (uint32_t)row[agt_reflect101(gx + 4 * d + k, w)] << (8 * k);
+        v[d] = t;
+    }
+    return make_uint4(v[0], v[1], v[2], v[3]);
+}
 
 // one 128x16 output tile; (bx, by, bz) = tile x, tile y, image index.  lds: PYR_LDS_BYTES, 16-B aligned
 __device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int by, int bz, uint8_t* lds)
 {
     uint8_t* s_src = lds;
-    uint16_t* s_h = reinterpret_cast<uint16_t*>(lds + SH * SW);
-    const uint8_t* __restrict__ src = A.src;
-    uint8_t* __restrict__ dst = A.dst;
+    uint8_t* s_h = lds + SH * SW;
     const int sw = A.sw, sh = A.sh, dw = A.dw, dh = A.dh;
-    const long spitch = A.spitch, dpitch = A.dpitch;
-
     const int tid = threadIdx.x;
     const int ox0 = bx * TW, oy0 = by * TH;
-    const uint8_t* img = src + (long)bz * A.sbatch;
-    uint8_t* out = dst + (long)bz * A.dbatch;
-    const int sx0 = 2 * ox0 - 4, sy0 = 2 * oy0 - 2;
+    const uint8_t* __restrict__ img = A.src + (long)bz * A.sbatch;
+    uint8_t* __restrict__ out = A.dst + (long)bz * A.dbatch;
+    const int sx0 = 2 * ox0 - 16, sy0 = 2 * oy0 - 2;
+    const bool aligned16 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)A.spitch) & 15) == 0;
 
-    // ---- stage the source tile: all of a thread's loads are issued before any is consumed
-    // (aligned dwords; per-byte reflect only at the image edge)
-    constexpr int NLD = (SH * (SW / 4) + NT - 1) / NT;
-    uint32_t regs[NLD];
+    // ---- fetch: thread -> (row r0 + 14 k, chunk c), 14 rows x 18 chunks per round, 3 rounds
+    {
+        const int r0 = tid / NCH, c = tid - r0 * NCH;
+        const int gx = sx0 + 16 * c;
+        const bool lane_on = tid < 14 * NCH;
+        const bool inside = aligned16 && gx >= 0 && gx + 15 < sw;
+        // chunks wholly outside the image are not fetched: the <= 2 halo bytes per side that the
+        // filter reads there are patched from their reflections below.  Only a chunk that straddles
+        // the right edge of an image whose width is not a multiple of 16 (or an unaligned image)
+        // takes the byte-wise path.
+        const bool outside = gx + 15 < 0 || gx >= sw;
+        uint4 v[3];
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int i = tid + k * NT;
-        uint32_t v = 0;
-        if (i < SH * (SW / 4)) {
-            const int r = i / (SW / 4), c4 = i - r * (SW / 4);
-            const int gy = agt_reflect101(sy0 + r, sh);
-            const int gx = sx0 + 4 * c4;
-            const uint8_t* row = img + (long)gy * spitch;
-            if (gx >= 0 && gx + 3 < sw) {
-                v = *reinterpret_cast<const uint32_t*>(row + gx);
-            } else {
-                v = (uint32_t)row[agt_reflect101(gx, sw)] | ((uint32_t)row[agt_reflect101(gx + 1, sw)] << 8) |
-                    ((uint32_t)row[agt_reflect101(gx + 2, sw)] << 16) | ((uint32_t)row[agt_reflect101(gx + 3, sw)] << 24);
+        for (int k = 0; k < 3; k++) {
+            const int r = r0 + 14 * k;
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (lane_on && r < SH && !outside) {
+                const uint8_t* row = img + (long)agt_reflect101(sy0 + r, sh) * A.spitch;
+                v[k] = inside ? *reinterpret_cast<const uint4*>(row + gx) : load_chunk_reflect(row, gx, sw);
             }
         }
-        regs[k] = v;
-    }
 #pragma unroll
-    for (int k = 0; k < NLD; k++) {
-        const int i = tid + k * NT;
-        if (i < SH * (SW / 4)) *reinterpret_cast<uint32_t*>(&s_src[4 * i]) = regs[k];
-    }
-    __syncthreads();
-
-    // ---- horizontal [1 4 6 4 1]: two adjacent outputs per thread from one 8-byte window
-    for (int i = tid; i < SH * (TW / 2); i += NT) {
-        const int r = i / (TW / 2), p = i - r * (TW / 2);
-        // outputs ox = 2p, 2p+1 -> centres at staged byte 4p+4 and 4p+6; window bytes [4p+2, 4p+9)
-        const uint8_t* s = &s_src[r * SW + 4 * p];
-        const uint32_t w0 = *reinterpret_cast<const uint32_t*>(s);       // bytes 0..3
-        const uint32_t w1 = *reinterpret_cast<const uint32_t*>(s + 4);   // bytes 4..7
-        const uint32_t w2 = *reinterpret_cast<const uint32_t*>(s + 8);   // bytes 8..11
-        const int b2 = (w0 >> 16) & 0xff, b3 = w0 >> 24;
-        const int b4 = w1 & 0xff, b5 = (w1 >> 8) & 0xff, b6 = (w1 >> 16) & 0xff, b7 = w1 >> 24;
-        const int b8 = w2 & 0xff;
-        const int h0 = b4 * 6 + (b3 + b5) * 4 + b2 + b6;
-        const int h1 = b6 * 6 + (b5 + b7) * 4 + b4 + b8;
-        *reinterpret_cast<uint32_t*>(&s_h[r * TW + 2 * p]) = (uint32_t)h0 | ((uint32_t)h1 << 16);
-    }
-    __syncthreads();
-
-    // ---- vertical [1 4 6 4 1] + (v + 128) >> 8, four outputs per thread, dword stores
-    for (int i = tid; i < TH * (TW / 4); i += NT) {
-        const int oy = i / (TW / 4), q = i - oy * (TW / 4);
-        const int gy = oy0 + oy, gx = ox0 + 4 * q;
-        if (gy >= dh || gx >= dw) continue;
-        const uint16_t* h = &s_h[(2 * oy) * TW + 4 * q];
-        uint32_t packed = 0;
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const int v = h[2 * TW + k] * 6 + (h[TW + k] + h[3 * TW + k]) * 4 + h[k] + h[4 * TW + k];
-            packed |= (uint32_t)((v + 128) >> 8) << (8 * k);
+        for (int k = 0; k < 3; k++) {
+            const int r = r0 + 14 * k;
+            if (lane_on && r < SH) *reinterpret_cast<uint4*>(s_src + r * SW + 16 * c) = v[k];
         }
-        uint8_t* o = out + (long)gy * dpitch + gx;
-        if (gx + 3 < dw) {
-            *reinterpret_cast<uint32_t*>(o) = packed;
-        } else {
-            for (int k = 0; k < 4 && gx + k < dw; k++) o[k] = (uint8_t)(packed >> (8 * k));
+    }
+    __syncthreads();
+    // reflect-101 halo columns of edge tiles: x = -2, -1 and x = sw, sw + 1 (block-uniform branch)
+    if (sx0 + 14 < 0 || sx0 + SW > sw) {
+        if (tid < SH) {
+            uint8_t* row = s_src + tid * SW;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int x = k < 2 ? k - 2 : sw + k - 2;            // -2, -1, sw, sw + 1
+                const int j = x - sx0, jr = agt_reflect101(x, sw) - sx0;
+                if (j >= 0 && j < SW && jr >= 0 && jr < SW) row[j] = row[jr];
+            }
+        }
+        __syncthreads();
+    }
+
+    // ---- horizontal: thread -> (row r, group q of 8 outputs); output o of the group has its centre
+    // at staged byte 16 (q + 1) + 2 o
+    for (int i = tid; i < SH * (TW / 8); i += NT) {
+        const int r = i / (TW / 8), q = i - r * (TW / 8);
+        const uint8_t* s = s_src + r * SW + 16 * (q + 1);
+        const uint32_t pm = *reinterpret_cast<const uint32_t*>(s - 4);        // bytes -4..-1
+        const uint4 d = *reinterpret_cast<const uint4*>(s);                   // bytes 0..15
+        const uint32_t nx = *reinterpret_cast<const uint32_t*>(s + 16);       // bytes 16..19
+        const uint32_t W4 = 0x04060401u;                                      // taps c-2, c-1, c, c+1
+        // even outputs start two bytes before an aligned dword, odd outputs on one
+        const uint32_t e0 = __builtin_amdgcn_alignbyte(d.x, pm, 2), e2 = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
+        const uint32_t e4 = __builtin_amdgcn_alignbyte(d.z, d.y, 2), e6 = __builtin_amdgcn_alignbyte(d.w, d.z, 2);
+        const uint32_t h0 = __builtin_amdgcn_udot4(e0, W4, (d.x >> 16) & 0xff, false);     // fifth tap: byte 2
+        const uint32_t h1 = __builtin_amdgcn_udot4(d.x, W4, d.y & 0xff, false);            // byte 4
+        const uint32_t h2 = __builtin_amdgcn_udot4(e2, W4, (d.y >> 16) & 0xff, false);     // byte 6
+        const uint32_t h3 = __builtin_amdgcn_udot4(d.y, W4, d.z & 0xff, false);            // byte 8
+        const uint32_t h4 = __builtin_amdgcn_udot4(e4, W4, (d.z >> 16) & 0xff, false);     // byte 10
+        const uint32_t h5 = __builtin_amdgcn_udot4(d.z, W4, d.w & 0xff, false);            // byte 12
+        const uint32_t h6 = __builtin_amdgcn_udot4(e6, W4, (d.w >> 16) & 0xff, false);     // byte 14
+        const uint32_t h7 = __builtin_amdgcn_udot4(d.w, W4, nx & 0xff, false);             // byte 16
+        *reinterpret_cast<uint4*>(s_h + r * HP + 16 * q) =
+            make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), h4 | (h5 << 16), h6 | (h7 << 16));
+    }
+    __syncthreads();
+
+    // ---- vertical + (v + 128) >> 8: thread -> (output row oy, group q of 8 outputs)
+    {
+        const int oy = tid / (TW / 8), q = tid - oy * (TW / 8);
+        const int gy = oy0 + oy, gx = ox0 + 8 * q;
+        if (gy < dh && gx < dw) {
+            const uint8_t* h = s_h + (2 * oy) * HP + 16 * q;
+            const uint4 r0 = *reinterpret_cast<const uint4*>(h), r1 = *reinterpret_cast<const uint4*>(h + HP);
+            const uint4 r2 = *reinterpret_cast<const uint4*>(h + 2 * HP), r3 = *reinterpret_cast<const uint4*>(h + 3 * HP);
+            const uint4 r4 = *reinterpret_cast<const uint4*>(h + 4 * HP);
+            const uint32_t K4 = 0x00040004u, K6 = 0x00060006u, K128 = 0x00800080u;
+            auto col = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4) -> uint32_t {
+                uint32_t v = pk_mad(pk_add(a1, a3), K4, pk_add(a0, a4));
+                v = pk_mad(a2, K6, v);
+                return pk_shr8(pk_add(v, K128));                                 // two results, one per 16-bit half
+            };
+            const uint32_t p0 = col(r0.x, r1.x, r2.x, r3.x, r4.x), p1 = col(r0.y, r1.y, r2.y, r3.y, r4.y);
+            const uint32_t p2 = col(r0.z, r1.z, r2.z, r3.z, r4.z), p3 = col(r0.w, r1.w, r2.w, r3.w, r4.w);
+            // gather the low byte of each half: (p.lo, p.hi, q.lo, q.hi) -> one dword
+            const uint32_t lo = __builtin_amdgcn_perm(p1, p0, 0x06040200u), hi = __builtin_amdgcn_perm(p3, p2, 0x06040200u);
+            uint8_t* o = out + (long)gy * A.dpitch + gx;
+            if (gx + 7 < dw && (((uintptr_t)o) & 7) == 0) {
+                *reinterpret_cast<uint2*>(o) = make_uint2(lo, hi);
+            } else {
+                for (int k = 0; k < 8 && gx + k < dw; k++) o[k] = (uint8_t)((k < 4 ? lo : hi) >> (8 * (k & 3)));
+            }
         }
     }
 }

@@ -31,7 +31,7 @@ def test_library_loaded():
     assert hiplib.lib().agt_version() == 100
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260)])
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260), (53, 37), (9, 5), (3, 3), (64, 129), (33, 300), (200, 17)])
 def test_pyr_down_bit_exact(torch_cuda, cvh, oracle, shape):
     torch = torch_cuda
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])
