@@ -4,6 +4,8 @@
 #include "agt_kernels.h"
 #include <new>
 #include <string.h>
+#include <math.h>
+#include <float.h>
 
 #define AGT_SLOTS 4
 
@@ -37,6 +39,8 @@ struct agt_ctx {
     double gate_px;
     // LK parameters of the fused step (COUNT+EPS (30, 0.01), minEig 1e-4, flags 0)
     int lk_max_count; double lk_eps; double lk_min_eig;
+    // undistortion maps of the pre-processing stage (built once per camera)
+    short2* map1; unsigned short* map2; int map_w, map_h;
     // optional per-kernel timing (agt_profile_begin/end)
     hipEvent_t* prof_ev;
     int prof_cap, prof_n;
@@ -143,6 +147,8 @@ int agt_destroy(agt_ctx* c)
     if (c->obj) (void)hipFree(c->obj);
     if (c->pose) (void)hipFree(c->pose);
     if (c->tstate) (void)hipFree(c->tstate);
+    if (c->map1) (void)hipFree(c->map1);
+    if (c->map2) (void)hipFree(c->map2);
     if (c->prof_ev) {
         for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
@@ -523,6 +529,169 @@ int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t
     if (d_corners) *d_corners = c->corners[c->trk_frame % AGT_SLOTS];
     if (d_status) *d_status = c->status[c->trk_frame % AGT_SLOTS];
     return AGT_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// frame pre-processing: detect_pose.py:147-183 undistort_frame, :602 cvtColor
+
+namespace {
+
+// cvUndistortPointsInternal for one point, R = I, optional new camera matrix P, 5 fixed iterations
+void undistort_point_host(double u, double v, const double* K, const double* k, bool has_dist, const double* P,
+                          double* ox, double* oy)
+{
+    const double ifx = 1. / K[0], ify = 1. / K[4], cx = K[2], cy = K[5];
+    double x = (u - cx) * ifx, y = (v - cy) * ify;
+    if (has_dist) {
+        const double x0 = x, y0 = y;
+        for (int it = 0; it < 5; it++) {
+            const double r2 = x * x + y * y;
+            const double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
+            if (icdist < 0) { x = (u - cx) * ifx; y = (v - cy) * ify; break; }
+            const double dX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
+            const double dY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
+            x = (x0 - dX) * icdist;
+            y = (y0 - dY) * icdist;
+        }
+    }
+    if (P) {
+        const double xx = P[0] * x + P[1] * y + P[2], yy = P[3] * x + P[4] * y + P[5], ww = 1. / (P[6] * x + P[7] * y + P[8]);
+        x = xx * ww; y = yy * ww;
+    }
+    *ox = x; *oy = y;
+}
+
+// calibration.cpp icvGetRectangles: inscribed / circumscribed rectangles of the undistorted 9x9 grid (float)
+struct RectF { float x, y, w, h; };
+void grid_rectangles(const double* K, const double* k, bool has_dist, const double* P, int w, int h, RectF* inner, RectF* outer)
+{
+    const int N = 9;
+    float in_l = -FLT_MAX, in_r = FLT_MAX, in_t = -FLT_MAX, in_b = FLT_MAX;
+    float out_l = FLT_MAX, out_r = -FLT_MAX, out_t = FLT_MAX, out_b = -FLT_MAX;
+    for (int gy = 0; gy < N; gy++)
+        for (int gx = 0; gx < N; gx++) {
+            const float px = (float)gx * w / (N - 1), py = (float)gy * h / (N - 1);
+            double ux, uy;
+            undistort_point_host((double)px, (double)py, K, k, has_dist, P, &ux, &uy);
+            const float qx = (float)ux, qy = (float)uy;
+            out_l = qx < out_l ? qx : out_l; out_r = qx > out_r ? qx : out_r;
+            out_t = qy < out_t ? qy : out_t; out_b = qy > out_b ? qy : out_b;
+            if (gx == 0 && qx > in_l) in_l = qx;
+            if (gx == N - 1 && qx < in_r) in_r = qx;
+            if (gy == 0 && qy > in_t) in_t = qy;
+            if (gy == N - 1 && qy < in_b) in_b = qy;
+        }
+    *inner = RectF{ in_l, in_t, in_r - in_l, in_b - in_t };
+    *outer = RectF{ out_l, out_t, out_r - out_l, out_b - out_t };
+}
+
+bool invert3(const double* A, double* B)
+{
+    const double c00 = A[4] * A[8] - A[5] * A[7], c01 = A[5] * A[6] - A[3] * A[8], c02 = A[3] * A[7] - A[4] * A[6];
+    const double det = A[0] * c00 + A[1] * c01 + A[2] * c02;
+    if (det == 0) return false;
+    const double id = 1. / det;
+    B[0] = c00 * id; B[1] = (A[2] * A[7] - A[1] * A[8]) * id; B[2] = (A[1] * A[5] - A[2] * A[4]) * id;
+    B[3] = c01 * id; B[4] = (A[0] * A[8] - A[2] * A[6]) * id; B[5] = (A[2] * A[3] - A[0] * A[5]) * id;
+    B[6] = c02 * id; B[7] = (A[1] * A[6] - A[0] * A[7]) * id; B[8] = (A[0] * A[4] - A[1] * A[3]) * id;
+    return true;
+}
+
+}  // namespace
+
+// cv::getOptimalNewCameraMatrix(K, dist, (w,h), alpha, (new_w,new_h), centerPrincipalPoint=false); host only
+int agt_get_optimal_new_camera_matrix(const double* K, const double* dist, int ndist, int w, int h, double alpha,
+                                      int new_w, int new_h, double* newK, int* roi)
+{
+    if (!K || !newK || w <= 0 || h <= 0) return AGT_ERR_ARG;
+    AgtCameraHost cam;
+    int rc = fill_camera(K, dist, ndist, &cam);
+    if (rc) return rc;
+    const bool has_dist = dist != nullptr && ndist > 0;
+    if ((long)new_w * new_h == 0) { new_w = w; new_h = h; }
+    alpha = alpha < 0. ? 0. : alpha > 1. ? 1. : alpha;
+    RectF inner, outer;
+    grid_rectangles(K, cam.k, has_dist, nullptr, w, h, &inner, &outer);
+    const double fx0 = (new_w - 1) / inner.w, fy0 = (new_h - 1) / inner.h;     // int / float, as OpenCV
+    const double cx0 = -fx0 * inner.x, cy0 = -fy0 * inner.y;
+    const double fx1 = (new_w - 1) / outer.w, fy1 = (new_h - 1) / outer.h;
+    const double cx1 = -fx1 * outer.x, cy1 = -fy1 * outer.y;
+    for (int i = 0; i < 9; i++) newK[i] = K[i];
+    newK[0] = fx0 * (1 - alpha) + fx1 * alpha;
+    newK[4] = fy0 * (1 - alpha) + fy1 * alpha;
+    newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
+    newK[5] = cy0 * (1 - alpha) + cy1 * alpha;
+    if (roi) {
+        grid_rectangles(K, cam.k, has_dist, newK, w, h, &inner, &outer);
+        const int rx = (int)lrintf(inner.x), ry = (int)lrintf(inner.y), rw = (int)lrintf(inner.w), rh = (int)lrintf(inner.h);
+        const int x1 = rx > 0 ? rx : 0, y1 = ry > 0 ? ry : 0;
+        const int x2 = rx + rw < new_w ? rx + rw : new_w, y2 = ry + rh < new_h ? ry + rh : new_h;
+        if (x2 <= x1 || y2 <= y1) roi[0] = roi[1] = roi[2] = roi[3] = 0;
+        else { roi[0] = x1; roi[1] = y1; roi[2] = x2 - x1; roi[3] = y2 - y1; }
+    }
+    return AGT_OK;
+}
+
+// cv::initUndistortRectifyMap(K, dist, I, newK, (w,h), CV_16SC2) into context-owned device maps
+int agt_undistort_init(agt_ctx* c, const double* K, const double* dist, int ndist, const double* newK, int w, int h)
+{
+    if (!c || !K || w <= 0 || h <= 0 || w > 32767 || h > 32767) return AGT_ERR_ARG;
+    AgtCameraHost cam;
+    int rc = fill_camera(K, dist, ndist, &cam);
+    if (rc) return rc;
+    double ir[9];
+    if (!invert3(newK ? newK : K, ir)) return AGT_ERR_ARG;
+    if (c->map_w != w || c->map_h != h) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        if (c->map1) (void)hipFree(c->map1);
+        if (c->map2) (void)hipFree(c->map2);
+        c->map1 = nullptr; c->map2 = nullptr; c->map_w = c->map_h = 0;
+        if (hipMalloc((void**)&c->map1, (size_t)w * h * sizeof(short2)) != hipSuccess ||
+            hipMalloc((void**)&c->map2, (size_t)w * h * sizeof(unsigned short)) != hipSuccess) {
+            if (c->map1) { (void)hipFree(c->map1); c->map1 = nullptr; }
+            return AGT_ERR_ALLOC;
+        }
+        c->map_w = w; c->map_h = h;
+    }
+    hipError_t e = agt_launch_undistort_map(c->stream, K, cam.k, ir, w, h, c->map1, c->map2);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_undistort_maps(const agt_ctx* c, const int16_t** d_map1, const uint16_t** d_map2, int* w, int* h)
+{
+    if (!c || !c->map1) return AGT_ERR_STATE;
+    if (d_map1) *d_map1 = reinterpret_cast<const int16_t*>(c->map1);
+    if (d_map2) *d_map2 = c->map2;
+    if (w) *w = c->map_w;
+    if (h) *h = c->map_h;
+    return AGT_OK;
+}
+
+// cv::undistort on B BGR frames of the map size (same-size output)
+int agt_undistort_bgr(agt_ctx* c, const uint8_t* d_src, size_t spitch, size_t sbatch,
+                      uint8_t* d_dst, size_t dpitch, size_t dbatch, int B)
+{
+    if (!c || !d_src || !d_dst || B <= 0) return AGT_ERR_ARG;
+    if (!c->map1) return AGT_ERR_STATE;
+    if (spitch < (size_t)c->map_w * 3 || dpitch < (size_t)c->map_w * 3) return AGT_ERR_ARG;
+    hipError_t e = agt_launch_preprocess(c->stream, d_src, (long)spitch, (long)sbatch, c->map_w, c->map_h, c->map1, c->map2, c->map_w,
+                                         0, 0, c->map_w, c->map_h, d_dst, (long)dpitch, (long)dbatch, 1, 0, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// undistort (optional) + BGR2GRAY + ROI crop in one pass: BGR (src_w x src_h) -> gray (roi_w x roi_h)
+int agt_preprocess_bgr(agt_ctx* c, const uint8_t* d_bgr, size_t spitch, size_t sbatch, int src_w, int src_h, int B,
+                       int undistort, int roi_x, int roi_y, int roi_w, int roi_h,
+                       uint8_t* d_gray, size_t gpitch, size_t gbatch)
+{
+    if (!c || !d_bgr || !d_gray || B <= 0 || src_w <= 0 || src_h <= 0) return AGT_ERR_ARG;
+    if (roi_x < 0 || roi_y < 0 || roi_w <= 0 || roi_h <= 0 || roi_x + roi_w > src_w || roi_y + roi_h > src_h) return AGT_ERR_ARG;
+    if (spitch < (size_t)src_w * 3 || gpitch < (size_t)roi_w) return AGT_ERR_ARG;
+    if (undistort && (!c->map1 || c->map_w != src_w || c->map_h != src_h)) return AGT_ERR_STATE;
+    hipError_t e = agt_launch_preprocess(c->stream, d_bgr, (long)spitch, (long)sbatch, src_w, src_h, c->map1, c->map2, src_w,
+                                         roi_x, roi_y, roi_w, roi_h, d_gray, (long)gpitch, (long)gbatch, undistort ? 1 : 0, 1, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
 int agt_profile_begin(agt_ctx* c, int max_frames)

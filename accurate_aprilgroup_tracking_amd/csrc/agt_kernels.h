@@ -103,6 +103,12 @@ hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, i
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B);
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B);
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
+hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,
+                                    int w, int h, short2* map1, unsigned short* map2);
+hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long spitch, long sbatch, int sw, int sh,
+                                 const short2* map1, const unsigned short* map2, int mw,
+                                 int rx, int ry, int rw, int rh, uint8_t* dst, long dpitch, long dbatch,
+                                 int undistort, int gray, int B);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);

@@ -1,0 +1,222 @@
+// agt_preproc.hip -- frame pre-processing of the reference's per-frame loop, on the device
+// (SURVEY.md section 8f rank 1):
+//   PoseDetector.undistort_frame  /root/reference/aprilgroup_tracking/aprilgroup_pose_estimation/detect_pose.py:147-183
+//       cv.getOptimalNewCameraMatrix (host, agt_get_optimal_new_camera_matrix)
+//       cv.undistort = initUndistortRectifyMap(CV_16SC2) + remap(INTER_LINEAR, BORDER_CONSTANT) + ROI crop
+//   cv.cvtColor(frame, COLOR_BGR2GRAY)   detect_pose.py:602
+// Semantics: OpenCV undistort.dispatch.cpp / imgwarp.cpp / color_rgb, restated in oracle/cv_imgproc.c;
+// maps and images are bit-identical to that oracle.
+//
+// Data flow: the undistortion map depends on the camera only, so it is built ONCE per camera
+// (6 B/pixel: int16 x, int16 y, 5+5 fraction bits) and stays L2/Infinity-Cache resident across
+// frames and streams.  Per frame one fused kernel gathers the four BGR taps, interpolates in
+// 15-bit fixed point per channel (exactly cv.undistort's rounding), converts to gray
+// (14-bit fixed point, exactly cv.cvtColor's) and writes only the ROI: 3 B/px in, 1 B/px out,
+// no intermediate BGR image in HBM.
+#include "agt_device.h"
+#include "agt_kernels.h"
+
+namespace {
+
+constexpr int INTER_BITS = 5, INTER_TAB = 32;
+
+struct MapParams {
+    double ir[9];                 // inverse of the new camera matrix
+    double fx, fy, u0, v0;        // original camera
+    double k[12];                 // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+    int w, h;
+    short2* map1;
+    unsigned short* map2;
+};
+
+// cv::initUndistortRectifyMap, R = I, m1type = CV_16SC2 (FP64 exactly as the oracle: no contraction)
+__global__ __launch_bounds__(256) void undistort_map_kernel(const MapParams P)
+{
+    const int j = blockIdx.x * blockDim.x + threadIdx.x, i = blockIdx.y;
+    if (j >= P.w) return;
+    const double* ir = P.ir;
+    const double _x = j * ir[0] + (i * ir[1] + ir[2]), _y = j * ir[3] + (i * ir[4] + ir[5]), _w = j * ir[6] + (i * ir[7] + ir[8]);
+    const double ww = 1. / _w, x = _x * ww, y = _y * ww;
+    const double x2 = x * x, y2 = y * y, r2 = x2 + y2, _2xy = 2 * x * y;
+    const double k1 = P.k[0], k2 = P.k[1], p1 = P.k[2], p2 = P.k[3], k3 = P.k[4], k4 = P.k[5], k5 = P.k[6], k6 = P.k[7];
+    const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
+    const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + P.k[8] * r2 + P.k[9] * r2 * r2);
+    const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + P.k[10] * r2 + P.k[11] * r2 * r2);
+    const double us = (P.fx * xd + P.u0) * INTER_TAB, vs = (P.fy * yd + P.v0) * INTER_TAB;
+    const int iu = us >= 2147483647. ? 2147483647 : us <= -2147483648. ? (-2147483647 - 1) : __double2int_rn(us);
+    const int iv = vs >= 2147483647. ? 2147483647 : vs <= -2147483648. ? (-2147483647 - 1) : __double2int_rn(vs);
+    const long o = (long)i * P.w + j;
+    P.map1[o] = make_short2((short)(iu >> INTER_BITS), (short)(iv >> INTER_BITS));
+    P.map2[o] = (unsigned short)((iv & (INTER_TAB - 1)) * INTER_TAB + (iu & (INTER_TAB - 1)));
+}
+
+struct RemapParams {
+    const uint8_t* src; long spitch, sbatch; int sw, sh;
+    const short2* map1; const unsigned short* map2; int mw;      // maps cover mw x (any) pixels
+    int rx, ry, rw, rh;                                          // output window in map coordinates
+    uint8_t* dst; long dpitch, dbatch;
+    int undistort;                                               // 0: taps come straight from (x, y)
+};
+
+struct __attribute__((packed)) Tap6 { uint32_t lo; uint16_t hi; };
+
+// every product below has operands under 2^24 (pixels 8 bit, weights <= 2^15): full-rate 24-bit multiplies
+__device__ __forceinline__ int gray14(int b, int g, int r) { return (__mul24(b, 1868) + __mul24(g, 9617) + __mul24(r, 4899) + (1 << 13)) >> 14; }
+__device__ __forceinline__ int blend4(int a, int b, int c, int d, int w00, int w01, int w10, int w11)
+{
+    return (__mul24(a, w00) + __mul24(b, w01) + __mul24(c, w10) + __mul24(d, w11) + (1 << 14)) >> 15;
+}
+__device__ __forceinline__ void tap_weights(int q, int& w00, int& w01, int& w10, int& w11)
+{
+    const int fx = q & 31, fy = (q >> 5) & 31;
+    w00 = __mul24(32 - fx, 32 - fy) << 5; w01 = __mul24(fx, 32 - fy) << 5; w10 = __mul24(32 - fx, fy) << 5; w11 = __mul24(fx, fy) << 5;
+}
+
+// one BGR pixel of cv.remap(INTER_LINEAR, BORDER_CONSTANT = 0) at map entry (sx, sy, fraction q)
+__device__ __forceinline__ void remap_bgr(const uint8_t* __restrict__ img, long spitch, int sw, int sh,
+                                          int sx, int sy, int q, int& b, int& g, int& r)
+{
+    int w00, w01, w10, w11;
+    tap_weights(q, w00, w01, w10, w11);
+    if ((unsigned)sx < (unsigned)(sw - 1) && (unsigned)sy < (unsigned)(sh - 1)) {
+        // the two BGR taps of a row are 6 contiguous bytes at an arbitrary byte offset: one unaligned
+        // dword + one unaligned ushort (gfx950 global loads need no alignment) instead of six byte loads
+        const Tap6 s = *reinterpret_cast<const Tap6*>(img + (long)sy * spitch + sx * 3);
+        const Tap6 t = *reinterpret_cast<const Tap6*>(img + (long)(sy + 1) * spitch + sx * 3);
+        const int s0 = s.lo & 0xff, s1 = (s.lo >> 8) & 0xff, s2 = (s.lo >> 16) & 0xff, s3 = s.lo >> 24, s4 = s.hi & 0xff, s5 = s.hi >> 8;
+        const int t0 = t.lo & 0xff, t1 = (t.lo >> 8) & 0xff, t2 = (t.lo >> 16) & 0xff, t3 = t.lo >> 24, t4 = t.hi & 0xff, t5 = t.hi >> 8;
+        b = blend4(s0, s3, t0, t3, w00, w01, w10, w11);
+        g = blend4(s1, s4, t1, t4, w00, w01, w10, w11);
+        r = blend4(s2, s5, t2, t5, w00, w01, w10, w11);
+        return;
+    }
+    b = g = r = 0;
+    if (sx >= sw || sx + 1 < 0 || sy >= sh || sy + 1 < 0) return;
+    const bool x0 = sx >= 0 && sx < sw, x1 = sx + 1 >= 0 && sx + 1 < sw, y0 = sy >= 0 && sy < sh, y1 = sy + 1 >= 0 && sy + 1 < sh;
+    int acc[3] = { 1 << 14, 1 << 14, 1 << 14 };
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        if (x0 && y0) acc[c] += img[(long)sy * spitch + sx * 3 + c] * w00;
+        if (x1 && y0) acc[c] += img[(long)sy * spitch + (sx + 1) * 3 + c] * w01;
+        if (x0 && y1) acc[c] += img[(long)(sy + 1) * spitch + sx * 3 + c] * w10;
+        if (x1 && y1) acc[c] += img[(long)(sy + 1) * spitch + (sx + 1) * 3 + c] * w11;
+    }
+    b = acc[0] >> 15; g = acc[1] >> 15; r = acc[2] >> 15;
+}
+
+// GRAY: undistort (optional) + cvtColor + crop, four output pixels per thread (one dword store).
+// !GRAY: cv.undistort to BGR, one pixel per thread.
+template <bool GRAY>
+__global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
+{
+    const uint8_t* img = P.src + (long)blockIdx.z * P.sbatch;
+    uint8_t* out = P.dst + (long)blockIdx.z * P.dbatch;
+    const int y = blockIdx.y;                                     // row inside the ROI
+    if (GRAY) {
+        const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+        if (x0 >= P.rw) return;
+        uint32_t packed = 0;
+        // map entries of the thread's four pixels: 16 + 8 contiguous bytes (unaligned vector loads)
+        struct __attribute__((packed)) M1x4 { short2 m[4]; };
+        struct __attribute__((packed)) M2x4 { unsigned short q[4]; };
+        M1x4 mm; M2x4 qq;
+        const long o0 = (long)(P.ry + y) * P.mw + (P.rx + x0);
+        if (P.undistort) {
+            if (x0 + 3 < P.rw) { mm = *reinterpret_cast<const M1x4*>(P.map1 + o0); qq = *reinterpret_cast<const M2x4*>(P.map2 + o0); }
+            else for (int k = 0; k < 4; k++) { const bool in = x0 + k < P.rw; mm.m[k] = in ? P.map1[o0 + k] : make_short2(0, 0); qq.q[k] = in ? P.map2[o0 + k] : 0; }
+        }
+        // Lens-like maps are locally regular: the four pixels of a thread usually read source pixels
+        // sx .. sx+4 of rows sy, sy+1.  Then two unaligned 16-byte loads replace sixteen narrow ones.
+        if (P.undistort && x0 + 3 < P.rw) {
+            const int sx = mm.m[0].x, sy = mm.m[0].y;
+            const bool regular = mm.m[1].x == sx + 1 && mm.m[2].x == sx + 2 && mm.m[3].x == sx + 3 &&
+                                 mm.m[1].y == sy && mm.m[2].y == sy && mm.m[3].y == sy &&
+                                 sx >= 0 && sx + 5 < P.sw && sy >= 0 && sy + 1 < P.sh;          // 16 bytes stay inside the row
+            if (regular) {
+                struct __attribute__((packed)) Row16 { uint32_t d[4]; };
+                const Row16 s = *reinterpret_cast<const Row16*>(img + (long)sy * P.spitch + sx * 3);
+                const Row16 t = *reinterpret_cast<const Row16*>(img + (long)(sy + 1) * P.spitch + sx * 3);
+                auto byte = [](const Row16& v, int i) -> int { return (v.d[i >> 2] >> (8 * (i & 3))) & 0xff; };
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    int w00, w01, w10, w11;
+                    tap_weights(qq.q[k], w00, w01, w10, w11);
+                    const int b = blend4(byte(s, 3 * k), byte(s, 3 * k + 3), byte(t, 3 * k), byte(t, 3 * k + 3), w00, w01, w10, w11);
+                    const int g = blend4(byte(s, 3 * k + 1), byte(s, 3 * k + 4), byte(t, 3 * k + 1), byte(t, 3 * k + 4), w00, w01, w10, w11);
+                    const int r = blend4(byte(s, 3 * k + 2), byte(s, 3 * k + 5), byte(t, 3 * k + 2), byte(t, 3 * k + 5), w00, w01, w10, w11);
+                    packed |= (uint32_t)gray14(b, g, r) << (8 * k);
+                }
+                uint8_t* o = out + (long)y * P.dpitch + x0;
+                if ((((uintptr_t)o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = packed;
+                else for (int k = 0; k < 4; k++) o[k] = (uint8_t)(packed >> (8 * k));
+                return;
+            }
+        }
+        if (!P.undistort && x0 + 3 < P.rw) {
+            // gray + crop only: the four BGR pixels are 12 contiguous bytes
+            struct __attribute__((packed)) Px4 { uint32_t d[3]; };
+            const Px4 v = *reinterpret_cast<const Px4*>(img + (long)(P.ry + y) * P.spitch + (P.rx + x0) * 3);
+            auto byte = [](const Px4& q, int i) -> int { return (q.d[i >> 2] >> (8 * (i & 3))) & 0xff; };
+#pragma unroll
+            for (int k = 0; k < 4; k++) packed |= (uint32_t)gray14(byte(v, 3 * k), byte(v, 3 * k + 1), byte(v, 3 * k + 2)) << (8 * k);
+            uint8_t* o = out + (long)y * P.dpitch + x0;
+            if ((((uintptr_t)o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = packed;
+            else for (int k = 0; k < 4; k++) o[k] = (uint8_t)(packed >> (8 * k));
+            return;
+        }
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const int x = x0 + k;
+            if (x < P.rw) {
+                int b, g, r;
+                if (P.undistort) {
+                    remap_bgr(img, P.spitch, P.sw, P.sh, mm.m[k].x, mm.m[k].y, qq.q[k], b, g, r);
+                } else {
+                    const uint8_t* S = img + (long)(P.ry + y) * P.spitch + (P.rx + x) * 3;
+                    b = S[0]; g = S[1]; r = S[2];
+                }
+                packed |= (uint32_t)gray14(b, g, r) << (8 * k);
+            }
+        }
+        uint8_t* o = out + (long)y * P.dpitch + x0;
+        if (x0 + 3 < P.rw && (((uintptr_t)o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = packed;
+        else for (int k = 0; k < 4 && x0 + k < P.rw; k++) o[k] = (uint8_t)(packed >> (8 * k));
+    } else {
+        const int x = blockIdx.x * blockDim.x + threadIdx.x;
+        if (x >= P.rw) return;
+        const long o = (long)(P.ry + y) * P.mw + (P.rx + x);
+        const short2 m = P.map1[o];
+        int b, g, r;
+        remap_bgr(img, P.spitch, P.sw, P.sh, m.x, m.y, P.map2[o], b, g, r);
+        uint8_t* d = out + (long)y * P.dpitch + x * 3;
+        d[0] = (uint8_t)b; d[1] = (uint8_t)g; d[2] = (uint8_t)r;
+    }
+}
+
+}  // namespace
+
+hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,
+                                    int w, int h, short2* map1, unsigned short* map2)
+{
+    MapParams P;
+    for (int i = 0; i < 9; i++) P.ir[i] = ir[i];
+    P.fx = K[0]; P.fy = K[4]; P.u0 = K[2]; P.v0 = K[5];
+    for (int i = 0; i < 12; i++) P.k[i] = k12[i];
+    P.w = w; P.h = h; P.map1 = map1; P.map2 = map2;
+    hipLaunchKernelGGL(undistort_map_kernel, dim3((w + 255) / 256, h), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}
+
+hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long spitch, long sbatch, int sw, int sh,
+                                 const short2* map1, const unsigned short* map2, int mw,
+                                 int rx, int ry, int rw, int rh, uint8_t* dst, long dpitch, long dbatch,
+                                 int undistort, int gray, int B)
+{
+    RemapParams P;
+    P.src = src; P.spitch = spitch; P.sbatch = sbatch; P.sw = sw; P.sh = sh;
+    P.map1 = map1; P.map2 = map2; P.mw = mw; P.rx = rx; P.ry = ry; P.rw = rw; P.rh = rh;
+    P.dst = dst; P.dpitch = dpitch; P.dbatch = dbatch; P.undistort = undistort;
+    if (gray) hipLaunchKernelGGL(preprocess_kernel<true>, dim3((rw + 1023) / 1024, rh, B), dim3(256), 0, stream, P);
+    else hipLaunchKernelGGL(preprocess_kernel<false>, dim3((rw + 255) / 256, rh, B), dim3(256), 0, stream, P);
+    return hipGetLastError();
+}

@@ -18,6 +18,7 @@ from . import hiplib as H
 from .host_math import Rodrigues  # noqa: F401  (host-side 3x3 algebra, as in the reference)
 
 SOLVEPNP_ITERATIVE = 0
+COLOR_BGR2GRAY = 6
 OPTFLOW_USE_INITIAL_FLOW = H.LK_USE_INITIAL_FLOW
 OPTFLOW_LK_GET_MIN_EIGENVALS = H.LK_GET_MIN_EIGENVALS
 TERM_CRITERIA_COUNT, TERM_CRITERIA_EPS = H.TERM_COUNT, H.TERM_EPS
@@ -102,6 +103,49 @@ class Context:
                 "agt_pyramid_build")
         self._keep[slot] = frames
 
+    # ---- frame pre-processing (detect_pose.py:147-183, :602)
+    def undistort_init(self, K, dist, newK, width, height):
+        """Build the CV_16SC2 undistortion maps for this camera on the device (once per camera)."""
+        Kh, _ = _host_f64(K); dh, nd = _host_f64(dist)
+        nk = None if newK is None else _host_f64(newK)[0]
+        H.check(self.L.agt_undistort_init(self.h, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                                          nk.ctypes.data_as(C.c_void_p) if nk is not None else None, width, height),
+                "agt_undistort_init")
+        self._map_size = (width, height)
+
+    def undistort_maps(self):
+        """(map1 [h,w,2] int16, map2 [h,w] uint16) copied to the host (tests)"""
+        p1, p2, w, h = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
+        H.check(self.L.agt_undistort_maps(self.h, C.byref(p1), C.byref(p2), C.byref(w), C.byref(h)), "agt_undistort_maps")
+        m1 = torch.empty((h.value, w.value, 2), dtype=torch.int16, device="cuda")
+        m2 = torch.empty((h.value, w.value), dtype=torch.int16, device="cuda")
+        import ctypes
+        hip = ctypes.CDLL("libamdhip64.so")
+        torch.cuda.synchronize()
+        assert hip.hipMemcpy(C.c_void_p(m1.data_ptr()), p1, m1.numel() * 2, 3) == 0
+        assert hip.hipMemcpy(C.c_void_p(m2.data_ptr()), p2, m2.numel() * 2, 3) == 0
+        return m1.cpu().numpy(), m2.cpu().numpy().view(np.uint16)
+
+    def undistort_bgr(self, frames):
+        """cv.undistort on cuda uint8 [B,H,W,3] -> same shape"""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+        out = torch.empty_like(frames)
+        H.check(self.L.agt_undistort_bgr(self.h, _ptr(frames), frames.stride(1), frames.stride(0), _ptr(out), out.stride(1),
+                                         out.stride(0), frames.shape[0]), "agt_undistort_bgr")
+        return out
+
+    def preprocess_bgr(self, frames, roi=None, undistort=True, out=None):
+        """fused undistort -> BGR2GRAY -> crop: cuda uint8 [B,H,W,3] -> [B,roi_h,roi_w] (row pitch padded to 16)"""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.dim() == 4 and frames.shape[3] == 3 and frames.is_contiguous()
+        B, h, w, _ = frames.shape
+        rx, ry, rw, rh = (0, 0, w, h) if roi is None else roi
+        if out is None:
+            pitch = (rw + 15) & ~15
+            out = torch.empty((B, rh, pitch), dtype=torch.uint8, device=frames.device)[:, :, :rw]
+        H.check(self.L.agt_preprocess_bgr(self.h, _ptr(frames), frames.stride(1), frames.stride(0), w, h, B, int(bool(undistort)),
+                                          rx, ry, rw, rh, _ptr(out), out.stride(1), out.stride(0)), "agt_preprocess_bgr")
+        return out
+
     # ---- LK
     def lk_track(self, prev_slot, next_slot, prev_pts, next_pts=None, criteria=(3, 30, 0.01), flags=0,
                  min_eig_threshold=1e-4, want_err=True):
@@ -180,6 +224,61 @@ def _context(width, height, max_level, win, n):
 
 def _geom_context(n):
     return _context(64, 64, 0, 21, n)
+
+
+def getOptimalNewCameraMatrix(cameraMatrix, distCoeffs, imageSize, alpha, newImgSize=(0, 0)):
+    """cv2.getOptimalNewCameraMatrix -> (newCameraMatrix (3,3) f64, roi (x, y, w, h)).  Host arithmetic
+    (81 grid points), done by the C-ABI library like every other cv2 replacement."""
+    Kh, _ = _host_f64(cameraMatrix)
+    dh, nd = _host_f64(distCoeffs)
+    newK = np.empty(9, np.float64); roi = np.zeros(4, np.int32)
+    rc = H.lib().agt_get_optimal_new_camera_matrix(Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                                                   int(imageSize[0]), int(imageSize[1]), float(alpha), int(newImgSize[0]),
+                                                   int(newImgSize[1]), newK.ctypes.data_as(C.c_void_p), roi.ctypes.data_as(C.c_void_p))
+    if rc:
+        raise error("getOptimalNewCameraMatrix: AGT error %d" % rc)
+    return newK.reshape(3, 3), tuple(int(v) for v in roi)
+
+
+_undist_cache = {}
+
+
+def _undistort_context(w, h, K, dist, newK):
+    key = (w, h, np.asarray(K, np.float64).tobytes(), None if dist is None else np.asarray(dist, np.float64).tobytes(),
+           None if newK is None else np.asarray(newK, np.float64).tobytes(), torch.cuda.current_device())
+    ctx = _undist_cache.get(key)
+    if ctx is None:
+        ctx = Context(64, 64, max_level=0)
+        ctx.undistort_init(K, dist, newK, w, h)
+        _undist_cache.clear()
+        _undist_cache[key] = ctx
+    ctx.use_current_stream()
+    return ctx
+
+
+def undistort(src, cameraMatrix, distCoeffs, dst=None, newCameraMatrix=None):
+    """cv2.undistort for 8-bit BGR frames (INTER_LINEAR, BORDER_CONSTANT): (H,W,3) u8 -> (H,W,3) u8"""
+    _require_gpu()
+    a = np.asarray(src)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise error("undistort: an 8-bit 3-channel frame is expected")
+    h, w = a.shape[:2]
+    ctx = _undistort_context(w, h, cameraMatrix, distCoeffs, newCameraMatrix)
+    out = ctx.undistort_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0))
+    return out[0].cpu().numpy()
+
+
+def cvtColor(src, code):
+    """cv2.cvtColor(frame, COLOR_BGR2GRAY) for 8-bit frames"""
+    _require_gpu()
+    if code != COLOR_BGR2GRAY:
+        raise error("cvtColor: only COLOR_BGR2GRAY is built")
+    a = np.asarray(src)
+    if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
+        raise error("cvtColor: an 8-bit 3-channel frame is expected")
+    ctx = _geom_context(1)
+    out = ctx.preprocess_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0), None, undistort=False)
+    return out[0].cpu().numpy()
 
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,

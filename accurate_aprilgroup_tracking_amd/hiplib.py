@@ -32,6 +32,8 @@ SYMBOLS = [
     "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
+    "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
+    "agt_preprocess_bgr",
 ]
 
 
@@ -92,6 +94,11 @@ def lib():
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.agt_tracker_pipeline.argtypes = [vp, i32]
     L.agt_tracker_join.argtypes = [vp]
+    L.agt_get_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, f64, i32, i32, vp, vp]
+    L.agt_undistort_init.argtypes = [vp, vp, vp, i32, vp, i32, i32]
+    L.agt_undistort_maps.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
+    L.agt_undistort_bgr.argtypes = [vp, vp, sz, sz, vp, sz, sz, i32]
+    L.agt_preprocess_bgr.argtypes = [vp, vp, sz, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, sz]
     L.agt_profile_begin.argtypes = [vp, i32]
     L.agt_profile_end.argtypes = [vp, vp, C.POINTER(i32)]
     _lib = L

@@ -164,18 +164,25 @@ class PoseDetector(TransformHelper):
         self.prev_transform = pose
 
     # ------------------------------------------------------------------ per-frame entry (:576-619)
+    def undistort_frame(self, frame):
+        """detect_pose.py:147-183: optimal new camera matrix (alpha = 1), undistort, crop to the ROI.
+        (As in the reference, the ORIGINAL mtx/dist keep being used by solvePnP afterwards.)"""
+        height, width = frame.shape[:2]
+        new_camera_matrix, roi = self.cv.getOptimalNewCameraMatrix(self.mtx, self.dist, (width, height), 1, (width, height))
+        dst = self.cv.undistort(frame, self.mtx, self.dist, None, new_camera_matrix)
+        x_val, y_val, width, height = roi
+        return dst[y_val:y_val + height, x_val:x_val + width]
+
     def process_frame(self, frame):
-        """The reference undistorts here (detect_pose.py:147-183); that remap is SURVEY.md 8f
-        rank 1 ("next") and not built yet, so frames pass through unchanged."""
+        """detect_pose.py:611-619"""
+        if self.dist is not None:
+            frame = self.undistort_frame(frame)
         return frame
 
-    @staticmethod
-    def _to_gray(frame):
+    def _to_gray(self, frame):
         if frame.ndim == 2:
             return frame
-        b, g, r = (frame[..., i].astype(np.uint32) for i in range(3))
-        # cv.cvtColor(BGR2GRAY) fixed-point weights (14-bit): R 4899, G 9617, B 1868
-        return ((r * 4899 + g * 9617 + b * 1868 + 8192) >> 14).astype(np.uint8)
+        return self.cv.cvtColor(np.ascontiguousarray(frame), self.cv.COLOR_BGR2GRAY)       # detect_pose.py:602
 
     def track_corners(self, gray):
         """North-star step: carry the previous frame's corners into `gray` with pyramidal LK

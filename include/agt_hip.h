@@ -180,6 +180,24 @@ int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronis
  * (device memory; read it back whenever convenient).  No host synchronisation. */
 int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out);
+/* ---- frame pre-processing (the step right before the path) ---- */
+/* cv.getOptimalNewCameraMatrix(K, dist, (w,h), alpha, (new_w,new_h)) -- host arithmetic only
+ * (detect_pose.py:167-173).  newK: 9 doubles out, roi: {x, y, w, h} out (may be NULL). */
+int agt_get_optimal_new_camera_matrix(const double* K, const double* dist, int ndist, int w, int h, double alpha,
+                                      int new_w, int new_h, double* newK, int* roi);
+/* cv.initUndistortRectifyMap(K, dist, I, newK, (w,h), CV_16SC2) into context-owned device maps
+ * (6 B/pixel, built once per camera; newK NULL = K). */
+int agt_undistort_init(agt_ctx* ctx, const double* K, const double* dist, int ndist, const double* newK, int w, int h);
+int agt_undistort_maps(const agt_ctx* ctx, const int16_t** d_map1, const uint16_t** d_map2, int* w, int* h);
+/* cv.undistort(frame, K, dist, None, newK) on B BGR u8 frames of the map size (detect_pose.py:176-177). */
+int agt_undistort_bgr(agt_ctx* ctx, const uint8_t* d_src, size_t spitch, size_t sbatch,
+                      uint8_t* d_dst, size_t dpitch, size_t dbatch, int B);
+/* Fused undistort (optional) -> cv.cvtColor(BGR2GRAY) -> ROI crop (detect_pose.py:176-181, :602):
+ * B BGR u8 frames (src_w x src_h) in, gray u8 (roi_w x roi_h) out; no intermediate image in HBM. */
+int agt_preprocess_bgr(agt_ctx* ctx, const uint8_t* d_bgr, size_t spitch, size_t sbatch, int src_w, int src_h, int B,
+                       int undistort, int roi_x, int roi_y, int roi_w, int roi_h,
+                       uint8_t* d_gray, size_t gpitch, size_t gbatch);
+
 /* ---- per-kernel timing of agt_track_frame with HIP events on the context's stream ---- */
 /* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its
  * four launches (pyrDown L0->L1, pyrDown L1->L2.., LK, PnP) into the next of max_frames

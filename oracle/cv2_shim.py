@@ -16,6 +16,10 @@ def make_cv2():
     m.projectPoints = lambda o, r, t, K, d: cvoracle.projectPoints(o, r, t, K, d)
     m.Rodrigues = cvoracle.Rodrigues
     m.calcOpticalFlowPyrLK = cvoracle.calcOpticalFlowPyrLK
+    m.getOptimalNewCameraMatrix = cvoracle.getOptimalNewCameraMatrix
+    m.undistort = cvoracle.undistort
+    m.cvtColor = cvoracle.cvtColor
+    m.COLOR_BGR2GRAY = cvoracle.COLOR_BGR2GRAY
     m.error = ValueError
     return m
 

@@ -125,6 +125,17 @@ double cvo_mean_reproj_error(const double* obj, const double* img, int n,
                              const double rvec[3], const double tvec[3],
                              const double K[9], const double* dist, int ndist);
 
+/* ---- frame pre-processing (cv_imgproc.c): detect_pose.py:147-183 undistort_frame, :602 cvtColor ---- */
+int cvo_cvt_bgr2gray(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+int cvo_get_optimal_new_camera_matrix(const double K[9], const double* dist, int ndist, int w, int h, double alpha,
+                                      int new_w, int new_h, double newK[9], int roi[4]);
+int cvo_init_undistort_rectify_map(const double K[9], const double* dist, int ndist, const double newK[9],
+                                   int w, int h, int16_t* map1, uint16_t* map2);
+int cvo_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int cn,
+                          const int16_t* map1, const uint16_t* map2, int dw, int dh, uint8_t* dst, int dstride);
+int cvo_undistort_u8(const uint8_t* src, int w, int h, int sstride, int cn, const double K[9], const double* dist, int ndist,
+                     const double newK[9], uint8_t* dst, int dstride);
+
 /* ---- small dense linear algebra (one-sided Jacobi SVD, as OpenCV's JacobiSVDImpl_) ---- */
 /* A: m x n row-major (m >= n). w: n, u: m x n (columns = left vectors), vt: n x n. sorted descending. */
 int cvo_svd(const double* A, int m, int n, double* w, double* u, double* vt);

@@ -59,6 +59,11 @@ def lib():
         L.cvo_mean_reproj_error.argtypes = [vp, vp, i32, vp, vp, vp, vp, i32]
         L.cvo_svd.argtypes = [vp, i32, i32, vp, vp, vp]
         L.cvo_solve_svd.argtypes = [vp, vp, i32, vp]
+        L.cvo_cvt_bgr2gray.argtypes = [vp, i32, i32, i32, vp, i32]
+        L.cvo_get_optimal_new_camera_matrix.argtypes = [vp, vp, i32, i32, i32, f64, i32, i32, vp, vp]
+        L.cvo_init_undistort_rectify_map.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
+        L.cvo_remap_bilinear_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32]
+        L.cvo_undistort_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32]
         L.cvo_track_frame.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32,
                                       vp, vp, i32, i32, i32, i32, f64, i32, i32, vp]
         _lib = L
@@ -161,6 +166,55 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     if rc:
         raise ValueError("calcOpticalFlowPyrLK oracle error %d" % rc)
     return nx.reshape(-1, 1, 2), st.reshape(-1, 1), er.reshape(-1, 1)
+
+
+COLOR_BGR2GRAY = 6
+
+
+def cvtColor(src, code):
+    if code != COLOR_BGR2GRAY:
+        raise ValueError("only COLOR_BGR2GRAY is restated")
+    a = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w, _ = a.shape
+    out = np.empty((h, w), np.uint8)
+    rc = lib().cvo_cvt_bgr2gray(_p(a), w, h, a.strides[0], _p(out), out.strides[0])
+    assert rc == 0
+    return out
+
+
+def getOptimalNewCameraMatrix(cameraMatrix, distCoeffs, imageSize, alpha, newImgSize=(0, 0)):
+    """cv2.getOptimalNewCameraMatrix -> (newK (3,3) f64, roi (x, y, w, h))"""
+    K = _f64(cameraMatrix).reshape(9); d, nd = _dist(distCoeffs)
+    newK = np.empty(9); roi = np.zeros(4, np.int32)
+    rc = lib().cvo_get_optimal_new_camera_matrix(_p(K), _p(d), nd, int(imageSize[0]), int(imageSize[1]), float(alpha),
+                                                 int(newImgSize[0]), int(newImgSize[1]), _p(newK), _p(roi))
+    if rc:
+        raise ValueError("getOptimalNewCameraMatrix oracle error %d" % rc)
+    return newK.reshape(3, 3), tuple(int(v) for v in roi)
+
+
+def initUndistortRectifyMap(cameraMatrix, distCoeffs, newCameraMatrix, size):
+    """CV_16SC2 maps: map1 (h, w, 2) int16, map2 (h, w) uint16; R = I"""
+    K = _f64(cameraMatrix).reshape(9); d, nd = _dist(distCoeffs); nK = _f64(newCameraMatrix).reshape(9)
+    w, h = int(size[0]), int(size[1])
+    m1 = np.empty((h, w, 2), np.int16); m2 = np.empty((h, w), np.uint16)
+    rc = lib().cvo_init_undistort_rectify_map(_p(K), _p(d), nd, _p(nK), w, h, _p(m1), _p(m2))
+    if rc:
+        raise ValueError("initUndistortRectifyMap oracle error %d" % rc)
+    return m1, m2
+
+
+def undistort(src, cameraMatrix, distCoeffs, dst=None, newCameraMatrix=None):
+    """cv2.undistort for 8-bit images with 1..4 channels (INTER_LINEAR, BORDER_CONSTANT)"""
+    a = np.ascontiguousarray(src, dtype=np.uint8)
+    h, w = a.shape[:2]; cn = 1 if a.ndim == 2 else a.shape[2]
+    K = _f64(cameraMatrix).reshape(9); d, nd = _dist(distCoeffs)
+    nK = K if newCameraMatrix is None else _f64(newCameraMatrix).reshape(9)
+    out = np.empty_like(a)
+    rc = lib().cvo_undistort_u8(_p(a), w, h, a.strides[0], cn, _p(K), _p(d), nd, _p(nK), _p(out), out.strides[0])
+    if rc:
+        raise ValueError("undistort oracle error %d" % rc)
+    return out
 
 
 # --------------------------------------------------------------------------- geometry
