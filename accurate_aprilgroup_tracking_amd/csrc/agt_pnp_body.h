@@ -315,7 +315,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         for (int i = 0; i < 6; i++) param[i] = P.pose[(long)b * 6 + i];
     }
 
-    const bool enough = use_guess ? n_used >= 3 : n_used >= 6;
+    const bool enough = use_guess ? n_used >= 3 : n_used >= 4;      // the DLT branch re-checks for >= 6
     if (!enough) {
         if (lane == 0 && P.info) {
             P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
@@ -343,10 +343,119 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         double Wm[3], Um[9], Vm[9];
         agt_svd3(MM, Wm, Um, Vm);
         if (Wm[2] / Wm[1] < 1e-3) {
-            // planar structure: homography initialisation is not built yet
+            // ---- planar structure: cvFindExtrinsicCameraParams2's homography branch.
+            // findHomography(method 0) = normalised DLT; OpenCV's LM polish of H is omitted, the pose LM
+            // below minimises the same error (same choice as oracle/cv_pnp.c homography_dlt).
+            flags |= AGT_PNP_PLANAR;
+            double Rt[9];
+#pragma unroll
+            for (int i = 0; i < 9; i++) Rt[i] = Vm[i];
+            if (Vm[2] * Vm[2] + Vm[5] * Vm[5] < 1e-10) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) Rt[i] = (i % 4 == 0) ? 1.0 : 0.0;
+            }
+            if (agt_det3(Rt) < 0) {
+#pragma unroll
+                for (int i = 0; i < 9; i++) Rt[i] = -Rt[i];
+            }
+            double Tt[3];
+#pragma unroll
+            for (int a = 0; a < 3; a++) Tt[a] = -(Rt[a * 3] * mcx + Rt[a * 3 + 1] * mcy + Rt[a * 3 + 2] * mcz);
+            double px_[PPL], py_[PPL], nx_[PPL], ny_[PPL];
+            double c8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int q = 0; q < PPL; q++) {
+                px_[q] = py_[q] = nx_[q] = ny_[q] = 0.0;
+                if (use[q]) {
+                    px_[q] = Rt[0] * X[q] + Rt[1] * Y[q] + Rt[2] * Z[q] + Tt[0];
+                    py_[q] = Rt[3] * X[q] + Rt[4] * Y[q] + Rt[5] * Z[q] + Tt[1];
+                    undistort5(cam, mu_[q], mv_[q], nx_[q], ny_[q]);
+                    c8[0] += nx_[q]; c8[1] += ny_[q]; c8[2] += px_[q]; c8[3] += py_[q];
+                }
+            }
+            wave_reduce_slab<8>(c8, sh, lane);
+            const double cmx = c8[0] / n_used, cmy = c8[1] / n_used, cMx = c8[2] / n_used, cMy = c8[3] / n_used;
+            double d8[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+#pragma unroll
+            for (int q = 0; q < PPL; q++) if (use[q]) {
+                d8[0] += fabs(nx_[q] - cmx); d8[1] += fabs(ny_[q] - cmy); d8[2] += fabs(px_[q] - cMx); d8[3] += fabs(py_[q] - cMy);
+            }
+            wave_reduce_slab<8>(d8, sh, lane);
+            bool hom_ok = !(fabs(d8[0]) < DBL_EPSILON || fabs(d8[1]) < DBL_EPSILON || fabs(d8[2]) < DBL_EPSILON || fabs(d8[3]) < DBL_EPSILON);
+            const double smx = n_used / d8[0], smy = n_used / d8[1], sMx = n_used / d8[2], sMy = n_used / d8[3];
+            // L^T L of the 2N x 9 system has 24 distinct sums: w * P P^T, P = (X, Y, 1), w in {1, x, y, x^2 + y^2}
+            double t0[6], tx[6], ty[6], tq[6];
+#pragma unroll
+            for (int i = 0; i < 6; i++) t0[i] = tx[i] = ty[i] = tq[i] = 0.0;
+#pragma unroll
+            for (int q = 0; q < PPL; q++) if (use[q]) {
+                const double x = (nx_[q] - cmx) * smx, y = (ny_[q] - cmy) * smy;
+                const double Xn = (px_[q] - cMx) * sMx, Yn = (py_[q] - cMy) * sMy;
+                const double pp[6] = { Xn * Xn, Xn * Yn, Xn, Yn * Yn, Yn, 1.0 };
+                const double w2 = x * x + y * y;
+#pragma unroll
+                for (int i = 0; i < 6; i++) { t0[i] += pp[i]; tx[i] += x * pp[i]; ty[i] += y * pp[i]; tq[i] += w2 * pp[i]; }
+            }
+            wave_reduce_slab<6>(t0, sh, lane);
+            wave_reduce_slab<6>(tx, sh, lane);
+            wave_reduce_slab<6>(ty, sh, lane);
+            wave_reduce_slab<6>(tq, sh, lane);
+            __syncthreads();
+            if (lane == 0) {
+                const int ui[3][3] = { { 0, 1, 2 }, { 1, 3, 4 }, { 2, 4, 5 } };
+                double* LtL = sh.LL;              // 9 x 9
+                for (int a = 0; a < 3; a++)
+                    for (int c = 0; c < 3; c++) {
+                        const int u = ui[a][c];
+                        LtL[a * 9 + c] = t0[u];          LtL[a * 9 + 3 + c] = 0.0;            LtL[a * 9 + 6 + c] = -tx[u];
+                        LtL[(3 + a) * 9 + c] = 0.0;      LtL[(3 + a) * 9 + 3 + c] = t0[u];    LtL[(3 + a) * 9 + 6 + c] = -ty[u];
+                        LtL[(6 + a) * 9 + c] = -tx[u];   LtL[(6 + a) * 9 + 3 + c] = -ty[u];   LtL[(6 + a) * 9 + 6 + c] = tq[u];
+                    }
+                double* hv = sh.vec;
+                smallest_eigvec(LtL, 9, hv, sh.vec + 16);
+                const double invHn[9] = { 1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1 };
+                const double Hn2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
+                double H0[9], Tm[9], h[9];
+                for (int i = 0; i < 9; i++) H0[i] = hv[i];
+                agt_mat3_mul(invHn, H0, Tm);
+                agt_mat3_mul(Tm, Hn2, h);
+                bool ok = hom_ok && h[8] != 0.0;
+                for (int i = 0; i < 9; i++) ok = ok && (h[i] - h[i] == 0.0);
+                double Rm[9], tv[3];
+                if (ok) {
+                    const double s8 = 1.0 / h[8];
+                    for (int i = 0; i < 9; i++) h[i] *= s8;
+                    const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
+                    const double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
+                    const double s1 = 1. / fmax(h1n, DBL_EPSILON), s2 = 1. / fmax(h2n, DBL_EPSILON), s3 = 2. / fmax(h1n + h2n, DBL_EPSILON);
+                    const double t3[3] = { h[2] * s3, h[5] * s3, h[8] * s3 };
+                    h[0] *= s1; h[3] *= s1; h[6] *= s1;
+                    h[1] *= s2; h[4] *= s2; h[7] *= s2;
+                    h[2] = h[3] * h[7] - h[6] * h[4];
+                    h[5] = h[6] * h[1] - h[0] * h[7];
+                    h[8] = h[0] * h[4] - h[3] * h[1];
+                    double rr[3], dummy[27];
+                    agt_rodrigues_inv(h, rr);
+                    agt_rodrigues<false>(rr, h, dummy);
+                    for (int a = 0; a < 3; a++) tv[a] = h[a * 3] * Tt[0] + h[a * 3 + 1] * Tt[1] + h[a * 3 + 2] * Tt[2] + t3[a];
+                    agt_mat3_mul(h, Rt, Rm);
+                } else {
+                    for (int i = 0; i < 9; i++) Rm[i] = (i % 4 == 0) ? 1.0 : 0.0;
+                    tv[0] = tv[1] = tv[2] = 0.0;
+                }
+                double rv[3];
+                agt_rodrigues_inv(Rm, rv);
+                sh.vec[32] = rv[0]; sh.vec[33] = rv[1]; sh.vec[34] = rv[2];
+                sh.vec[35] = tv[0]; sh.vec[36] = tv[1]; sh.vec[37] = tv[2];
+            }
+            __syncthreads();
+#pragma unroll
+            for (int i = 0; i < 6; i++) param[i] = sh.vec[32 + i];
+        } else {
+        if (n_used < 6) {                     // non-planar DLT needs six correspondences
             if (lane == 0 && P.info) {
                 P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
-                P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_PLANAR;
+                P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_TOO_FEW;
             }
             if (lane == 0 && P.err) P.err[b] = 0.0;
             if (lane == 0 && ts) {
@@ -354,7 +463,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 if (P.state_out) {
                     double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_PLANAR;
+                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
                 }
             }
             return;
@@ -411,6 +520,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         __syncthreads();
 #pragma unroll
         for (int i = 0; i < 6; i++) param[i] = sh.vec[32 + i];
+        }   // non-planar (DLT) branch
     }
 
     // ---- CvLevMarq

@@ -350,9 +350,7 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
     p = pose.cpu().numpy().reshape(6)
     inf = info.cpu().numpy().reshape(4)
     if not inf[H.INFO_OK]:
-        if inf[H.INFO_FLAGS] & H.PNP_PLANAR:
-            raise error("solvePnP: un-guessed solve on a planar point set is not built yet")
-        raise error("solvePnP: not enough usable points")
+        raise error("solvePnP: not enough usable points (non-planar sets need 6 without a guess)")
     if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
             and rvec.dtype in (np.float32, np.float64) and tvec.dtype in (np.float32, np.float64):
         rvec.reshape(-1)[:] = p[:3]

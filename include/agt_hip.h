@@ -63,7 +63,7 @@ extern "C" {
 #define AGT_INFO_NUSED  2   /* points with mask != 0 */
 #define AGT_INFO_FLAGS  3   /* AGT_PNP_* bits */
 #define AGT_PNP_SINGULAR  1 /* a damped normal-equation solve hit a non-positive pivot */
-#define AGT_PNP_PLANAR    2 /* un-guessed solve on a planar point set (homography init) */
+#define AGT_PNP_PLANAR    2 /* un-guessed solve initialised through the planar (homography) branch */
 #define AGT_PNP_TOO_FEW   4 /* fewer usable points than the solve needs; pose untouched */
 
 /* agt_track_frame state flags, state_out[b*AGT_STATE_STRIDE + ...] (doubles) */

@@ -204,6 +204,33 @@ def test_solve_pnp_large_n(cvh, oracle):
     assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
 
 
+def test_solve_pnp_planar_init(torch_cuda, cvh, oracle):
+    """cvFindExtrinsicCameraParams2's homography branch: coplanar points, no guess"""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn, hiplib as H
+    K = syn.camera_matrix(640, 480)
+    rng = np.random.default_rng(6)
+    r = np.array([0.3, -0.2, 0.1]); t = np.array([0.01, 0.02, 0.4])
+    h = 0.01
+    cases = [np.array([[-h, -h, 0], [-h, h, 0], [h, h, 0], [h, -h, 0.0]]),                                  # one tag
+             np.concatenate([rng.uniform(-0.05, 0.05, (10, 2)), np.zeros((10, 1))], axis=1)]               # 10 coplanar points
+    Rt = oracle.Rodrigues(np.array([0.4, 0.5, -0.3]))[0]
+    cases.append(cases[1] @ Rt.T + np.array([0.01, -0.02, 0.03]))                                          # tilted plane
+    for obj in cases:
+        for dist in (None, syn.MILD_DIST):
+            img = syn.project(obj, r, t, K, dist) + rng.normal(0, 0.02, (len(obj), 2))
+            ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, dist)
+            ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, dist)
+            assert np.abs(r_o - r_g).max() < 1e-8 and np.abs(t_o - t_g).max() < 1e-8
+            assert np.abs(r_g.ravel() - r).max() < 2e-2
+    # the flag is reported
+    ctx = cvh.Context(64, 64, max_level=0)
+    obj = torch_cuda.from_numpy(cases[1]).cuda(); img = torch_cuda.from_numpy(syn.project(cases[1], r, t, K)[None]).cuda()
+    pose, info, err = ctx.solve_pnp(obj, img, K, None)
+    assert info.cpu().numpy()[0, H.INFO_OK] == 1 and info.cpu().numpy()[0, H.INFO_FLAGS] & H.PNP_PLANAR
+    with pytest.raises(ValueError):
+        cvh.solvePnP(rng.uniform(-1, 1, (5, 3)), rng.uniform(0, 100, (5, 2)), K, None)      # non-planar with 5 points
+
+
 def test_error_behaviour(cvh):
     obj = np.zeros((3, 3)); img = np.zeros((3, 2)); K = np.eye(3)
     with pytest.raises(ValueError):
