@@ -41,6 +41,8 @@ struct agt_ctx {
     int lk_max_count; double lk_eps; double lk_min_eig;
     // undistortion maps of the pre-processing stage (built once per camera)
     short2* map1; unsigned short* map2; int map_w, map_h;
+    // scratch of the dense refinement: per-block partial sums and the per-stream done words
+    double* dense_partials; int* dense_done; size_t dense_cap;
     // optional per-kernel timing (agt_profile_begin/end)
     hipEvent_t* prof_ev;
     int prof_cap, prof_n;
@@ -147,6 +149,8 @@ int agt_destroy(agt_ctx* c)
     if (c->obj) (void)hipFree(c->obj);
     if (c->pose) (void)hipFree(c->pose);
     if (c->tstate) (void)hipFree(c->tstate);
+    if (c->dense_partials) (void)hipFree(c->dense_partials);
+    if (c->dense_done) (void)hipFree(c->dense_done);
     if (c->map1) (void)hipFree(c->map1);
     if (c->map2) (void)hipFree(c->map2);
     if (c->prof_ev) {
@@ -644,7 +648,9 @@ int agt_undistort_init(agt_ctx* c, const double* K, const double* dist, int ndis
     if (c->map_w != w || c->map_h != h) {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(c, e);
-        if (c->map1) (void)hipFree(c->map1);
+        if (c->dense_partials) (void)hipFree(c->dense_partials);
+    if (c->dense_done) (void)hipFree(c->dense_done);
+    if (c->map1) (void)hipFree(c->map1);
         if (c->map2) (void)hipFree(c->map2);
         c->map1 = nullptr; c->map2 = nullptr; c->map_w = c->map_h = 0;
         if (hipMalloc((void**)&c->map1, (size_t)w * h * sizeof(short2)) != hipSuccess ||
@@ -691,6 +697,36 @@ int agt_preprocess_bgr(agt_ctx* c, const uint8_t* d_bgr, size_t spitch, size_t s
     if (undistort && (!c->map1 || c->map_w != src_w || c->map_h != src_h)) return AGT_ERR_STATE;
     hipError_t e = agt_launch_preprocess(c->stream, d_bgr, (long)spitch, (long)sbatch, src_w, src_h, c->map1, c->map2, src_w,
                                          roi_x, roi_y, roi_w, roi_h, d_gray, (long)gpitch, (long)gbatch, undistort ? 1 : 0, 1, B);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// dense photometric + geometric pose refinement (semantics: oracle/cv_dense.c / csrc/agt_dense.hip)
+int agt_dense_refine(agt_ctx* c, const uint8_t* d_img, size_t pitch, size_t batch_stride, int w, int h,
+                     const float* d_model_xyz, const float* d_model_t, int M,
+                     const float* d_obj, const float* d_img_pts, const uint8_t* d_mask, int N,
+                     const double* K, const double* dist, int ndist,
+                     double* d_pose, int B, int iters, double photo_weight, double* d_stats)
+{
+    if (!c || !d_img || !d_pose || !d_stats || B <= 0 || w < 4 || h < 4 || iters < 0 || iters > 1000) return AGT_ERR_ARG;
+    if (M < 0 || N < 0 || (M > 0 && (!d_model_xyz || !d_model_t)) || (N > 0 && (!d_obj || !d_img_pts))) return AGT_ERR_ARG;
+    if (M + N == 0 || pitch < (size_t)w || !(photo_weight >= 0.0)) return AGT_ERR_ARG;
+    AgtCameraHost cam;
+    int rc = fill_camera(K, dist, ndist, &cam);
+    if (rc) return rc;
+    const size_t need = (size_t)B * (size_t)(agt_dense_blocks(M) > 0 ? agt_dense_blocks(M) : 1) * 32;
+    if (need > c->dense_cap) {
+        hipError_t e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        if (c->dense_partials) (void)hipFree(c->dense_partials);
+        if (c->dense_done) (void)hipFree(c->dense_done);
+        c->dense_partials = nullptr; c->dense_done = nullptr; c->dense_cap = 0;
+        if (hipMalloc((void**)&c->dense_partials, need * sizeof(double)) != hipSuccess ||
+            hipMalloc((void**)&c->dense_done, (size_t)B * sizeof(int) + 64) != hipSuccess) return AGT_ERR_ALLOC;
+        c->dense_cap = need;
+    }
+    hipError_t e = agt_launch_dense(c->stream, d_img, (long)pitch, (long)batch_stride, w, h, d_model_xyz, d_model_t, M,
+                                    d_obj, d_img_pts, d_mask, N, cam, d_pose, c->dense_partials, d_stats, c->dense_done,
+                                    B, iters, photo_weight, 1e-3);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 

@@ -109,6 +109,12 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
                                  const short2* map1, const unsigned short* map2, int mw,
                                  int rx, int ry, int rw, int rh, uint8_t* dst, long dpitch, long dbatch,
                                  int undistort, int gray, int B);
+hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,
+                            const float* mxyz, const float* mt, int M,
+                            const float* obj, const float* ipts, const uint8_t* mask, int N,
+                            const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
+                            int B, int iters, double photo_weight, double mu);
+int agt_dense_blocks(int M);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);

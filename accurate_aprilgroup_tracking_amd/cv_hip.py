@@ -146,6 +146,27 @@ class Context:
                                           rx, ry, rw, rh, _ptr(out), out.stride(1), out.stride(0)), "agt_preprocess_bgr")
         return out
 
+    # ---- dense photometric + geometric refinement (BASELINE config 5; semantics: oracle/cv_dense.c)
+    def dense_refine(self, frames, model_xyz, model_t, pose, K, dist, obj=None, img_pts=None, mask=None, iters=5, photo_weight=0.01):
+        """frames cuda u8 [B,H,W]; model_xyz cuda f32 [M,3]; model_t cuda f32 [M]; pose cuda f64 [B,6] (in/out);
+        obj cuda f32 [N,3] + img_pts cuda f32 [B,N,2] (+ mask u8 [B,N]) add the corner term.  Returns (pose, stats [B,8])."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.dim() == 3
+        assert model_xyz.dtype == torch.float32 and model_xyz.is_contiguous() and model_t.dtype == torch.float32 and model_t.is_contiguous()
+        assert pose.dtype == torch.float64 and pose.is_contiguous()
+        B, h, w = frames.shape
+        M = model_xyz.shape[0]
+        N = 0 if obj is None else obj.shape[0]
+        if N:
+            assert obj.dtype == torch.float32 and obj.is_contiguous() and img_pts.dtype == torch.float32 and img_pts.is_contiguous()
+            assert img_pts.shape == (B, N, 2)
+        stats = torch.zeros((B, 8), dtype=torch.float64, device=frames.device)
+        Kh, _ = _host_f64(K); dh, nd = _host_f64(dist)
+        H.check(self.L.agt_dense_refine(self.h, _ptr(frames), frames.stride(1), frames.stride(0), w, h, _ptr(model_xyz), _ptr(model_t), M,
+                                        _ptr(obj), _ptr(img_pts), _ptr(mask), N, Kh.ctypes.data_as(C.c_void_p),
+                                        dh.ctypes.data_as(C.c_void_p) if nd else None, nd, _ptr(pose), B, int(iters),
+                                        float(photo_weight), _ptr(stats)), "agt_dense_refine")
+        return pose, stats
+
     # ---- LK
     def lk_track(self, prev_slot, next_slot, prev_pts, next_pts=None, criteria=(3, 30, 0.01), flags=0,
                  min_eig_threshold=1e-4, want_err=True):

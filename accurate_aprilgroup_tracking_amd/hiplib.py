@@ -33,7 +33,7 @@ SYMBOLS = [
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
-    "agt_preprocess_bgr",
+    "agt_preprocess_bgr", "agt_dense_refine",
 ]
 
 
@@ -99,6 +99,7 @@ def lib():
     L.agt_undistort_maps.argtypes = [vp, C.POINTER(vp), C.POINTER(vp), C.POINTER(i32), C.POINTER(i32)]
     L.agt_undistort_bgr.argtypes = [vp, vp, sz, sz, vp, sz, sz, i32]
     L.agt_preprocess_bgr.argtypes = [vp, vp, sz, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, sz]
+    L.agt_dense_refine.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f64, vp]
     L.agt_profile_begin.argtypes = [vp, i32]
     L.agt_profile_end.argtypes = [vp, vp, C.POINTER(i32)]
     _lib = L

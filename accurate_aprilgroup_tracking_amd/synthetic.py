@@ -85,6 +85,35 @@ def group_object_points(group):
     return np.array(pts).reshape(-1, 3)
 
 
+def model_samples(group, grid=32, extent=0.6):
+    """(T*grid*grid, 3) float32 object-frame points on every tag plane, a grid x grid lattice over
+    [-extent*size, +extent*size]^2 (covers the black border and its outer edge): the dense-alignment
+    model of BASELINE config 5 (60 tags x 32 x 32 = 61,440 samples)."""
+    pts = []
+    lin = (np.arange(grid) + 0.5) / grid * 2.0 - 1.0
+    for key in group["tags"]:
+        tag = group["tags"][key]
+        s = tag["size"] * extent
+        uu, vv = np.meshgrid(lin * s, lin * s)
+        local = np.stack([uu.ravel(), vv.ravel(), np.zeros(uu.size)], axis=1)
+        tvec = np.array(tag["extrinsics"][:3], dtype=np.float32).astype(np.float64)
+        rvec = np.array(tag["extrinsics"][-3:], dtype=np.float32).astype(np.float64)
+        pts.append(local @ Rotation.from_rotvec(rvec).as_matrix().T + tvec)
+    return np.concatenate(pts).astype(np.float32)
+
+
+def sample_bilinear(img, uv):
+    """bilinear samples of a gray image at (N,2) pixel coordinates (float64); NaN outside"""
+    img = np.asarray(img, np.float64); h, w = img.shape
+    x, y = uv[:, 0], uv[:, 1]
+    x0 = np.floor(x).astype(np.int64); y0 = np.floor(y).astype(np.int64)
+    ok = (x0 >= 0) & (x0 < w - 1) & (y0 >= 0) & (y0 < h - 1)
+    x0c = np.clip(x0, 0, w - 2); y0c = np.clip(y0, 0, h - 2)
+    a = x - x0; b = y - y0
+    v = (1 - a) * (1 - b) * img[y0c, x0c] + a * (1 - b) * img[y0c, x0c + 1] + (1 - a) * b * img[y0c + 1, x0c] + a * b * img[y0c + 1, x0c + 1]
+    return np.where(ok, v, np.nan)
+
+
 def tag_bits(n_tags, seed=0):
     """(T, 6, 6) pseudo tag36 payloads (random bits; decoding is out of scope)."""
     return np.random.default_rng(seed + 7919).integers(0, 2, size=(n_tags, 6, 6)).astype(np.uint8)

@@ -198,6 +198,20 @@ int agt_preprocess_bgr(agt_ctx* ctx, const uint8_t* d_bgr, size_t spitch, size_t
                        int undistort, int roi_x, int roi_y, int roi_w, int roi_h,
                        uint8_t* d_gray, size_t gpitch, size_t gbatch);
 
+/* ---- dense photometric + geometric pose refinement (BASELINE configs[4]; no reference code exists:
+ * the semantics are specified in oracle/cv_dense.c and implemented by csrc/agt_dense.hip) ----
+ * E(p) = sum |project(obj_j; p) - img_j|^2 + photo_weight * sum (I~(project(X_i; p)) - T_i)^2, damped
+ * Gauss-Newton (mu = 1e-3), `iters` iterations at most, early stop at relative step < FLT_EPSILON.
+ * d_img: B gray u8 frames (w x h).  d_model_xyz [M][3] f32 / d_model_t [M] f32: model samples and
+ * template intensities (shared by the B streams).  d_obj [N][3] f32, d_img_pts [B][N][2] f32,
+ * d_mask [B][N] u8 or NULL: corner term (N may be 0).  d_pose [B][6] f64 in/out.
+ * d_stats [B][8] f64: photometric RMS, geometric RMS, valid samples, iterations run, corners used. */
+int agt_dense_refine(agt_ctx* ctx, const uint8_t* d_img, size_t pitch, size_t batch_stride, int w, int h,
+                     const float* d_model_xyz, const float* d_model_t, int M,
+                     const float* d_obj, const float* d_img_pts, const uint8_t* d_mask, int N,
+                     const double* K, const double* dist, int ndist,
+                     double* d_pose, int B, int iters, double photo_weight, double* d_stats);
+
 /* ---- per-kernel timing of agt_track_frame with HIP events on the context's stream ---- */
 /* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its
  * four launches (pyrDown L0->L1, pyrDown L1->L2.., LK, PnP) into the next of max_frames

@@ -136,6 +136,15 @@ int cvo_remap_bilinear_u8(const uint8_t* src, int sw, int sh, int sstride, int c
 int cvo_undistort_u8(const uint8_t* src, int w, int h, int sstride, int cn, const double K[9], const double* dist, int ndist,
                      const double newK[9], uint8_t* dst, int dstride);
 
+/* ---- dense photometric pose refinement (cv_dense.c; semantics DEFINED by this build, see that file) ---- */
+int cvo_dense_sample(const uint8_t* img, int w, int h, int stride, double u, double v, const double ju[6], const double jv[6],
+                     double t, double* r, double jrow[6]);
+int cvo_dense_refine(const uint8_t* img, int w, int h, int stride,
+                     const float* model_xyz, const float* model_t, int M,
+                     const float* obj, const float* img_pts, const uint8_t* mask, int N,
+                     const double K[9], const double* dist, int ndist,
+                     double pose[6], int iters, double photo_weight, double mu, double stats[8]);
+
 /* ---- small dense linear algebra (one-sided Jacobi SVD, as OpenCV's JacobiSVDImpl_) ---- */
 /* A: m x n row-major (m >= n). w: n, u: m x n (columns = left vectors), vt: n x n. sorted descending. */
 int cvo_svd(const double* A, int m, int n, double* w, double* u, double* vt);

@@ -64,6 +64,7 @@ def lib():
         L.cvo_init_undistort_rectify_map.argtypes = [vp, vp, i32, vp, i32, i32, vp, vp]
         L.cvo_remap_bilinear_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, i32, vp, i32]
         L.cvo_undistort_u8.argtypes = [vp, i32, i32, i32, i32, vp, vp, i32, vp, vp, i32]
+        L.cvo_dense_refine.argtypes = [vp, i32, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, f64, f64, vp]
         L.cvo_track_frame.argtypes = [vp, vp, i32, i32, i32, vp, vp, vp, vp, i32, vp, vp, vp, i32,
                                       vp, vp, i32, i32, i32, i32, f64, i32, i32, vp]
         _lib = L
@@ -310,6 +311,26 @@ def mean_reproj_error(objectPoints, imagePoints, rvec, tvec, cameraMatrix, distC
     K = _f64(cameraMatrix).reshape(9); d, nd = _dist(distCoeffs)
     r = _f64(rvec).reshape(3); t = _f64(tvec).reshape(3)
     return lib().cvo_mean_reproj_error(_p(obj), _p(img), obj.shape[0], _p(r), _p(t), _p(K), _p(d), nd)
+
+
+def dense_refine(img, model_xyz, model_t, obj, img_pts, mask, K, dist, rvec, tvec, iters=5, photo_weight=0.01, mu=1e-3):
+    """Dense photometric + geometric Gauss-Newton refinement (semantics: oracle/cv_dense.c).
+    -> (rvec (3,), tvec (3,), stats dict)"""
+    a = np.ascontiguousarray(img, dtype=np.uint8); h, w = a.shape
+    mx = np.ascontiguousarray(np.asarray(model_xyz, np.float32).reshape(-1, 3)); mt = np.ascontiguousarray(np.asarray(model_t, np.float32).reshape(-1))
+    M = mx.shape[0]
+    if obj is None:
+        o = ip = mk = None; N = 0
+    else:
+        o = np.ascontiguousarray(np.asarray(obj, np.float32).reshape(-1, 3)); ip = np.ascontiguousarray(np.asarray(img_pts, np.float32).reshape(-1, 2))
+        N = o.shape[0]; mk = None if mask is None else np.ascontiguousarray(np.asarray(mask, np.uint8).reshape(-1))
+    Kc = _f64(K).reshape(9); d, nd = _dist(dist)
+    pose = np.concatenate([_f64(rvec).reshape(3), _f64(tvec).reshape(3)]).copy(); stats = np.zeros(8)
+    rc = lib().cvo_dense_refine(_p(a), w, h, a.strides[0], _p(mx), _p(mt), M, _p(o), _p(ip), _p(mk), N, _p(Kc), _p(d), nd,
+                                _p(pose), int(iters), float(photo_weight), float(mu), _p(stats))
+    if rc:
+        raise ValueError("dense_refine oracle error %d" % rc)
+    return pose[:3].copy(), pose[3:].copy(), dict(photo_rms=stats[0], geo_rms=stats[1], valid=int(stats[2]), iters=int(stats[3]), used=int(stats[4]))
 
 
 def svd(A):

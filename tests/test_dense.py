@@ -1,0 +1,148 @@
+"""Dense photometric pose refinement (BASELINE configs[4] / SURVEY a12, 8f rank 2).  No reference code
+exists; the specification lives in oracle/cv_dense.c.  CPU: the oracle satisfies its own spec
+(finite-difference Jacobian, convergence to a known pose).  GPU: HIP vs oracle."""
+import ctypes as C
+import numpy as np
+import pytest
+
+from accurate_aprilgroup_tracking_amd import synthetic as syn
+
+
+@pytest.fixture(scope="module")
+def scene():
+    s = syn.Sequence(1280, 720, n_tags=12, n_frames=3, seed=5, supersample=3)
+    mx = syn.model_samples(s.group, 32)
+    return s, mx
+
+
+def _template(s, mx, k):
+    return np.nan_to_num(syn.sample_bilinear(s.frame(k), syn.project(mx, s.rvecs[k], s.tvecs[k], s.K)), nan=128.0).astype(np.float32)
+
+
+def test_photometric_rows_follow_the_specification(oracle, scene):
+    """r_i and dr_i/dp against an independent numpy statement of the spec (bilinear intensity,
+    bilinearly interpolated central-difference gradient), and the cost gradient J^T r against finite
+    differences of the cost (the interpolated gradient is a smoothed derivative, so directions --
+    not individual entries -- are compared)."""
+    s, mx = scene
+    f = s.frame(1).astype(np.float64)
+    L = oracle.lib()
+    L.cvo_dense_sample.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_double, C.c_double, C.c_void_p, C.c_void_p,
+                                   C.c_double, C.c_void_p, C.c_void_p]
+    f8 = s.frame(1)
+    gxi = np.zeros_like(f); gyi = np.zeros_like(f)
+    gxi[:, 1:-1] = (f[:, 2:] - f[:, :-2]) * 0.5
+    gyi[1:-1, :] = (f[2:, :] - f[:-2, :]) * 0.5
+    T = 100.0
+
+    def rows(pp, idx, use_oracle):
+        nonlocal f8
+        uv, jac = oracle.projectPoints(mx[idx].astype(np.float64), pp[:3], pp[3:], s.K, None, jacobian=True)
+        uv = uv.reshape(-1, 2)
+        if not use_oracle:
+            I = syn.sample_bilinear(f, uv); gx = syn.sample_bilinear(gxi, uv); gy = syn.sample_bilinear(gyi, uv)
+            return I - T, gx[:, None] * jac[0::2] + gy[:, None] * jac[1::2]
+        out_r, out_j = [], []
+        for n in range(len(idx)):
+            ju = np.ascontiguousarray(jac[2 * n]); jv = np.ascontiguousarray(jac[2 * n + 1])
+            r = C.c_double(); J = np.zeros(6)
+            assert L.cvo_dense_sample(f8.ctypes.data, 1280, 720, f8.strides[0], float(uv[n, 0]), float(uv[n, 1]),
+                                      ju.ctypes.data, jv.ctypes.data, T, C.byref(r), J.ctypes.data)
+            out_r.append(r.value); out_j.append(J)
+        return np.array(out_r), np.array(out_j)
+    p = np.concatenate([s.rvecs[1], s.tvecs[1]])
+    idx = np.arange(0, len(mx), 97)
+    uv0 = syn.project(mx[idx], s.rvecs[1], s.tvecs[1], s.K)
+    inside = (uv0[:, 0] > 4) & (uv0[:, 0] < 1280 - 6) & (uv0[:, 1] > 4) & (uv0[:, 1] < 720 - 6)     # valid for every perturbed pose below
+    idx = idx[inside]
+    assert len(idx) > 100
+    r_o, J_o = rows(p, idx, True)
+    r_n, J_n = rows(p, idx, False)
+    assert np.abs(r_o - r_n).max() < 1e-9 and np.abs(J_o - J_n).max() < 1e-7 * np.abs(J_n).max()
+    # samples whose 2x2 cell touches the frame border are invalid
+    r = C.c_double(); J = np.zeros(6); z = np.zeros(6)
+    for (u, v, ok) in ((0.5, 100.0, 0), (1.0, 1.0, 1), (1277.99, 300.0, 1), (1278.0, 300.0, 0), (640.0, 717.99, 1), (640.0, 718.0, 0), (-3.0, 5.0, 0)):
+        assert L.cvo_dense_sample(f8.ctypes.data, 1280, 720, f8.strides[0], u, v, z.ctypes.data, z.ctypes.data, 0.0, C.byref(r), J.ctypes.data) == ok
+    # cost gradient direction on a band-limited version of the frame (where central differences are a
+    # faithful derivative): J^T r must point along the finite-difference gradient of the cost
+    from scipy.ndimage import gaussian_filter
+    f8 = np.clip(np.rint(gaussian_filter(f, 2.5)), 0, 255).astype(np.uint8)
+    r_o, J_o = rows(p, idx, True)
+    g = J_o.T @ r_o
+    num = np.zeros(6)
+    for k in range(6):
+        d = np.zeros(6); d[k] = 1e-4 if k < 3 else 1e-5
+        num[k] = (0.5 * (rows(p + d, idx, True)[0] ** 2).sum() - 0.5 * (rows(p - d, idx, True)[0] ** 2).sum()) / (2 * d[k])
+    scale = np.array([1, 1, 1, 10, 10, 10.0])       # rvec / tvec entries live on different scales
+    cosang = (g / scale) @ (num / scale) / (np.linalg.norm(g / scale) * np.linalg.norm(num / scale))
+    assert cosang > 0.97
+
+
+def test_oracle_converges_to_known_pose(oracle, scene):
+    s, mx = scene
+    f = s.frame(1)
+    T = _template(s, mx, 1)
+    r0 = s.rvecs[1] + np.array([0.004, -0.003, 0.002]); t0 = s.tvecs[1] + np.array([0.0004, -0.0003, 0.001])
+    assert np.abs(syn.project(s.obj, r0, t0, s.K) - s.corners(1)).max() > 2.0            # starts > 2 px off
+    r, t, st = oracle.dense_refine(f, mx, T, None, None, None, s.K, None, r0, t0, iters=10, photo_weight=1.0)
+    assert st["valid"] > 0.95 * len(mx) and st["photo_rms"] < 0.05
+    assert np.abs(r - s.rvecs[1]).max() < 1e-6 and np.abs(t - s.tvecs[1]).max() < 1e-6
+    # template from the previous frame, joint with the corner term: lands near the true pose of frame 1
+    T0 = _template(s, mx, 0)
+    r, t, st = oracle.dense_refine(f, mx, T0, s.obj, s.corners(1), None, s.K, None, s.rvecs[0], s.tvecs[0], iters=10, photo_weight=0.01)
+    assert np.abs(r - s.rvecs[1]).max() < 5e-4 and np.abs(t - s.tvecs[1]).max() < 5e-5 and st["used"] == 48
+    # early stop fires
+    r2, t2, st2 = oracle.dense_refine(f, mx, T, None, None, None, s.K, None, s.rvecs[1], s.tvecs[1], iters=50, photo_weight=1.0)
+    assert st2["iters"] < 50
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("use_dist", [False, True])
+def test_hip_matches_oracle(oracle, scene, use_dist):
+    import torch
+    from accurate_aprilgroup_tracking_amd import cv_hip
+    s, mx = scene
+    dist = syn.MILD_DIST if use_dist else None
+    T = _template(s, mx, 1)
+    rng = np.random.default_rng(1)
+    B = 3
+    starts = [np.concatenate([s.rvecs[1] + rng.normal(0, 0.003, 3), s.tvecs[1] + rng.normal(0, 0.0005, 3)]) for _ in range(B)]
+    frames = torch.from_numpy(np.stack([s.frame(1)] * B)).cuda()
+    ipts = np.stack([s.corners(1) + rng.normal(0, 0.1, (48, 2)).astype(np.float32) for _ in range(B)])
+    mask = (rng.uniform(size=(B, 48)) > 0.2).astype(np.uint8)
+    ctx = cv_hip.Context(64, 64, max_level=0)
+    for (iters, pw, with_corners) in ((1, 1.0, False), (6, 1.0, False), (6, 0.01, True)):
+        pose = torch.from_numpy(np.stack(starts)).cuda().contiguous()
+        kw = dict(obj=torch.from_numpy(s.obj.astype(np.float32)).cuda(), img_pts=torch.from_numpy(ipts).cuda().contiguous(),
+                  mask=torch.from_numpy(mask).cuda().contiguous()) if with_corners else {}
+        pose, stats = ctx.dense_refine(frames, torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), pose, s.K, dist,
+                                       iters=iters, photo_weight=pw, **kw)
+        pose, stats = pose.cpu().numpy(), stats.cpu().numpy()
+        for b in range(B):
+            r, t, st = oracle.dense_refine(s.frame(1), mx, T, s.obj if with_corners else None, ipts[b] if with_corners else None,
+                                           mask[b] if with_corners else None, s.K, dist, starts[b][:3], starts[b][3:], iters=iters, photo_weight=pw)
+            assert np.abs(pose[b, :3] - r).max() < 1e-9 and np.abs(pose[b, 3:] - t).max() < 1e-9
+            assert int(stats[b, 2]) == st["valid"] and int(stats[b, 3]) == st["iters"] and int(stats[b, 4]) == st["used"]
+            assert abs(stats[b, 0] - st["photo_rms"]) < 1e-8 and abs(stats[b, 1] - st["geo_rms"]) < 1e-8
+
+
+@pytest.mark.gpu
+def test_config5_sizes_240_corners_61440_samples(oracle):
+    """BASELINE configs[4]: 60 tags / 240 corners + 60 x 32 x 32 dense samples on a 1280x720 frame"""
+    import torch
+    from accurate_aprilgroup_tracking_amd import cv_hip
+    s = syn.Sequence(1280, 720, n_tags=60, n_frames=2, seed=8, supersample=2, z0=0.62)
+    mx = syn.model_samples(s.group, 32)
+    assert mx.shape[0] == 61440 and s.obj.shape[0] == 240
+    T = np.nan_to_num(syn.sample_bilinear(s.frame(1), syn.project(mx, s.rvecs[1], s.tvecs[1], s.K)), nan=128.0).astype(np.float32)
+    start = np.concatenate([s.rvecs[1] + 0.002, s.tvecs[1] - 0.0006])
+    ctx = cv_hip.Context(64, 64, max_level=0)
+    pose = torch.from_numpy(start[None].copy()).cuda()
+    pose, stats = ctx.dense_refine(torch.from_numpy(s.frame(1)[None]).cuda(), torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), pose,
+                                   s.K, None, obj=torch.from_numpy(s.obj.astype(np.float32)).cuda(),
+                                   img_pts=torch.from_numpy(s.corners(1)[None]).cuda().contiguous(), iters=8, photo_weight=0.05)
+    pose = pose.cpu().numpy()[0]
+    r, t, st = oracle.dense_refine(s.frame(1), mx, T, s.obj, s.corners(1), None, s.K, None, start[:3], start[3:], iters=8, photo_weight=0.05)
+    assert np.abs(pose[:3] - r).max() < 1e-9 and np.abs(pose[3:] - t).max() < 1e-9
+    assert np.abs(pose[:3] - s.rvecs[1]).max() < 1e-4 and np.abs(pose[3:] - s.tvecs[1]).max() < 1e-4
+    assert stats.cpu().numpy()[0, 4] == 240
