@@ -10,7 +10,7 @@
 //       straight from the frame (u8, L2/HBM), 21 + 6 + 1 + 1 partial sums.  Each wave reduces
 //       through a transposed LDS slab (as the PnP kernel), the four waves through LDS again, and
 //       the block writes ONE row of 32 doubles: no atomics, bit-reproducible.
-//   dense_update_kernel one wave per stream: sums the block rows in index order, adds the corner
+//   dense_update_kernel one block per stream: sums the block rows (8 interleaved groups, fixed order), adds the corner
 //       (geometric) rows evaluated in place, solves the damped 6x6 system, updates the pose and
 //       raises a `done` word when the relative step falls under FLT_EPSILON (later launches of
 //       the same call then fall through).
@@ -118,11 +118,23 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     }
 }
 
-__global__ __launch_bounds__(AGT_WAVE) void dense_update_kernel(const DenseParams P)
+__global__ __launch_bounds__(256) void dense_update_kernel(const DenseParams P)
 {
     __shared__ agt_pnp::PnpShared sh;
-    const int b = blockIdx.x, lane = threadIdx.x;
+    __shared__ double s_rows[8][DROW];
+    const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (P.done[b]) return;
+    // photometric block rows: 8 interleaved groups of rows are summed concurrently (independent loads in
+    // flight), then combined in a fixed order -> reproducible, and short even for hundreds of rows
+    {
+        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+        const double* row = P.partials + (long)b * P.nblk * DROW + k;
+        double s = 0.0;
+        for (int j = g; j < P.nblk; j += 8) s += row[(long)j * DROW];
+        s_rows[g][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x >= AGT_WAVE) return;
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
     bool has_dist = false;
@@ -132,12 +144,10 @@ __global__ __launch_bounds__(AGT_WAVE) void dense_update_kernel(const DenseParam
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
 
-    // photometric block rows, summed in index order by lane k (coalesced: a row is 32 doubles)
     double ph = 0.0;
-    if (lane < DROW) {
-        const double* row = P.partials + (long)b * P.nblk * DROW + lane;
-        for (int j = 0; j < P.nblk; j++) ph += row[(long)j * DROW];
-    }
+    if (lane < DROW)
+        ph = ((s_rows[0][lane] + s_rows[1][lane]) + (s_rows[2][lane] + s_rows[3][lane])) +
+             ((s_rows[4][lane] + s_rows[5][lane]) + (s_rows[6][lane] + s_rows[7][lane]));
     // geometric rows
     double acc[agt_pnp::NACC];
 #pragma unroll
@@ -215,7 +225,7 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
         if (P.nblk > 0) hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk, B), dim3(256), sizeof(DenseShared), stream, P);
-        hipLaunchKernelGGL(dense_update_kernel, dim3(B), dim3(AGT_WAVE), 0, stream, P);
+        hipLaunchKernelGGL(dense_update_kernel, dim3(B), dim3(256), 0, stream, P);
         e = hipGetLastError();
     }
     return e;
