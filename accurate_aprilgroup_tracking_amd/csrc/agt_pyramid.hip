@@ -8,7 +8,17 @@ namespace {
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    agt_pyr::pyr_down_body(A, blockIdx.x, blockIdx.y, blockIdx.z, lds);
+    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
+    // workgroup b takes tile (b % 8) * per_xcd + b / 8 -- every XCD walks a CONTIGUOUS row-major run of
+    // tiles and the 128-B lines shared by neighbouring tiles (16-B side halos, 3 halo rows) hit in its L2
+    // instead of being fetched once per XCD.
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per_img = A.gx * A.gy;
+    if (t >= per_img * A.B) return;
+    const int bz = t / per_img, r = t - bz * per_img;
+    const int by = r / A.gx;
+    agt_pyr::pyr_down_body(A, r - by * A.gx, by, bz, lds);
 }
 
 }  // namespace
@@ -27,6 +37,7 @@ hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, i
     A.dst = dst; A.dw = (sw + 1) / 2; A.dh = (sh + 1) / 2; A.dpitch = dpitch; A.dbatch = dbatch;
     agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
     A.B = B;
-    hipLaunchKernelGGL(pyr_down_kernel, dim3(A.gx, A.gy, B), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
+    const long tiles = (long)A.gx * A.gy * B;
+    hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
     return hipGetLastError();
 }

@@ -9,6 +9,7 @@ W, H, B, SLOTS = 1280, 720, 64, 6
 ctx = cv_hip.Context(W, H, max_level=2, max_points=48, max_streams=B)
 src = torch.randint(0, 256, (SLOTS, B, H, W), dtype=torch.uint8, device="cuda")      # 354 MB
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+calib = src[0].clone()          # 58,982,400-byte streaming copy: calibrates FETCH_SIZE / WRITE_SIZE in the same pass
 for i in range(10):
     ctx.pyr_down(src[i % SLOTS])
 torch.cuda.synchronize()
