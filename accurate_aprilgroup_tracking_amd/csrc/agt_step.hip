@@ -12,6 +12,7 @@
 // Bodies: agt_pyramid_body.h, agt_lk_body.h, agt_pnp_body.h (shared with the stand-alone kernels).
 #undef AGT_LK_STAMPS
 #undef AGT_PNP_STAMPS
+#include <cstdlib>
 #include "agt_pyramid_body.h"
 #include "agt_lk_body.h"
 #include "agt_pnp_body.h"
@@ -24,19 +25,16 @@ template <int WIN, int NW, int NLEV>
 __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams S)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
+    // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
     int blk = blockIdx.x;
-#pragma unroll
-    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) {
-        if (blk < S.n_pyr[s]) {
-            const AgtPyrArgs& A = S.pyr[s];
-            const int per_img = A.gx * A.gy;
-            const int bz = blk / per_img, r = blk - bz * per_img;
-            const int by = r / A.gx, bx = r - by * A.gx;
-            agt_pyr::pyr_down_body(A, bx, by, bz, lds);
-            return;
-        }
-        blk -= S.n_pyr[s];
+    if (blk < S.n_pnp) {
+        if (threadIdx.x >= AGT_WAVE) return;
+        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
+        agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh);        // fused path: n <= 64 (agt_step_supported)
+        return;
     }
+    blk -= S.n_pnp;
     if (blk < S.n_lk) {
         // NW = 4: the workgroup is one corner; NW = 1: each wave is its own corner
         constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
@@ -49,10 +47,25 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
         return;
     }
     blk -= S.n_lk;
-    if (blk < S.n_pnp) {
-        if (threadIdx.x >= AGT_WAVE) return;
-        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh);        // fused path: n <= 64 (agt_step_supported)
+    int base = S.n_pnp + S.n_lk;              // workgroup index of the stage's first tile
+#pragma unroll
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) {
+        if (blk < S.n_pyr[s]) {
+            const AgtPyrArgs& A = S.pyr[s];
+            // XCD-aware tile order (see agt_pyramid.hip): workgroup index % 8 is the XCD; the stage's
+            // workgroups on XCD j take a contiguous run of tiles, runs laid out in XCD order.
+            const int n = S.n_pyr[s];
+            const int j = (blk + base) & 7;
+            int tile = (blk - ((j - base) & 7)) >> 3;
+            for (int q = 0; q < j; q++) tile += (n - ((q - base) & 7) + 7) >> 3;
+            const int per_img = A.gx * A.gy;
+            const int bz = tile / per_img, r = tile - bz * per_img;
+            const int by = r / A.gx, bx = r - by * A.gx;
+            agt_pyr::pyr_down_body(A, bx, by, bz, lds);
+            return;
+        }
+        blk -= S.n_pyr[s];
+        base += S.n_pyr[s];
     }
 }
 
@@ -82,7 +95,11 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S)
 }  // namespace
 
 bool agt_step_supported(int win) { return win == 21; }
-bool agt_step_fits(int n, int B) { return n <= AGT_WAVE && (long)n * B <= 128; }
+bool agt_step_fits(int n, int B)
+{
+    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 128L; }();   // tuning knob
+    return n <= AGT_WAVE && (long)n * B <= cap;
+}
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win)
 {

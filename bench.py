@@ -36,6 +36,26 @@ def algorithmic_bytes():
     return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + NPTS * LEVELS * 1600 + NPTS * 21}
 
 
+def pmc_traffic(kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json;
+    FETCH_SIZE / WRITE_SIZE are collected in their own runs, never inside this timed program)."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
+            return json.load(f)[kernel]["traffic_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
 def pingpong(i, nf):
     j = i % (2 * nf - 2)
     return j if j < nf else 2 * nf - 2 - j
@@ -150,7 +170,9 @@ def main():
             achieved = B * ab["frame"] / (step_us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: pyrDown x2 | LK | PnP of 4 consecutive frames)",
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": None, "avg_launch_us": round(step_us, 3), "bytes_per_launch": int(B * ab["frame"]),
+                    "traffic": pmc_traffic("step_kernel<21,4,3>") if B == 1 else None,
+                    "frac_of_measured_copy_6290GBs": round(achieved / 6290.0, 6),
+                    "avg_launch_us": round(step_us, 3), "bytes_per_launch": int(B * ab["frame"]),
                     "note": "latency-bound by construction: one 720p stream is a serial chain of ~10 LK and 4 LM iterations"}
         else:
             dom = int(np.argmax(stage_us))
@@ -225,9 +247,23 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
         if time.perf_counter() - t0 > 10.0 or n >= 4000:
             break
     dt = time.perf_counter() - t0
+    # same chain with OpenMP over rows / points on every host core (as OpenCV's parallel_for_), ~5 s
+    nthr = os.cpu_count() or 1
+    pyr2 = cvo.Pyramid(frames[0]); pts2 = seq.corners(0)
+    r2, t2 = seq.rvecs[0].copy(), seq.tvecs[0].copy()
+    n2 = 0; t1 = time.perf_counter()
+    while nthr > 1:
+        k = pingpong(n2 + 1, NF)
+        pyr2, pts2, _, _, _, r2, t2 = cvo.track_frame(pyr2, frames[k], pts2, seq.obj, seq.K, None, r2, t2, nthreads=nthr)
+        n2 += 1
+        if time.perf_counter() - t1 > 5.0 or n2 >= 4000:
+            break
+    dt2 = time.perf_counter() - t1
     cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
            "sample": "%d frames of the same 1280x720 stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores"
-                     % (n, dt, os.cpu_count())}
+                     % (n, dt, os.cpu_count()),
+           "cpu_model": cpu_model(),
+           "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr, "sample": "%d frames, %.1f s" % (n2, dt2)} if n2 else None}
     # -- parity: reference-validated state machine on the oracle backend over the first frames
     tmp = tempfile.mkdtemp()
     open(os.path.join(tmp, "april_group.json"), "w").write(json.dumps(seq.group))
