@@ -16,6 +16,7 @@
 //       the same call then fall through).
 // One Gauss-Newton iteration = two launches; a call enqueues 2 * iters launches and never
 // synchronises.  No MFMA: the contraction is 6x6.
+#undef AGT_PNP_STAMPS
 #include "agt_pnp_body.h"
 
 namespace {

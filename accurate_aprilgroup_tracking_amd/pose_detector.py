@@ -53,6 +53,22 @@ class PoseDetector(TransformHelper):
         self._prev_corners = None       # (N,2) float32, rows ordered as _prev_ids x 4
         self._prev_ids = None
 
+    @classmethod
+    def from_files(cls, logger, camera_params, enhance_ape=True, cv=None, detector=None, april_group=None):
+        """Build from the reference's on-disk files: `CameraParams.npz` (calibrate_camera.py:107-123) and,
+        optionally, an `april_group.json` somewhere else than DIRPATH/JSON_FILE (detect_pose.py:54-55).
+        `detector` may be a recorded-detections .npz (formats.ReplayDetector) to replay a session."""
+        import os
+        from . import formats
+        mtx, dist, _, _ = formats.load_camera_params(camera_params)
+        if isinstance(detector, (str, os.PathLike)):
+            detector = formats.ReplayDetector(detector)
+        if april_group is None:
+            return cls(logger, mtx, dist, enhance_ape, cv=cv, detector=detector)
+        folder, name = os.path.split(os.fspath(april_group))
+        sub = type(cls.__name__, (cls,), {"DIRPATH": folder or ".", "JSON_FILE": name})
+        return sub(logger, mtx, dist, enhance_ape, cv=cv, detector=detector)
+
     # ------------------------------------------------------------------ model (detect_pose.py:105-227)
     def get_extrinsics(self):
         filepath = Path(self.DIRPATH) / self.JSON_FILE

@@ -84,6 +84,18 @@ class StreamTracker:
                 "agt_estimate_pose")
         return state_out
 
+    def estimate_pose_from_detections(self, detections_per_stream, tag_ids, state_out=None):
+        """Detector-fed frame (detect_pose.py:389-437 -> :467-574): `detections_per_stream` holds, per stream,
+        the swatbotics-style detections of this frame; `tag_ids` is the tag order of the object points.
+        Builds the dense corner table + mask (formats.detections_to_corner_table) and runs the device
+        state machine."""
+        from . import formats
+        tabs = [formats.detections_to_corner_table(d, tag_ids) for d in detections_per_stream]
+        assert len(tabs) == self.B and tabs[0][0].shape[0] == self.n
+        corners = torch.from_numpy(np.stack([t[0] for t in tabs])).to(self.dev)
+        mask = torch.from_numpy(np.stack([t[1] for t in tabs])).to(self.dev)
+        return self.estimate_pose(corners, mask, state_out)
+
     def new_state_buffer(self, frames=1):
         shape = (frames, self.B, H.STATE_STRIDE) if frames > 1 else (self.B, H.STATE_STRIDE)
         return torch.zeros(shape, dtype=torch.float64, device=self.dev)

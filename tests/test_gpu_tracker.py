@@ -202,3 +202,43 @@ def test_track_frame_argument_and_state_errors(torch_cuda):
     trk.estimate_pose(torch.zeros((1, 48, 2), dtype=torch.float32, device="cuda"), m, so)
     st = so.cpu().numpy()
     assert st[0, H.ST_OK] == 0 and int(st[0, H.ST_FLAGS]) & H.PNP_TOO_FEW and st[0, H.ST_NTRACK] == 4
+
+
+def test_detector_fed_device_state_machine(tmp_path, oracle):
+    """swatbotics-style detections (decision margin filter, missing tags, a frame with
+    fewer than two tags) -> dense corner table + mask -> device _estimate_pose, against the PoseDetector
+    mirror replaying the same recording on the oracle backend."""
+    from oracle import cv2_shim
+    from accurate_aprilgroup_tracking_amd import formats, hiplib as HL, synthetic as syn
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    seq = syn.Sequence(640, 480, n_tags=12, n_frames=8, seed=5)
+    tag_ids = [int(t) for t in seq.group["tags"].keys()]
+    frames = []
+    for k in range(8):
+        c = seq.corners(k).reshape(-1, 4, 2)
+        dets = [formats.make_detection(t, c[i], decision_margin=20.0 if i == (k + 3) % 12 else 75.0)
+                for i, t in enumerate(tag_ids) if i != k % 12]
+        frames.append(dets[:1] if k == 4 else dets)
+    rec = tmp_path / "det.npz"
+    formats.save_detections(rec, frames)
+    (tmp_path / "april_group.json").write_text(json.dumps(seq.group))
+    formats.save_camera_params(tmp_path / "CameraParams.npz", seq.K, np.zeros(5))
+    log = logging.getLogger("t"); log.setLevel(logging.CRITICAL)
+    det = PoseDetector.from_files(log, tmp_path / "CameraParams.npz", True, cv=cv2_shim.make_cv2(), detector=rec,
+                                  april_group=tmp_path / "april_group.json")
+    trk = StreamTracker(640, 480, det.all_objpts, seq.K, None, n_streams=1, enhance_ape=True)
+    trk.reset()
+    out = trk.new_state_buffer()
+    replay = formats.ReplayDetector(rec)
+    for k in range(8):
+        il, ol, ids = det._obtain_detections(None)
+        det._estimate_pose(il, ol)
+        trk.estimate_pose_from_detections([replay()], tag_ids, out)
+        st = out.cpu().numpy()[0]
+        if k == 4:
+            assert st[HL.ST_OK] == 0
+            continue
+        assert st[HL.ST_OK] == 1 and st[HL.ST_NTRACK] == 4 * len(ids)
+        assert np.abs(st[:3] - det.last_pose[0].ravel()).max() < 1e-8
+        assert np.abs(st[3:6] - det.last_pose[1].ravel().astype(np.float64)).max() < 1e-8
