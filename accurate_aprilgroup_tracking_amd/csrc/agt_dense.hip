@@ -19,6 +19,8 @@
 #undef AGT_PNP_STAMPS
 #include "agt_pnp_body.h"
 
+#pragma clang fp contract(fast)      // FP64 pose code only, see agt_device.h
+
 namespace {
 
 constexpr int DN = 29;                 // 21 (upper JtJ) + 6 (Jt r) + r^2 + valid count

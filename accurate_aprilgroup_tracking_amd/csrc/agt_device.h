@@ -67,6 +67,12 @@ __device__ __forceinline__ float agt_uniform(float v)
 
 // ---------------------------------------------------------------------------
 // FP64 geometry (OpenCV calibration.cpp semantics; see oracle/cv_pnp.c for the restatement)
+//
+// The library is compiled with -ffp-contract=off because the LK float expressions must round exactly
+// as OpenCV's do.  The FP64 pose code has no such requirement (parity bar 1e-9 on the pose, far above
+// FP64 round-off), and it is a serial dependency chain: contracting a*b+c into one v_fma_f64 halves the
+// length of most of its links.  Contraction is therefore switched on for this section only.
+#pragma clang fp contract(fast)
 
 // cvRodrigues2 vector->matrix.  J (3x9, J[i*9+k] = dR[k]/dr[i]) only when JAC.
 template <bool JAC>
@@ -376,3 +382,5 @@ __device__ __forceinline__ bool agt_solve6(const double A[36], const double b[6]
     }
     return ok;
 }
+
+#pragma clang fp contract(off)

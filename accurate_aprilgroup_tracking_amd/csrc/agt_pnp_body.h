@@ -32,6 +32,8 @@ extern "C" int agt_debug_pnp_stamps(unsigned long long* host64)
 #define PSTAMP(i)
 #endif
 
+#pragma clang fp contract(fast)      // FP64 pose code only, see agt_device.h
+
 namespace agt_pnp {
 
 constexpr int NACC = 28;            // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
@@ -747,3 +749,5 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 }
 
 }  // namespace agt_pnp
+
+#pragma clang fp contract(off)
