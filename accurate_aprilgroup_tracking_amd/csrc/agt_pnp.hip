@@ -26,17 +26,17 @@ __global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
     for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
     const T* obj = reinterpret_cast<const T*>(P.obj) + (long)b * P.obj_bstride;
     T* out = reinterpret_cast<T*>(P.img_out) + (long)b * P.n * 2;
-    double R[9], dRdr[27], u, v, jr[6], jt[6];
+    double R[9], G[9], u, v, jr[6], jt[6];
     const double X = (double)obj[i * 3], Y = (double)obj[i * 3 + 1], Z = (double)obj[i * 3 + 2];
     if (P.jac) {
-        agt_rodrigues<true>(param, R, dRdr);
-        agt_project<true>(cam, R, dRdr, param + 3, X, Y, Z, u, v, jr, jt);
+        agt_rodrigues<true>(param, R, G);
+        agt_project<true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
         double* J = P.jac + ((long)b * P.n + i) * 12;
 #pragma unroll
         for (int k = 0; k < 3; k++) { J[k] = jr[k]; J[3 + k] = jt[k]; J[6 + k] = jr[3 + k]; J[9 + k] = jt[3 + k]; }
     } else {
-        agt_rodrigues<false>(param, R, dRdr);
-        agt_project<false>(cam, R, dRdr, param + 3, X, Y, Z, u, v, nullptr, nullptr);
+        agt_rodrigues<false>(param, R, G);
+        agt_project<false>(cam, R, G, param + 3, X, Y, Z, u, v, nullptr, nullptr);
     }
     out[i * 2] = (T)u; out[i * 2 + 1] = (T)v;
 }

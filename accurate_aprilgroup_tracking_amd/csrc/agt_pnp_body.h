@@ -549,8 +549,8 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     auto evaluate_t = [&](int mode, auto DIST) -> double {
         constexpr bool D = decltype(DIST)::value;
         const bool needJ = mode != 0;
-        double R[9], dRdr[27];
-        if (needJ) agt_rodrigues<true>(param, R, dRdr); else agt_rodrigues<false>(param, R, dRdr);
+        double R[9], G[9];
+        if (needJ) agt_rodrigues<true>(param, R, G); else agt_rodrigues<false>(param, R, G);
 #pragma unroll
         for (int i = 0; i < 9; i++) Rlast[i] = R[i];
         if (needJ) {
@@ -560,7 +560,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 #pragma unroll
             for (int q = 0; q < PPL; q++) if (use[q]) {
                 double u, v, jr[6], jt[6];
-                agt_project<true, D>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, jr, jt);
+                agt_project<true, D>(cam, R, G, param + 3, X[q], Y[q], Z[q], u, v, jr, jt);
                 const double ex = u - mu_[q], ey = v - mv_[q];
                 rex[q] = ex; rey[q] = ey;
                 const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
@@ -589,7 +589,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 #pragma unroll
         for (int q = 0; q < PPL; q++) if (use[q]) {
             double u, v;
-            agt_project<false, D>(cam, R, dRdr, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
+            agt_project<false, D>(cam, R, G, param + 3, X[q], Y[q], Z[q], u, v, nullptr, nullptr);
             const double ex = u - mu_[q], ey = v - mv_[q];
             rex[q] = ex; rey[q] = ey;
             e2 += ex * ex + ey * ey;
@@ -725,12 +725,12 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         }
         if (accepted && P.reproject && P.corners_rw) {
             // refresh the whole corner set with projectPoints(all_objpts) (detect_pose.py:455-461)
-            double R[9], dRdr[27];
-            agt_rodrigues<false>(param, R, dRdr);
+            double R[9], G[9];
+            agt_rodrigues<false>(param, R, G);
             float* cw = P.corners_rw + (long)b * n * 2;
             for (int i = lane; i < n; i += AGT_WAVE) {
                 double u, v;
-                agt_project<false>(cam, R, dRdr, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2],
+                agt_project<false>(cam, R, G, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2],
                                    u, v, nullptr, nullptr);
                 cw[i * 2] = (float)u; cw[i * 2 + 1] = (float)v;
             }

@@ -74,6 +74,8 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S)
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
+    { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();   // EXPERIMENT
+      if (skip & 1) P.n_pnp = 0; if (skip & 2) P.n_lk = 0; if (skip & 4) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.n_pyr[s] = 0; } }
     size_t lds = 0;
     int blocks = 0;
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) if (P.n_pyr[s] > 0) { blocks += P.n_pyr[s]; lds = lds > (size_t)agt_pyr::PYR_LDS_BYTES ? lds : (size_t)agt_pyr::PYR_LDS_BYTES; }
