@@ -73,6 +73,63 @@ __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& s
     }
 }
 
+// ---- register butterfly: 32 per-lane partials -> 32 wave totals without LDS traffic
+// Recursive halving over the six lane bits.  Stages over bits 5 and 4 use gfx950's v_permlane32_swap /
+// v_permlane16_swap (the swap leaves "my half" and "the partner's half" side by side: two swaps and one add
+// per value, no selects); stages over bits 3..1 pair lanes through DPP row_mirror / row_half_mirror /
+// quad_perm[3,2,1,0] (each pairs lanes that differ in the stage's bit and agree on the higher ones); the last
+// stage adds the xor-1 neighbour.  Afterwards lane l holds the total of value l >> 1.
+// ~125 VALU instructions in 6 short dependent stages, against 28 LDS stores + 32 dependent LDS load/adds.
+__device__ __forceinline__ double dswap32(double a, double b, double& b_out)
+{
+    const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    b_out = __hiloint2double((int)hi[1], (int)lo[1]);
+    return __hiloint2double((int)hi[0], (int)lo[0]);
+}
+__device__ __forceinline__ double dswap16(double a, double b, double& b_out)
+{
+    const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+    const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+    b_out = __hiloint2double((int)hi[1], (int)lo[1]);
+    return __hiloint2double((int)hi[0], (int)lo[0]);
+}
+template <int CTRL>
+__device__ __forceinline__ double ddpp(double v)
+{
+    return __hiloint2double(agt_dpp_i32<CTRL>(__double2hiint(v)), agt_dpp_i32<CTRL>(__double2loint(v)));
+}
+template <int CTRL, int N>
+__device__ __forceinline__ void bfly_stage(double (&v)[32], bool upper)
+{
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        const double a = v[i], b = v[i + N];
+        const double keep = upper ? b : a, send = upper ? a : b;
+        v[i] = keep + ddpp<CTRL>(send);
+    }
+}
+// vals[K] (K <= 32) summed over the wave; totals to sh.tot[0..K).  Ends with a barrier.
+template <int K>
+__device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpShared& sh, int lane)
+{
+    static_assert(K <= 32, "one pass handles at most 32 sums");
+    double v[32];
+#pragma unroll
+    for (int i = 0; i < 32; i++) v[i] = i < K ? vals[i] : 0.0;
+#pragma unroll
+    for (int i = 0; i < 16; i++) { double b; const double a = dswap32(v[i], v[i + 16], b); v[i] = a + b; }
+#pragma unroll
+    for (int i = 0; i < 8; i++) { double b; const double a = dswap16(v[i], v[i + 8], b); v[i] = a + b; }
+    bfly_stage<0x140, 4>(v, (lane & 8) != 0);      // row_mirror        l <-> l ^ 15
+    bfly_stage<0x141, 2>(v, (lane & 4) != 0);      // row_half_mirror   l <-> l ^ 7
+    bfly_stage<0x1B, 1>(v, (lane & 2) != 0);       // quad_perm [3,2,1,0]  l <-> l ^ 3
+    const double tot = v[0] + ddpp<0xB1>(v[0]);    // quad_perm [1,0,3,2]  l <-> l ^ 1
+    __syncthreads();                               // earlier readers of sh.tot are done
+    if (!(lane & 1) && (lane >> 1) < K) sh.tot[lane >> 1] = tot;
+    __syncthreads();
+}
+
 __device__ __forceinline__ double wave_sum_f64(double v)
 {
 #pragma unroll
@@ -550,9 +607,11 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         constexpr bool D = decltype(DIST)::value;
         const bool needJ = mode != 0;
         double R[9], G[9];
+        if (mode == 2) PSTAMP(48);
         if (needJ) agt_rodrigues<true>(param, R, G); else agt_rodrigues<false>(param, R, G);
 #pragma unroll
         for (int i = 0; i < 9; i++) Rlast[i] = R[i];
+        if (mode == 2) PSTAMP(49);
         if (needJ) {
             double acc[NACC];
 #pragma unroll
@@ -574,16 +633,17 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 }
                 acc[27] += ex * ex + ey * ey;
             }
+            if (mode == 2) PSTAMP(50);
+            wave_reduce_bfly<NACC>(acc, sh, lane);
             if (mode == 2) {
-                wave_reduce_slab<NACC, false>(acc, sh, lane);
+                PSTAMP(51);
                 return sh.tot[27];
             }
-            wave_reduce_slab<NACC>(acc, sh, lane);
 #pragma unroll
-            for (int i = 0; i < 21; i++) JtJ[i] = acc[i];
+            for (int i = 0; i < 21; i++) JtJ[i] = sh.tot[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++) JtErr[i] = acc[21 + i];
-            return acc[27];
+            for (int i = 0; i < 6; i++) JtErr[i] = sh.tot[21 + i];
+            return sh.tot[27];
         }
         double e2 = 0.0;
 #pragma unroll

@@ -24,3 +24,5 @@ for k in range(10):
     for i in range(it):
         b = 8 + i * 4
         print("    iter %d: solve %.2f  err-eval %.2f  J-eval %.2f" % (i, f(b + 1) - f(b), f(b + 2) - f(b + 1), (f(b + 3) - f(b + 2)) if i < it - 1 else 0.0))
+    print("    last mode-2 evaluation: rodrigues %.2f | per-point projection + products %.2f | 28-sum reduction %.2f us" % (
+        (st[49] - st[48]) / 2387.0, (st[50] - st[49]) / 2387.0, (st[51] - st[50]) / 2387.0))
