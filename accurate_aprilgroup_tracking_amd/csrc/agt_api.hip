@@ -7,7 +7,8 @@
 #include <math.h>
 #include <float.h>
 
-#define AGT_SLOTS 4
+#define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
+#define AGT_RING_MAX 64          // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
 
 struct agt_ctx {
     agt_config cfg;
@@ -16,16 +17,19 @@ struct agt_ctx {
     int eff_max_level;                       // after OpenCV's early stop
     int lw[AGT_MAX_LEVELS], lh[AGT_MAX_LEVELS];
     long lpitch[AGT_MAX_LEVELS];             // levels >= 1 (context-owned)
-    uint8_t* lmem[AGT_SLOTS][AGT_MAX_LEVELS];
-    const uint8_t* l0_ptr[AGT_SLOTS];
-    long l0_pitch[AGT_SLOTS], l0_bstride[AGT_SLOTS];
-    int built_B[AGT_SLOTS];
-    // tracker: rings of 4 (frame t lives in entry t % 4) so that one fused launch can work on
-    // pyramid stage s of frame t-s, LK of frame t-(L-1) and PnP of frame t-L at once
-    float* corners[AGT_SLOTS];               // [B][n][2]
-    uint8_t* status[AGT_SLOTS];              // [B][n]
-    double* so_ring[AGT_SLOTS];              // caller's state_out of the frames in flight
+    uint8_t* lmem[AGT_RING_MAX][AGT_MAX_LEVELS];
+    const uint8_t* l0_ptr[AGT_RING_MAX];
+    long l0_pitch[AGT_RING_MAX], l0_bstride[AGT_RING_MAX];
+    int built_B[AGT_RING_MAX];
+    // tracker: rings (frame t lives in entry t % ring) so that one fused launch can work on pyramid
+    // stage s of frames t-sF.., LK of frames t-LF.. and PnP of frames t-(L+1)F.. at once (F = group)
+    int ring;                                // allocated ring entries: >= (L + 2) * group
+    float* corners[AGT_RING_MAX];            // [B][n][2]
+    uint8_t* status[AGT_RING_MAX];           // [B][n]
+    double* so_ring[AGT_RING_MAX];           // caller's state_out of the frames in flight
     int pipeline;                            // 1 = software-pipelined fused step (agt_step.hip)
+    int group;                               // frames per fused launch (1..AGT_MAX_GROUP)
+    int live_ring;                           // ring modulus in use (<= ring): (L + 2) * group, at least AGT_SLOTS
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
@@ -67,6 +71,24 @@ int fill_camera(const double* K, const double* dist, int ndist, AgtCameraHost* c
     if (ndist > 0 && !dist) return AGT_ERR_ARG;
     cam->fx = K[0]; cam->fy = K[4]; cam->cx = K[2]; cam->cy = K[5];
     for (int i = 0; i < 12; i++) cam->k[i] = i < ndist ? dist[i] : 0.0;
+    return AGT_OK;
+}
+
+// grow the rings to `want` entries (pyramid levels >= 1, corners, status)
+int ensure_ring(agt_ctx* c, int want)
+{
+    if (want > AGT_RING_MAX) return AGT_ERR_UNSUPPORTED;
+    const size_t B = (size_t)c->cfg.max_streams, N = (size_t)c->cfg.max_points;
+    for (int s = c->ring; s < want; s++) {
+        bool ok = true;
+        for (int l = 1; l <= c->eff_max_level && ok; l++)
+            ok = hipMalloc((void**)&c->lmem[s][l], B * (size_t)c->lh[l] * (size_t)c->lpitch[l]) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->corners[s], B * N * 2 * sizeof(float)) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->status[s], B * N) == hipSuccess;
+        ok = ok && hipMemsetAsync(c->status[s], 1, B * N, c->stream) == hipSuccess;
+        if (!ok) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }      // partial entry is freed by agt_destroy
+        c->ring = s + 1;
+    }
     return AGT_OK;
 }
 
@@ -117,13 +139,10 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
         if (w <= cfg->win || h <= cfg->win) break;
     }
     const size_t B = (size_t)cfg->max_streams, N = (size_t)cfg->max_points;
-    bool ok = true;
-    for (int s = 0; s < AGT_SLOTS && ok; s++) {
-        for (int l = 1; l <= c->eff_max_level && ok; l++)
-            ok = hipMalloc((void**)&c->lmem[s][l], B * (size_t)c->lh[l] * (size_t)c->lpitch[l]) == hipSuccess;
-        ok = ok && hipMalloc((void**)&c->corners[s], B * N * 2 * sizeof(float)) == hipSuccess;
-        ok = ok && hipMalloc((void**)&c->status[s], B * N) == hipSuccess;
-    }
+    c->group = 1;
+    const int ring0 = c->eff_max_level + 2 > AGT_SLOTS ? c->eff_max_level + 2 : AGT_SLOTS;
+    bool ok = ensure_ring(c, ring0) == AGT_OK;
+    c->live_ring = ring0;
     ok = ok && hipMalloc((void**)&c->lkerr, B * N * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->obj, N * 3 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
@@ -140,7 +159,7 @@ int agt_destroy(agt_ctx* c)
 {
     if (!c) return AGT_OK;
     (void)hipStreamSynchronize(c->stream);
-    for (int s = 0; s < AGT_SLOTS; s++) {
+    for (int s = 0; s < AGT_RING_MAX; s++) {
         for (int l = 1; l < AGT_MAX_LEVELS; l++) if (c->lmem[s][l]) (void)hipFree(c->lmem[s][l]);
         if (c->corners[s]) (void)hipFree(c->corners[s]);
         if (c->status[s]) (void)hipFree(c->status[s]);
@@ -191,7 +210,7 @@ int agt_pyr_down_u8(agt_ctx* c, const uint8_t* d_src, int sw, int sh, size_t spi
 
 static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
 {
-    if (!c || !d_frames || slot < 0 || slot >= AGT_SLOTS || B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
+    if (!c || !d_frames || slot < 0 || slot >= c->ring || B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
     if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
@@ -216,7 +235,7 @@ int agt_pyramid_max_level(const agt_ctx* c) { return c ? c->eff_max_level : AGT_
 int agt_pyramid_level(const agt_ctx* c, int slot, int level, const uint8_t** d_ptr,
                       int* w, int* h, size_t* pitch, size_t* batch_stride)
 {
-    if (!c || slot < 0 || slot >= AGT_SLOTS || level < 0 || level > c->eff_max_level) return AGT_ERR_ARG;
+    if (!c || slot < 0 || slot >= c->ring || level < 0 || level > c->eff_max_level) return AGT_ERR_ARG;
     if (c->built_B[slot] <= 0) return AGT_ERR_STATE;
     if (d_ptr) *d_ptr = level == 0 ? c->l0_ptr[slot] : c->lmem[slot][level];
     if (w) *w = c->lw[level];
@@ -241,7 +260,7 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
                        int flags, double min_eig_threshold)
 {
     if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
-    if (prev_slot < 0 || prev_slot >= AGT_SLOTS || next_slot < 0 || next_slot >= AGT_SLOTS) return AGT_ERR_ARG;
+    if (prev_slot < 0 || prev_slot >= c->ring || next_slot < 0 || next_slot >= c->ring) return AGT_ERR_ARG;
     if (n < 0 || B <= 0) return AGT_ERR_ARG;
     if (n == 0) return AGT_OK;
     if (c->built_B[prev_slot] < B || c->built_B[next_slot] < B) return AGT_ERR_STATE;
@@ -327,7 +346,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (d_corners) e = hipMemcpyAsync(c->corners[0], d_corners, (size_t)B * n * 2 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
-    for (int s = 0; s < AGT_SLOTS && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
+    for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
     if (e != hipSuccess) return hip_fail(c, e);
     c->trk_n = n; c->trk_B = B; c->trk_frame = 0; c->n_lk = c->n_pnp = 0; c->enhance_ape = enhance_ape ? 1 : 0;
     for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = 0;
@@ -344,13 +363,38 @@ int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_p
     return AGT_OK;
 }
 
-int agt_tracker_pipeline(agt_ctx* c, int enable)
+// move frame `f`'s ring entry when the ring size changes (only the newest frame is live after a join)
+static void ring_move(agt_ctx* c, long f, int old_ring, int new_ring)
 {
-    if (!c) return AGT_ERR_ARG;
-    if (enable && !agt_step_supported(c->cfg.win)) return AGT_ERR_UNSUPPORTED;
+    const int a = (int)(f % old_ring), b = (int)(f % new_ring);
+    if (a == b) return;
+    for (int l = 1; l < AGT_MAX_LEVELS; l++) { uint8_t* t = c->lmem[a][l]; c->lmem[a][l] = c->lmem[b][l]; c->lmem[b][l] = t; }
+    { float* t = c->corners[a]; c->corners[a] = c->corners[b]; c->corners[b] = t; }
+    { uint8_t* t = c->status[a]; c->status[a] = c->status[b]; c->status[b] = t; }
+    c->l0_ptr[b] = c->l0_ptr[a]; c->l0_pitch[b] = c->l0_pitch[a]; c->l0_bstride[b] = c->l0_bstride[a];
+    c->built_B[b] = c->built_B[a]; c->built_B[a] = 0;
+}
+
+// depth 0: separate launches per stage, pose complete in stream order.  depth F >= 1: fused software-pipelined
+// step that advances every stage by F frames per launch (one launch every F calls of agt_track_frame).
+int agt_tracker_pipeline(agt_ctx* c, int depth)
+{
+    if (!c || depth < 0 || depth > AGT_MAX_GROUP) return AGT_ERR_ARG;
+    if (depth && !agt_step_supported(c->cfg.win)) return AGT_ERR_UNSUPPORTED;
     int rc = agt_tracker_join(c);
     if (rc) return rc;
-    c->pipeline = enable ? 1 : 0;
+    c->pipeline = depth ? 1 : 0;
+    const int group = depth ? depth : 1;
+    if (group != c->group) {
+        // every frame <= trk_frame is complete; re-seat the newest one in a ring that fits the new depth
+        const int want = (c->eff_max_level + 2) * group > AGT_SLOTS ? (c->eff_max_level + 2) * group : AGT_SLOTS;
+        const int live_ring = c->live_ring;
+        rc = ensure_ring(c, want);
+        if (rc) return rc;
+        if (c->trk_ready == 2) ring_move(c, c->trk_frame, live_ring, want);
+        c->live_ring = want;
+        c->group = group;
+    }
     return AGT_OK;
 }
 
@@ -383,64 +427,102 @@ static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slo
     return AGT_OK;
 }
 
-// One fused launch: every pipeline stage advances by one frame if its input is complete.
-// d_frames != NULL supplies frame T+1 (its L0->L1 stage runs in this launch).
-static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+// One fused launch: every pipeline stage advances by up to `group` frames whose input is complete.
+static int launch_group(agt_ctx* c, int B)
 {
     const int L = c->eff_max_level;              // pyramid stages 0..L-1 (stage s: level s -> s+1)
+    const int F = c->group, M = c->live_ring;
     AgtStepParams S;
+    AgtStepTables T;
     memset(&S, 0, sizeof(S));
+    memset(&T, 0, sizeof(T));
     long done_before[AGT_MAX_LEVELS + 1];        // [s] = frames available as input of stage s (s = L: input of LK)
     done_before[0] = c->trk_frame;
     for (int s = 0; s < L; s++) done_before[s + 1] = c->n_stage[s];
     const long lk_before = c->n_lk;
     bool any = false;
-    if (d_frames) {
-        const long t = c->trk_frame + 1;
-        const int slot = (int)(t % AGT_SLOTS);
-        c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
-        c->built_B[slot] = B;
-        c->so_ring[slot] = d_state_out;
-        c->trk_frame = t;
-        done_before[0] = t;                      // the new frame is stage 0's input in this very launch
-        any = true;
-    }
     for (int s = 0; s < L; s++) {
-        if (c->n_stage[s] >= done_before[s]) continue;
-        const long f = c->n_stage[s] + 1;
-        const int slot = (int)(f % AGT_SLOTS);
+        long cnt = done_before[s] - c->n_stage[s];
+        if (cnt <= 0) continue;
+        if (cnt > F) cnt = F;
         AgtPyrArgs& A = S.pyr[s];
-        if (s == 0) { A.src = c->l0_ptr[slot]; A.spitch = c->l0_pitch[slot]; A.sbatch = c->l0_bstride[slot]; }
-        else { A.src = c->lmem[slot][s]; A.spitch = c->lpitch[s]; A.sbatch = (long)c->lh[s] * c->lpitch[s]; }
         A.sw = c->lw[s]; A.sh = c->lh[s];
-        A.dst = c->lmem[slot][s + 1]; A.dw = c->lw[s + 1]; A.dh = c->lh[s + 1];
+        A.dw = c->lw[s + 1]; A.dh = c->lh[s + 1];
         A.dpitch = c->lpitch[s + 1]; A.dbatch = (long)c->lh[s + 1] * c->lpitch[s + 1];
         agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
         A.B = B;
-        S.n_pyr[s] = A.gx * A.gy * B;
-        c->n_stage[s] = f;
+        for (long k = 0; k < cnt; k++) {
+            const int slot = (int)((c->n_stage[s] + 1 + k) % M);
+            if (s == 0) {
+                // level 0 is the caller's frame: the frames of a group must share pitch and stream stride
+                if (k == 0) { A.spitch = c->l0_pitch[slot]; A.sbatch = c->l0_bstride[slot]; }
+                else if (A.spitch != c->l0_pitch[slot] || A.sbatch != c->l0_bstride[slot]) { cnt = k; break; }
+                T.pyr_src[s][k] = c->l0_ptr[slot];
+            } else {
+                A.spitch = c->lpitch[s]; A.sbatch = (long)c->lh[s] * c->lpitch[s];
+                T.pyr_src[s][k] = c->lmem[slot][s];
+            }
+            T.pyr_dst[s][k] = c->lmem[slot][s + 1];
+        }
+        A.src = T.pyr_src[s][0]; A.dst = T.pyr_dst[s][0];
+        S.pyr_nf[s] = (int)cnt;
+        S.n_pyr[s] = A.gx * A.gy * B * (int)cnt;
+        c->n_stage[s] += cnt;
         any = true;
     }
     if (c->n_lk < done_before[L]) {
-        const long f = c->n_lk + 1;
-        const int slot = (int)(f % AGT_SLOTS), pslot = (int)((f - 1) % AGT_SLOTS);
+        long cnt = done_before[L] - c->n_lk;
+        if (cnt > F) cnt = F;
+        const long f0 = c->n_lk;                 // the frame before the group
+        // level 0 geometry comes from the frame's own registration; a group needs it uniform
+        for (long k = 1; k <= cnt; k++) {
+            const int a = (int)(f0 % M), q = (int)((f0 + k) % M);
+            if (c->l0_pitch[q] != c->l0_pitch[a] || c->l0_bstride[q] != c->l0_bstride[a]) { cnt = k > 1 ? k - 1 : 1; break; }
+        }
+        const int pslot = (int)(f0 % M), slot = (int)((f0 + 1) % M);
         fill_lk(c, &S.lk, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr, c->trk_n,
                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+        S.lk_nf = (int)cnt;
+        for (long k = 0; k <= cnt; k++) {
+            const int q = (int)((f0 + k) % M);
+            for (int l = 0; l <= L; l++) T.lk.img[k][l] = l == 0 ? c->l0_ptr[q] : c->lmem[q][l];
+            if (k) { T.lk.next[k - 1] = c->corners[q]; T.lk.status[k - 1] = c->status[q]; }
+        }
         S.n_lk = 1; S.lk_B = B;
-        c->n_lk = f;
+        c->n_lk += cnt;
         any = true;
     }
     if (c->n_pnp < lk_before) {
-        const long f = c->n_pnp + 1;
-        const int slot = (int)(f % AGT_SLOTS);
+        long cnt = lk_before - c->n_pnp;
+        if (cnt > F) cnt = F;
+        const int slot = (int)((c->n_pnp + 1) % M);
         fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
+        for (long k = 0; k < cnt; k++) {
+            const int q = (int)((c->n_pnp + 1 + k) % M);
+            T.pnp.img[k] = c->corners[q]; T.pnp.mask[k] = c->status[q]; T.pnp.so[k] = c->so_ring[q];
+        }
+        S.pnp_nf = (int)cnt;
         S.n_pnp = B;
-        c->n_pnp = f;
+        c->n_pnp += cnt;
         any = true;
     }
     if (!any) return AGT_OK;
-    hipError_t e = agt_launch_step(c->stream, S, c->cfg.win);
+    hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
+static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+{
+    const long t = c->trk_frame + 1;
+    const int slot = (int)(t % c->live_ring);
+    c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
+    c->built_B[slot] = B;
+    c->so_ring[slot] = d_state_out;
+    c->trk_frame = t;
+    const long first_done = c->eff_max_level > 0 ? c->n_stage[0] : c->n_lk;
+    if (t - first_done < c->group) return AGT_OK;
+    return launch_group(c, B);
 }
 
 // Drain the software pipeline: enqueue the remaining stages of every frame supplied so far.
@@ -450,7 +532,7 @@ int agt_tracker_join(agt_ctx* c)
     if (!c) return AGT_ERR_ARG;
     if (c->trk_ready != 2) return AGT_OK;
     while (c->n_pnp < c->trk_frame) {
-        int rc = step_pipelined(c, nullptr, 0, 0, c->trk_B, nullptr);
+        int rc = launch_group(c, c->trk_B);
         if (rc) return rc;
     }
     return AGT_OK;
@@ -494,7 +576,7 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first
     if (rc) return rc;
     const long t = c->trk_frame + 1;
-    const int slot = (int)(t % AGT_SLOTS), pslot = (int)((t - 1) % AGT_SLOTS);
+    const int slot = (int)(t % c->live_ring), pslot = (int)((t - 1) % c->live_ring);
     hipStream_t M = c->stream;
     if (pev) (void)hipEventRecord(pev[0], M);
     rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
@@ -530,8 +612,8 @@ int agt_tracker_state_read(agt_ctx* c, void* host_dst, int B)
 int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t** d_status)
 {
     if (!c || !c->trk_ready) return AGT_ERR_STATE;
-    if (d_corners) *d_corners = c->corners[c->trk_frame % AGT_SLOTS];
-    if (d_status) *d_status = c->status[c->trk_frame % AGT_SLOTS];
+    if (d_corners) *d_corners = c->corners[c->trk_frame % c->live_ring];
+    if (d_status) *d_status = c->status[c->trk_frame % c->live_ring];
     return AGT_OK;
 }
 

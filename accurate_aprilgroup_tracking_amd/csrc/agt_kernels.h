@@ -19,6 +19,8 @@ struct AgtPyrArgs {
     int pad;
 };
 
+#define AGT_MAX_GROUP 8          // frames one fused launch may advance each pipeline stage by
+
 struct AgtLkParams {
     AgtLevel prev[AGT_MAX_LEVELS];
     AgtLevel next[AGT_MAX_LEVELS];
@@ -78,15 +80,39 @@ struct AgtTrackState {
     int pad[2];
 };
 
-// one fused per-frame launch (agt_step.hip): block ranges [pyr stage 0 | stage 1 | .. | LK | PnP]
+// one fused launch (agt_step.hip): block ranges [PnP | LK | pyr stage 0 | stage 1 | ..]; every role advances
+// by up to AGT_MAX_GROUP consecutive frames (the LK and PnP roles loop over them inside the launch: their
+// chains are serial across frames; the pyramid stages treat the frames as a batch)
 struct AgtStepParams {
-    AgtPyrArgs pyr[AGT_MAX_LEVELS - 1];
-    int n_pyr[AGT_MAX_LEVELS - 1];    // blocks of each pyramid stage (0 = stage idle this step)
-    AgtLkParams lk;
+    AgtPyrArgs pyr[AGT_MAX_LEVELS - 1];                        // geometry; src / dst per frame in AgtStepTables
+    int pyr_nf[AGT_MAX_LEVELS - 1];
+    int n_pyr[AGT_MAX_LEVELS - 1];    // blocks of each pyramid stage = tiles x streams x frames (0 = stage idle)
+    AgtLkParams lk;                   // geometry of prev[] / next[], criteria; images per frame in AgtStepTables
+    int lk_nf;
     int n_lk;                         // != 0: LK role active (block count is derived at launch)
     int lk_B;                         // streams of the LK role
     AgtPnpParams pnp;
+    int pnp_nf;
     int n_pnp;                        // blocks of the PnP role (= streams) or 0
+};
+
+// per-frame pointer tables of the fused launch: its SECOND kernel argument.  They are indexed with run-time
+// frame numbers and therefore read from the kernel-argument segment directly (never through a by-value copy).
+struct AgtLkTables {
+    const uint8_t* img[AGT_MAX_GROUP + 1][AGT_MAX_LEVELS];     // image k of the group per level (k = 0: the frame before it)
+    float* next[AGT_MAX_GROUP];                                // frame k+1's corners / status
+    uint8_t* status[AGT_MAX_GROUP];
+};
+struct AgtPnpTables {
+    const float* img[AGT_MAX_GROUP];                           // per frame: corners, LK status, caller's state record
+    const uint8_t* mask[AGT_MAX_GROUP];
+    double* so[AGT_MAX_GROUP];
+};
+struct AgtStepTables {
+    const uint8_t* pyr_src[AGT_MAX_LEVELS - 1][AGT_MAX_GROUP];
+    uint8_t* pyr_dst[AGT_MAX_LEVELS - 1][AGT_MAX_GROUP];
+    AgtLkTables lk;
+    AgtPnpTables pnp;
 };
 
 struct AgtProjParams {
@@ -119,4 +145,4 @@ bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
 bool agt_step_fits(int n, int B);   // the fused launch is used for small, latency-bound launches only
-hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win);
+hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win);

@@ -7,7 +7,11 @@ template <int WIN, int NW, int NLEV>
 __global__ __launch_bounds__(AGT_WAVE * NW) void lk_kernel(const AgtLkParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    agt_lk::lk_body<WIN, NW, NLEV>(P, blockIdx.x, blockIdx.y, lds);
+    agt_lk::LkFrameIo<NLEV> io;
+    io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
+    io.have_pos = false; io.px = io.py = 0.f;
+    float ox, oy;
+    agt_lk::lk_body<WIN, NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ox, oy);
 }
 
 template <int WIN, int NW>

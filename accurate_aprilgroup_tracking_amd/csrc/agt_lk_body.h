@@ -180,19 +180,44 @@ __host__ __device__ constexpr size_t lk_lds_bytes(int levels)
     return (size_t)levels * C::LEVEL_LDS + (size_t)((C::DW * C::DW + 3) & ~3) * sizeof(int) + (size_t)2 * NW * 4 * sizeof(long long);
 }
 
-// Track corner `pt` of stream `b`.  Called by all 64*NW threads of a workgroup; lds: lk_lds_bytes, 16-B aligned.
-template <int WIN, int NW, int NLEV>
-__device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uint8_t* lds)
+
+// Where one frame of the tracker reads and writes.  grouped = image bases come from imgI / imgJ (the frame
+// group of the fused step) instead of P.prev / P.next; have_pos = the previous position comes in registers
+// (frame 2.. of a group: the corner was tracked by this same workgroup a moment ago) instead of from prev_pts.
+template <int NLEV>
+struct LkFrameIo {
+    const uint8_t* imgI[NLEV];      // previous image, per level
+    const uint8_t* imgJ[NLEV];      // next image, per level
+    bool grouped;
+    const float* prev_pts; float* next_pts; uint8_t* status; float* err;
+    bool have_pos; float px, py;
+};
+
+// Track corner `pt` of stream `b` through one frame.  Called by all 64*NW threads of a workgroup; lds:
+// lk_lds_bytes, 16-B aligned.  Returns the new position in (ox, oy) (identical in every thread).
+// field-wise copy: L may live in the kernel-argument address space (no implicit struct copy from there)
+template <typename LV>
+__device__ __forceinline__ AgtLevel get_level(const LV& L)
+{
+    AgtLevel r;
+    r.ptr = L.ptr; r.pitch = L.pitch; r.bstride = L.bstride; r.w = L.w; r.h = L.h;
+    return r;
+}
+
+// PP: pointer to the parameters -- `const AgtLkParams*` (stand-alone launch) or a pointer into the kernel-argument
+// segment (fused step, where the level tables are indexed with run-time levels inside a frame loop).
+template <int WIN, int NW, int NLEV, typename PP>
+__device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float& ox, float& oy)
 {
     using C = LkCfg<WIN, NW>;
     constexpr int T = C::T;
-    int* sD = reinterpret_cast<int*>(lds + (P.max_level + 1) * C::LEVEL_LDS);
+    int* sD = reinterpret_cast<int*>(lds + (P->max_level + 1) * C::LEVEL_LDS);
     long long* slots = reinterpret_cast<long long*>(sD + ((C::DW * C::DW + 3) & ~3));
     int phase = 0;
 
     const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;   // thread index within the corner
     const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
-    const long pidx = (long)b * P.n + pt;
+    const long pidx = (long)b * P->n + pt;
 
     // window pixels of this thread, as byte / element offsets into the three LDS tiles (computed once;
     // threads without a k-th pixel point at offset 0 and are masked arithmetically, not by branches)
@@ -210,11 +235,11 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
 
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
-    const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
+    const float ppx = io.have_pos ? io.px : io.prev_pts[pidx * 2], ppy = io.have_pos ? io.py : io.prev_pts[pidx * 2 + 1];
     float outx = 0.f, outy = 0.f;              // nextPts[ptidx]
-    if (P.flags & AGT_LK_USE_INITIAL_FLOW) { outx = P.next_pts[pidx * 2]; outy = P.next_pts[pidx * 2 + 1]; }
-    const float gsx = (P.flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;     // where the search is expected to start
-    const float gsy = (P.flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
+    if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
+    const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;     // where the search is expected to start
+    const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 
     STAMP(0);
     // ---- prologue: request every level's tiles before touching any of them
@@ -222,12 +247,13 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
         uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            if (l <= P.max_level) {
+            if (l <= P->max_level) {
                 const float scale = 1.f / (float)(1 << l);
                 const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
                 const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
-                const AgtLevel LI = P.prev[l];
-                const AgtLevel LJ = P.next[l];
+                AgtLevel LI = get_level(P->prev[l]);
+                AgtLevel LJ = get_level(P->next[l]);
+                if (io.grouped) { LI.ptr = io.imgI[l]; LJ.ptr = io.imgJ[l]; }
                 if (!(ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h)) {
                     tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti[l]);
                     tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj[l]);
@@ -237,7 +263,7 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
         STAMP(1);
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            if (l <= P.max_level) {
+            if (l <= P->max_level) {
                 tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, tid, ti[l]);
                 tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, tid, tj[l]);
             }
@@ -249,17 +275,23 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
     int st = 1;
     float errv = 0.f;
 
-    for (int level = P.max_level; level >= 0; level--) {
-        const AgtLevel LI = P.prev[level];
-        const AgtLevel LJ = P.next[level];
+    for (int level = P->max_level; level >= 0; level--) {
+        const AgtLevel LI = get_level(P->prev[level]);
+        AgtLevel LJ = get_level(P->next[level]);
+        if (io.grouped) {
+            const uint8_t* q = io.imgJ[0];
+#pragma unroll
+            for (int l = 1; l < NLEV; l++) q = level == l ? io.imgJ[l] : q;
+            LJ.ptr = q;
+        }
         const uint8_t* imgJ = LJ.ptr + (long)b * LJ.bstride;
         const uint8_t* sI = lds + level * C::LEVEL_LDS;
         uint8_t* sJ = lds + level * C::LEVEL_LDS + C::IW * C::IP;
         const float scale = 1.f / (float)(1 << level);
         float prevx = ppx * scale, prevy = ppy * scale;
         float nextx, nexty;
-        if (level == P.max_level) {
-            if (P.flags & AGT_LK_USE_INITIAL_FLOW) { nextx = outx * scale; nexty = outy * scale; }
+        if (level == P->max_level) {
+            if (P->flags & AGT_LK_USE_INITIAL_FLOW) { nextx = outx * scale; nexty = outy * scale; }
             else { nextx = prevx; nexty = prevy; }
         } else { nextx = outx * 2.f; nexty = outy * 2.f; }
         outx = nextx; outy = nexty;
@@ -321,8 +353,8 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
 
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
-        if (P.flags & AGT_LK_GET_MIN_EIGENVALS) errv = minEig;
-        if (agt_uniform((int)((double)minEig < P.min_eig_threshold || D < FLT_EPSILON))) {
+        if (P->flags & AGT_LK_GET_MIN_EIGENVALS) errv = minEig;
+        if (agt_uniform((int)((double)minEig < P->min_eig_threshold || D < FLT_EPSILON))) {
             if (level == 0) st = 0;
             continue;
         }
@@ -353,7 +385,7 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
                 else { acc[0] += __mul24(diff, Ix[k]); acc[1] += __mul24(diff, Iy[k]); }   // Ix = Iy = 0 where !pv
             }
         };
-        for (int j = 0; j < P.max_count; j++) {
+        for (int j = 0; j < P->max_count; j++) {
             if (j == 1) STAMP(39);
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
@@ -381,7 +413,7 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
 #ifdef AGT_LK_STAMPS
             if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
 #endif
-            if (agt_uniform((int)((double)dx * dx + (double)dy * dy <= P.eps2))) break;
+            if (agt_uniform((int)((double)dx * dx + (double)dy * dy <= P->eps2))) break;
             if (j > 0 && agt_uniform((int)(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01))) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
@@ -391,7 +423,7 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
         }
 
         STAMP(8 + level * 8 + 4);
-        if (st && P.err && level == 0 && !(P.flags & AGT_LK_GET_MIN_EIGENVALS)) {
+        if (st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
             const float npx = outx - halfw, npy = outy - halfw;
             const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) { st = 0; continue; }
@@ -408,11 +440,12 @@ __device__ __forceinline__ void lk_body(const AgtLkParams& P, int pt, int b, uin
 
     STAMP(3);
     if (tid == 0) {
-        P.next_pts[pidx * 2] = outx;
-        P.next_pts[pidx * 2 + 1] = outy;
-        P.status[pidx] = (uint8_t)st;
-        if (P.err) P.err[pidx] = errv;
+        io.next_pts[pidx * 2] = outx;
+        io.next_pts[pidx * 2 + 1] = outy;
+        io.status[pidx] = (uint8_t)st;
+        if (io.err) io.err[pidx] = errv;
     }
+    ox = outx; oy = outy;
 }
 
 }  // namespace agt_lk

@@ -10,7 +10,7 @@ template <typename T, int PPL>
 __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 {
     __shared__ agt_pnp::PnpShared sh;
-    agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh);
+    agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh, P.img, P.mask, P.state_out);
 }
 
 template <typename T>

@@ -45,6 +45,7 @@ struct PnpShared {
     double tot[NACC + 4];
     double LL[144];
     double vec[48];
+    unsigned long long tab[3 * AGT_MAX_GROUP];     // fused step: copy of AgtStepParams::pnp_img / pnp_mask / pnp_so
 };
 
 // sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
@@ -319,7 +320,8 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
 
 // Solve problem `b`.  Called by ONE wave (threadIdx.x < 64 of its workgroup); sh: that workgroup's scratch.
 template <typename T, int PPL>
-__device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh)
+__device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
+                                         double* so_p)
 {
     const int lane = threadIdx.x;
     const int n = P.n;
@@ -331,8 +333,8 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     double X[PPL], Y[PPL], Z[PPL], mu_[PPL], mv_[PPL];
     bool use[PPL];
     const T* obj = reinterpret_cast<const T*>(P.obj) + (long)b * P.obj_bstride;
-    const T* img = reinterpret_cast<const T*>(P.img) + (long)b * n * 2;
-    const uint8_t* mask = P.mask ? P.mask + (long)b * n : nullptr;
+    const T* img = reinterpret_cast<const T*>(img_p) + (long)b * n * 2;
+    const uint8_t* mask = mask_p ? mask_p + (long)b * n : nullptr;
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
@@ -361,8 +363,8 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
             if (lane == 0) {
                 ts->has_guess = 0; ts->frame++;
-                if (P.state_out) {
-                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+                if (so_p) {
+                    double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
                     so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
                 }
@@ -519,8 +521,8 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             if (lane == 0 && P.err) P.err[b] = 0.0;
             if (lane == 0 && ts) {
                 ts->has_guess = 0; ts->frame++;
-                if (P.state_out) {
-                    double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+                if (so_p) {
+                    double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
                     so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
                 }
@@ -774,8 +776,8 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             }
             ts->frame++;
             PSTAMP(5);
-            if (P.state_out) {
-                double* so = P.state_out + (long)b * AGT_STATE_STRIDE;
+            if (so_p) {
+                double* so = so_p + (long)b * AGT_STATE_STRIDE;
                 for (int i = 0; i < 6; i++) so[i] = param[i];
                 so[AGT_ST_OK] = accepted ? 1.0 : 0.0; so[AGT_ST_ERR] = esum; so[AGT_ST_NTRACK] = n_used;
                 so[AGT_ST_ITERS] = iters; so[AGT_ST_GUESS] = use_guess ? 1.0 : 0.0; so[AGT_ST_FLAGS] = tflags;

@@ -18,7 +18,7 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs 
     if (t >= per_img * A.B) return;
     const int bz = t / per_img, r = t - bz * per_img;
     const int by = r / A.gx;
-    agt_pyr::pyr_down_body(A, r - by * A.gx, by, bz, lds);
+    agt_pyr::pyr_down_body(A, r - by * A.gx, by, A.src + (long)bz * A.sbatch, A.dst + (long)bz * A.dbatch, lds);
 }
 
 }  // namespace

@@ -54,16 +54,15 @@ __device__ __noinline__ uint4 load_chunk_reflect(const uint8_t* __restrict__ row
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
-// one 128x16 output tile; (bx, by, bz) = tile x, tile y, image index.  lds: PYR_LDS_BYTES, 16-B aligned
-__device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int by, int bz, uint8_t* lds)
+// one 128x16 output tile (bx, by) of the image at `img` -> `out`.  lds: PYR_LDS_BYTES, 16-B aligned
+__device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int by, const uint8_t* __restrict__ img,
+                                              uint8_t* __restrict__ out, uint8_t* lds)
 {
     uint8_t* s_src = lds;
     uint8_t* s_h = lds + SH * SW;
     const int sw = A.sw, sh = A.sh, dw = A.dw, dh = A.dh;
     const int tid = threadIdx.x;
     const int ox0 = bx * TW, oy0 = by * TH;
-    const uint8_t* __restrict__ img = A.src + (long)bz * A.sbatch;
-    uint8_t* __restrict__ out = A.dst + (long)bz * A.dbatch;
     const int sx0 = 2 * ox0 - 16, sy0 = 2 * oy0 - 2;
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)A.spitch) & 15) == 0;
 

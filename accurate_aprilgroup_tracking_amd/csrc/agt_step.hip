@@ -13,6 +13,7 @@
 #undef AGT_LK_STAMPS
 #undef AGT_PNP_STAMPS
 #include <cstdlib>
+#include <cstddef>
 #include "agt_pyramid_body.h"
 #include "agt_lk_body.h"
 #include "agt_pnp_body.h"
@@ -22,16 +23,35 @@ namespace {
 constexpr int STEP_THREADS = 256;
 
 template <int WIN, int NW, int NLEV>
-__global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams S)
+__global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    // The per-frame tables (second argument) are indexed with run-time frame numbers; they are read straight
+    // from the kernel-argument segment -- indexing a by-value argument dynamically forces a copy into scratch.
+    static_assert(alignof(AgtStepTables) == 8 && alignof(AgtStepParams) == 8, "kernel-argument layout");
+    const __attribute__((address_space(4))) AgtStepParams* KS = (const __attribute__((address_space(4))) AgtStepParams*)__builtin_amdgcn_kernarg_segment_ptr();
+    const __attribute__((address_space(4))) AgtStepTables* KT = (const __attribute__((address_space(4))) AgtStepTables*)(
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
     // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
     // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
     int blk = blockIdx.x;
     if (blk < S.n_pnp) {
         if (threadIdx.x >= AGT_WAVE) return;
         agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh);        // fused path: n <= 64 (agt_step_supported)
+        // consecutive frames of stream `blk`: frame k+1 starts from the tracker state frame k left in
+        // global memory (written and read by this one wave; the barrier orders the two).  Frames 2.. read
+        // their pointers from an LDS copy of the tables requested up front (see the LK role).
+        static_assert(sizeof(AgtPnpTables) == 24 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
+        if (S.pnp_nf > 1 && threadIdx.x < sizeof(AgtPnpTables) / 4)
+            reinterpret_cast<uint32_t*>(sh.tab)[threadIdx.x] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[threadIdx.x];
+        for (int k = 0; k < S.pnp_nf; k++) {
+            const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
+            if (k) {
+                __syncthreads();
+                img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
+            }
+            agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh, img, mask, so);     // fused path: n <= 64
+        }
         return;
     }
     blk -= S.n_pnp;
@@ -42,8 +62,39 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
         const long corner = (long)blk * CPB + (NW == 1 ? wave : 0);
         if (corner >= (long)S.lk.n * S.lk_B) return;
         const int b = (int)(corner / S.lk.n), pt = (int)(corner - (long)b * S.lk.n);
-        uint8_t* my = lds + (NW == 1 ? (size_t)wave * ((agt_lk::lk_lds_bytes<WIN, NW>(S.lk.max_level + 1) + 15) & ~(size_t)15) : 0);
-        agt_lk::lk_body<WIN, NW, NLEV>(S.lk, pt, b, my);
+        constexpr size_t LKB = sizeof(AgtLkTables);
+        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(S.lk.max_level + 1) + LKB + 15) & ~(size_t)15;
+        uint8_t* my = lds + (NW == 1 ? (size_t)wave * per : 0);
+        // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: the kernel-
+        // argument segment is host memory, a dependent scalar load from it in the middle of the chain costs a
+        // PCIe round trip.  The copy is requested here, before anything else, and lands while the first frame's
+        // corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
+        AgtLkTables* tab = reinterpret_cast<AgtLkTables*>(my + per - LKB);
+        {
+            const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
+            const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)&KT->lk;
+            if (S.lk_nf > 1) {
+                const uint32_t* gsrc = (const uint32_t*)src;              // vector loads: one per lane, all in flight at once
+                for (int i = tid; i < (int)(LKB / 4); i += AGT_WAVE * NW) reinterpret_cast<uint32_t*>(tab)[i] = gsrc[i];
+            }
+        }
+        // consecutive frames of this corner: its position is carried in registers from frame to frame
+        float px = 0.f, py = 0.f;
+        for (int k = 0; k < S.lk_nf; k++) {
+            agt_lk::LkFrameIo<NLEV> io;
+            io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py;
+            if (k == 0) {
+#pragma unroll
+                for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
+                io.next_pts = T.lk.next[0]; io.status = T.lk.status[0];
+            } else {
+                agt_lk::block_sync<NW>();          // the previous frame's LDS tiles are free again; the table copy is visible
+#pragma unroll
+                for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
+                io.next_pts = tab->next[k]; io.status = tab->status[k];
+            }
+            agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py);
+        }
         return;
     }
     blk -= S.n_lk;
@@ -59,9 +110,10 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
             int tile = (blk - ((j - base) & 7)) >> 3;
             for (int q = 0; q < j; q++) tile += (n - ((q - base) & 7) + 7) >> 3;
             const int per_img = A.gx * A.gy;
-            const int bz = tile / per_img, r = tile - bz * per_img;
+            const int bz = tile / per_img, r = tile - bz * per_img;      // bz = frame * B + stream
             const int by = r / A.gx, bx = r - by * A.gx;
-            agt_pyr::pyr_down_body(A, bx, by, bz, lds);
+            const int fr = bz / A.B, st = bz - fr * A.B;
+            agt_pyr::pyr_down_body(A, bx, by, KT->pyr_src[s][fr] + (long)st * A.sbatch, KT->pyr_dst[s][fr] + (long)st * A.dbatch, lds);
             return;
         }
         blk -= S.n_pyr[s];
@@ -70,7 +122,7 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
 }
 
 template <int WIN, int NW>
-hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S)
+hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T)
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
@@ -83,14 +135,14 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S)
         const long corners = (long)P.lk.n * P.lk_B;
         P.n_lk = (int)((corners + CPB - 1) / CPB);
         blocks += P.n_lk;
-        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(P.lk.max_level + 1) + 15) & ~(size_t)15;
+        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(P.lk.max_level + 1) + sizeof(AgtLkTables) + 15) & ~(size_t)15;
         const size_t need = per * (NW == 1 ? CPB : 1);
         lds = lds > need ? lds : need;
     }
     if (P.n_pnp > 0) { blocks += P.n_pnp; lds = lds > sizeof(agt_pnp::PnpShared) ? lds : sizeof(agt_pnp::PnpShared); }
     if (blocks == 0) return hipSuccess;
-    if (P.lk.max_level < 3) hipLaunchKernelGGL((step_kernel<WIN, NW, 3>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P);
-    else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P);
+    if (P.lk.max_level < 3) hipLaunchKernelGGL((step_kernel<WIN, NW, 3>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     return hipGetLastError();
 }
 
@@ -103,9 +155,9 @@ bool agt_step_fits(int n, int B)
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
 
-hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, int win)
+hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win)
 {
     if (win != 21) return hipErrorInvalidValue;
     const bool wide = S.n_lk > 0 ? agt_lk_wide(S.lk.n, S.lk_B) : true;
-    return wide ? launch_step_t<21, 4>(stream, S) : launch_step_t<21, 1>(stream, S);
+    return wide ? launch_step_t<21, 4>(stream, S, T) : launch_step_t<21, 1>(stream, S, T);
 }

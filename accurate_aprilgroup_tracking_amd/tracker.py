@@ -38,7 +38,8 @@ class StreamTracker:
         assert H.lib().agt_tracker_state_size() == C.sizeof(TrackState)
         H.check(self.ctx.L.agt_tracker_options(self.ctx.h, int(reproject), int(min_points), float(gate_px)),
                 "agt_tracker_options")
-        self._alive = []            # frames aliased by pyramid level 0 of the three ring slots
+        self._alive = []            # frames aliased by pyramid level 0 of the ring entries in flight
+        self._keep_frames = (max_level + 3) + 2
 
     def _dist_ptr(self):
         return self.dist.ctypes.data_as(C.c_void_p) if self.ndist else None
@@ -55,9 +56,13 @@ class StreamTracker:
                                              int(self.enhance_ape)), "agt_tracker_reset")
         self._alive = [frames]
 
-    def pipeline(self, enable):
-        """Software-pipelined fused step (default on): one launch per frame, poses L+1 steps late."""
-        H.check(self.ctx.L.agt_tracker_pipeline(self.ctx.h, int(bool(enable))), "agt_tracker_pipeline")
+    def pipeline(self, depth):
+        """0 / False: separate launches per stage, pose complete in stream order.  F >= 1 (True = 1, the default):
+        fused software-pipelined step advancing every stage by F frames per launch -- one launch every F calls
+        of step(); the record of frame t is written about (L + 2) * F steps later (join() flushes)."""
+        depth = int(depth)
+        H.check(self.ctx.L.agt_tracker_pipeline(self.ctx.h, depth), "agt_tracker_pipeline")
+        self._keep_frames = (self.ctx.max_level + 3) * max(depth, 1) + 2
 
     def step(self, frames, state_out=None):
         """frames: cuda u8 [B,H,W] (a reference is kept while the frame is in flight: level 0 of the
@@ -67,7 +72,7 @@ class StreamTracker:
         H.check(self.ctx.L.agt_track_frame(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
                                            _ptr(state_out)), "agt_track_frame")
         self._alive.append(frames)
-        if len(self._alive) > 6:
+        if len(self._alive) > self._keep_frames:
             del self._alive[0]
         return state_out
 

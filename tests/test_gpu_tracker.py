@@ -159,20 +159,21 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
     assert np.abs(np.array(states[1].guess[:]) - g).max() < 10 * tol
 
 
-def test_pipelined_stream_equals_serial(torch_cuda, seq640):
-    """many frames enqueued back-to-back with NO host sync: the three-stream overlap must give
-    bit-identical state records to the serial order (dependencies are exact, not heuristic)"""
+@pytest.mark.parametrize("max_level", [2, 3])
+def test_pipelined_stream_equals_serial(torch_cuda, seq640, max_level):
+    """many frames enqueued back-to-back with NO host sync: the software-pipelined fused step, at every group
+    size (frames per launch), must give bit-identical state records to the serial order -- the launch order is
+    the only dependency mechanism.  max_level 3 needs a ring of 5 entries per frame of the group."""
     torch = torch_cuda
     from accurate_aprilgroup_tracking_amd import hiplib as H
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
     s = seq640
-    F = len(s)
     frames = torch.from_numpy(s.frames()).cuda()
     order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0] * 3
     outs = []
-    for mode in (False, True):
-        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
-        trk.pipeline(mode)
+    for depth in (0, 1, 2, 3, 4, 8):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1, max_level=max_level)
+        trk.pipeline(depth)
         trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
         so = trk.new_state_buffer(len(order))
         for i, k in enumerate(order):
@@ -180,8 +181,34 @@ def test_pipelined_stream_equals_serial(torch_cuda, seq640):
         trk.join()
         outs.append(so.cpu().numpy())
         assert trk.read_state()[0].frame == len(order)
-    assert np.array_equal(outs[0], outs[1])
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
     assert outs[0][:, 0, H.ST_OK].all()
+
+
+def test_pipeline_depth_switch_mid_stream(torch_cuda, seq640):
+    """changing the group size (or leaving the pipeline) between frames drains the frames in flight and re-seats
+    the newest frame's ring entry; the records stay those of the serial order"""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3]
+    plan = {0: 4, 7: 1, 11: 0, 14: 8, 20: 2, 23: 3}
+    outs = []
+    for switching in (False, True):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2)
+        trk.pipeline(0)
+        c0 = torch.from_numpy(np.stack([s.corners(0), s.corners(0)])).cuda().contiguous()
+        trk.reset(torch.stack([frames[0], frames[0]]).contiguous(), c0)
+        so = trk.new_state_buffer(len(order))
+        for i, k in enumerate(order):
+            if switching and i in plan:
+                trk.pipeline(plan[i])
+            trk.step(torch.stack([frames[k], frames[k]]).contiguous(), so[i])
+        trk.join()
+        outs.append(so.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
 
 
 def test_track_frame_argument_and_state_errors(torch_cuda):
