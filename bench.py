@@ -124,6 +124,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (c2: 1, c3: 64)")
     ap.add_argument("--render-frames", type=int, default=24)
+    ap.add_argument("--depth", type=int, default=4, help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-extra", action="store_true", help="skip the 64-stream HBM-bound side measurement")
     args = ap.parse_args()
@@ -146,6 +147,9 @@ def main():
     render_s = time.time() - t_r
     sq0 = seqs[0]
     trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+    fused = B * NPTS <= 128
+    depth = max(1, min(args.depth, 8)) if fused else 1
+    trk.pipeline(depth)
     fps, dt, state, gathered, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world)
     st = state.cpu().numpy()
     accepted = float(st[Wm:, :, HL.ST_OK].mean())
@@ -153,26 +157,30 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes()
-        M = min(K, 200)
-        fused = B * NPTS <= 128
+        M = min(K, 200) // depth * depth
         # per-launch durations from HIP events on the launch stream, second (instrumented) pass
         stage_us = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, False)     # separate kernels
         names = ["pyramid", "lk", "pnp"]
         if fused:
-            # one launch per step: average launch period from two HIP events around M launches on the launch stream
-            trk.pipeline(True)
-            trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-            run(Wm, 1, None)
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record(); run(M, 1 + Wm, None); e1.record()
-            trk.join(); torch.cuda.synchronize()
-            step_us = e0.elapsed_time(e1) * 1e3 / M
-            achieved = B * ab["frame"] / (step_us * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: pyrDown x2 | LK | PnP of 4 consecutive frames)",
+            # one launch per `depth` steps: average launch period from two HIP events around M / depth launches on
+            # the launch stream (steady state: every launch carries depth frames of each pipeline stage)
+            def fused_period(d):
+                trk.pipeline(d)
+                trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
+                run(Wm // d * d, 1, None)
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record(); run(M // d * d, 1 + Wm // d * d, None); e1.record()
+                trk.join(); torch.cuda.synchronize()
+                return e0.elapsed_time(e1) * 1e3 / (M // d * d) * d
+            launch_us = fused_period(depth)
+            launch_us_d1 = fused_period(1) if depth != 1 else launch_us
+            achieved = depth * B * ab["frame"] / (launch_us * 1e-6) / 1e9
+            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: PnP | LK | pyrDown x2, %d consecutive frames of each stage per launch)" % depth,
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": pmc_traffic("step_kernel<21,4,3>") if B == 1 else None,
+                    "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth) if B == 1 else None,
                     "frac_of_measured_copy_6290GBs": round(achieved / 6290.0, 6),
-                    "avg_launch_us": round(step_us, 3), "bytes_per_launch": int(B * ab["frame"]),
+                    "avg_launch_us": round(launch_us, 3), "frames_per_launch": depth, "bytes_per_launch": int(depth * B * ab["frame"]),
+                    "one_frame_per_launch": {"avg_launch_us": round(launch_us_d1, 3), "frames_per_s": round(B / (launch_us_d1 * 1e-6), 1)},
                     "note": "latency-bound by construction: one 720p stream is a serial chain of ~10 LK and 4 LM iterations"}
         else:
             dom = int(np.argmax(stage_us))
@@ -199,7 +207,8 @@ def main():
                                       "iterative PnP with motion-model guess" % (args.workload, B),
                           "streams_per_gpu": B, "frames_resident": "HBM ring %d slots (%.0f MiB)" % (ring_slots, ring.numel() / 2**20),
                           "parallelism": "stream-per-GPU x%d, RCCL all_gather of poses once" % world,
-                          "launch": "fused software-pipelined step" if fused else "separate kernels per stage"},
+                          "launch": ("fused software-pipelined step, %d frames per launch (record of frame t written ~%d steps later)"
+                                     % (depth, (LEVELS + 1) * depth)) if fused else "separate kernels per stage"},
                "roofline": roof, "cpu_baseline": cpu,
                "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
                "batch64_hbm": extra, "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape)}
@@ -248,7 +257,11 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
             break
     dt = time.perf_counter() - t0
     # same chain with OpenMP over rows / points on every host core (as OpenCV's parallel_for_), ~5 s
-    nthr = os.cpu_count() or 1
+    try:
+        nthr = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nthr = os.cpu_count() or 1
+    nthr = max(1, min(nthr, 16))          # the GPU box grants about 16 cores per GPU; 48 corners do not scale further anyway
     pyr2 = cvo.Pyramid(frames[0]); pts2 = seq.corners(0)
     r2, t2 = seq.rvecs[0].copy(), seq.tvecs[0].copy()
     n2 = 0; t1 = time.perf_counter()
