@@ -56,6 +56,7 @@ struct RemapParams {
     int rx, ry, rw, rh;                                          // output window in map coordinates
     uint8_t* dst; long dpitch, dbatch;
     int undistort;                                               // 0: taps come straight from (x, y)
+    int B;                                                       // images (gray path: flattened work order)
 };
 
 struct __attribute__((packed)) Tap6 { uint32_t lo; uint16_t hi; };
@@ -109,12 +110,23 @@ __device__ __forceinline__ void remap_bgr(const uint8_t* __restrict__ img, long 
 template <bool GRAY>
 __global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
 {
-    const uint8_t* img = P.src + (long)blockIdx.z * P.sbatch;
-    uint8_t* out = P.dst + (long)blockIdx.z * P.dbatch;
-    const int y = blockIdx.y;                                     // row inside the ROI
     if (GRAY) {
-        const int x0 = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
-        if (x0 >= P.rw) return;
+        // A workgroup = 4 rows x 64 groups of four output pixels.  Grid (8 * 2 * nseg, images, bands / 8): gridDim.x
+        // is a multiple of 8 and workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so
+        // blockIdx.x % 8 IS the XCD: XCD k owns the bands k * gridDim.z .. (k + 1) * gridDim.z - 1 (8 rows each),
+        // and walks band by band, image by image.  Inside a band the map rows (6 B/px, shared by all images) stay
+        // in that XCD's L2 while the images go by, and the source rows that consecutive output rows share
+        // (sy and sy + 1) are fetched into one L2 instead of two.  No divisions: the split is done by the grid.
+        const int nseg = (int)gridDim.x >> 4;
+        const int xcd = blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int strip = j >= nseg ? 1 : 0, seg = j - strip * nseg;
+        const int band = xcd * (int)gridDim.z + (int)blockIdx.z;
+        const int bz = blockIdx.y;
+        const int y = band * 8 + strip * 4 + ((int)threadIdx.x >> 6);          // row inside the ROI
+        const int x0 = (seg * 64 + ((int)threadIdx.x & 63)) * 4;
+        if (y >= P.rh || x0 >= P.rw) return;
+        const uint8_t* img = P.src + (long)bz * P.sbatch;
+        uint8_t* out = P.dst + (long)bz * P.dbatch;
         uint32_t packed = 0;
         // map entries of the thread's four pixels: 16 + 8 contiguous bytes (unaligned vector loads)
         struct __attribute__((packed)) M1x4 { short2 m[4]; };
@@ -125,25 +137,45 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
             if (x0 + 3 < P.rw) { mm = *reinterpret_cast<const M1x4*>(P.map1 + o0); qq = *reinterpret_cast<const M2x4*>(P.map2 + o0); }
             else for (int k = 0; k < 4; k++) { const bool in = x0 + k < P.rw; mm.m[k] = in ? P.map1[o0 + k] : make_short2(0, 0); qq.q[k] = in ? P.map2[o0 + k] : 0; }
         }
-        // Lens-like maps are locally regular: the four pixels of a thread usually read source pixels
-        // sx .. sx+4 of rows sy, sy+1.  Then two unaligned 16-byte loads replace sixteen narrow ones.
         if (P.undistort && x0 + 3 < P.rw) {
-            const int sx = mm.m[0].x, sy = mm.m[0].y;
-            const bool regular = mm.m[1].x == sx + 1 && mm.m[2].x == sx + 2 && mm.m[3].x == sx + 3 &&
-                                 mm.m[1].y == sy && mm.m[2].y == sy && mm.m[3].y == sy &&
-                                 sx >= 0 && sx + 5 < P.sw && sy >= 0 && sy + 1 < P.sh;          // 16 bytes stay inside the row
-            if (regular) {
-                struct __attribute__((packed)) Row16 { uint32_t d[4]; };
-                const Row16 s = *reinterpret_cast<const Row16*>(img + (long)sy * P.spitch + sx * 3);
-                const Row16 t = *reinterpret_cast<const Row16*>(img + (long)(sy + 1) * P.spitch + sx * 3);
-                auto byte = [](const Row16& v, int i) -> int { return (v.d[i >> 2] >> (8 * (i & 3))) & 0xff; };
+            // Interior path: all four map entries inside the source.  Each pixel's two taps per row are 6 contiguous
+            // bytes at an arbitrary byte offset: one unaligned 8-byte load per pixel per row (gfx950 global loads need
+            // no alignment), all eight requested before the first is used.  (A variant that served "regular" groups
+            // -- sx advancing by exactly one -- with two 16-byte loads made the kernel slower: lens + zoom maps mix
+            // regular and irregular groups inside every wave, so both paths ran.)
+            bool interior = true;
+            // (sx <= sw - 4 keeps the 12 aligned bytes of a tap inside its row; an unaligned frame base also needs
+            // the bytes just before the tap to exist)
+            const bool base4 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)P.spitch) & 3) == 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                interior = interior && (unsigned)mm.m[k].x < (unsigned)(P.sw - 3) && (unsigned)mm.m[k].y < (unsigned)(P.sh - 1) &&
+                           (base4 || mm.m[k].x > 1 || mm.m[k].y > 0);
+            if (interior) {
+                // The 6 tap bytes of a row start at an arbitrary byte offset o.  Misaligned vector loads go through the
+                // texture addresser lane by lane; instead the three ALIGNED dwords that cover [o, o + 6) are loaded
+                // (dwordx3, 4-byte aligned) and funnel-shifted by o & 3 bytes (v_alignbyte_b32).
+                struct Row12 { uint32_t d0, d1, d2; };
+                Row12 s[4], t[4];
+                unsigned sh[4];
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const unsigned o = (unsigned)(__mul24((int)mm.m[k].y, (int)P.spitch) + __mul24((int)mm.m[k].x, 3));   // < 2^31: one frame
+                    const uintptr_t a = reinterpret_cast<uintptr_t>(img) + o;
+                    sh[k] = (unsigned)(a & 3);
+                    const uint8_t* al = reinterpret_cast<const uint8_t*>(a & ~(uintptr_t)3);
+                    s[k] = *reinterpret_cast<const Row12*>(al);
+                    t[k] = *reinterpret_cast<const Row12*>(al + P.spitch);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     int w00, w01, w10, w11;
                     tap_weights(qq.q[k], w00, w01, w10, w11);
-                    const int b = blend4(byte(s, 3 * k), byte(s, 3 * k + 3), byte(t, 3 * k), byte(t, 3 * k + 3), w00, w01, w10, w11);
-                    const int g = blend4(byte(s, 3 * k + 1), byte(s, 3 * k + 4), byte(t, 3 * k + 1), byte(t, 3 * k + 4), w00, w01, w10, w11);
-                    const int r = blend4(byte(s, 3 * k + 2), byte(s, 3 * k + 5), byte(t, 3 * k + 2), byte(t, 3 * k + 5), w00, w01, w10, w11);
+                    const uint32_t slo = __builtin_amdgcn_alignbyte(s[k].d1, s[k].d0, sh[k]), shi = __builtin_amdgcn_alignbyte(s[k].d2, s[k].d1, sh[k]);
+                    const uint32_t tlo = __builtin_amdgcn_alignbyte(t[k].d1, t[k].d0, sh[k]), thi = __builtin_amdgcn_alignbyte(t[k].d2, t[k].d1, sh[k]);
+                    const int b = blend4(slo & 0xff, slo >> 24, tlo & 0xff, tlo >> 24, w00, w01, w10, w11);
+                    const int g = blend4((slo >> 8) & 0xff, shi & 0xff, (tlo >> 8) & 0xff, thi & 0xff, w00, w01, w10, w11);
+                    const int r = blend4((slo >> 16) & 0xff, (shi >> 8) & 0xff, (tlo >> 16) & 0xff, (thi >> 8) & 0xff, w00, w01, w10, w11);
                     packed |= (uint32_t)gray14(b, g, r) << (8 * k);
                 }
                 uint8_t* o = out + (long)y * P.dpitch + x0;
@@ -182,6 +214,9 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
         if (x0 + 3 < P.rw && (((uintptr_t)o) & 3) == 0) *reinterpret_cast<uint32_t*>(o) = packed;
         else for (int k = 0; k < 4 && x0 + k < P.rw; k++) o[k] = (uint8_t)(packed >> (8 * k));
     } else {
+        const uint8_t* img = P.src + (long)blockIdx.z * P.sbatch;
+        uint8_t* out = P.dst + (long)blockIdx.z * P.dbatch;
+        const int y = blockIdx.y;
         const int x = blockIdx.x * blockDim.x + threadIdx.x;
         if (x >= P.rw) return;
         const long o = (long)(P.ry + y) * P.mw + (P.rx + x);
@@ -216,7 +251,9 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
     P.src = src; P.spitch = spitch; P.sbatch = sbatch; P.sw = sw; P.sh = sh;
     P.map1 = map1; P.map2 = map2; P.mw = mw; P.rx = rx; P.ry = ry; P.rw = rw; P.rh = rh;
     P.dst = dst; P.dpitch = dpitch; P.dbatch = dbatch; P.undistort = undistort;
-    if (gray) hipLaunchKernelGGL(preprocess_kernel<true>, dim3((rw + 1023) / 1024, rh, B), dim3(256), 0, stream, P);
+    P.B = B;
+    const int nseg = (rw + 255) / 256, bands = (rh + 7) / 8;
+    if (gray) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(16 * nseg, B, (bands + 7) / 8), dim3(256), 0, stream, P);
     else hipLaunchKernelGGL(preprocess_kernel<false>, dim3((rw + 255) / 256, rh, B), dim3(256), 0, stream, P);
     return hipGetLastError();
 }
