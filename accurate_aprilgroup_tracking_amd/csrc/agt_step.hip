@@ -22,8 +22,12 @@ namespace {
 
 constexpr int STEP_THREADS = 256;
 
-template <int WIN, int NW, int NLEV>
-__global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams S, const AgtStepTables T)
+// PNP = false: the launch carries no PnP role (big batches: the FP64 solver's 256 VGPRs would cap every role at
+// one workgroup per CU; it then runs as its own launch right behind this one)
+// OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).  The one-wave-per-corner
+// LK role of big batches wants 3, as the stand-alone LK kernel has.
+template <int WIN, int NW, int NLEV, bool PNP, int OCC>
+__global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void step_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     // The per-frame tables (second argument) are indexed with run-time frame numbers; they are read straight
@@ -35,7 +39,7 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
     // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
     // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
     int blk = blockIdx.x;
-    if (blk < S.n_pnp) {
+    if (PNP && blk < S.n_pnp) {
         if (threadIdx.x >= AGT_WAVE) return;
         agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
         // consecutive frames of stream `blk`: frame k+1 starts from the tracker state frame k left in
@@ -54,7 +58,7 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
         }
         return;
     }
-    blk -= S.n_pnp;
+    if (PNP) blk -= S.n_pnp;
     if (blk < S.n_lk) {
         // NW = 4: the workgroup is one corner; NW = 1: each wave is its own corner
         constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
@@ -98,7 +102,7 @@ __global__ __launch_bounds__(STEP_THREADS) void step_kernel(const AgtStepParams 
         return;
     }
     blk -= S.n_lk;
-    int base = S.n_pnp + S.n_lk;              // workgroup index of the stage's first tile
+    int base = (PNP ? S.n_pnp : 0) + S.n_lk;  // workgroup index of the stage's first tile
 #pragma unroll
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) {
         if (blk < S.n_pyr[s]) {
@@ -141,8 +145,15 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     }
     if (P.n_pnp > 0) { blocks += P.n_pnp; lds = lds > sizeof(agt_pnp::PnpShared) ? lds : sizeof(agt_pnp::PnpShared); }
     if (blocks == 0) return hipSuccess;
-    if (P.lk.max_level < 3) hipLaunchKernelGGL((step_kernel<WIN, NW, 3>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-    else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    const bool small = P.lk.max_level < 3;
+    if (P.n_pnp > 0) {
+        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    } else {
+        constexpr int OCC = NW == 1 ? 3 : 1;
+        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, false, OCC>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, false, OCC>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    }
     return hipGetLastError();
 }
 
@@ -151,9 +162,15 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 bool agt_step_supported(int win) { return win == 21; }
 bool agt_step_fits(int n, int B)
 {
-    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 128L; }();   // tuning knob
+    // measured (48 corners per stream): PnP inside the launch wins up to 4-5 streams (22 us/step at 4), from 8 on
+    // its register budget serialises the other roles and the two-launch form is faster
+    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 256L; }();   // tuning knob
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
+
+// two-launch form (pyramid + LK fused, PnP behind): measured faster than separate kernels up to ~32 streams of 48
+// corners (58 vs 67 us/step), slower at 64 (93 vs 85: the LK role then fills the chip on its own)
+bool agt_step_batch_fits(int n, int B) { return (long)n * B <= 2048; }
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win)
 {
