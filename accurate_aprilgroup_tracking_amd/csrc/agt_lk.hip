@@ -1,4 +1,5 @@
 // agt_lk.hip -- stand-alone cv::calcOpticalFlowPyrLK launch (body and design notes: agt_lk_body.h).
+#include <cstdlib>
 #include "agt_lk_body.h"
 
 namespace {
@@ -30,7 +31,11 @@ bool agt_lk_window_supported(int win) { return win == 21 || win == 15 || win == 
 
 // waves per corner: 4 while the launch cannot fill the chip with single-wave corners (latency
 // matters), 1 for large batches (throughput matters)
-bool agt_lk_wide(int n, int B) { return (long)n * B <= 1024; }
+bool agt_lk_wide(int n, int B)
+{
+    static const long cap = [] { const char* e = getenv("AGT_LK_WIDE_MAX"); return e ? atol(e) : 1024L; }();   // tuning knob
+    return (long)n * B <= cap;
+}
 
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B)
 {

@@ -35,3 +35,10 @@ def seq720():
 def seq640_dist():
     from accurate_aprilgroup_tracking_amd import synthetic as syn
     return syn.Sequence(640, 480, n_tags=12, n_frames=4, seed=2, dist=syn.MILD_DIST)
+
+
+@pytest.fixture(scope="session")
+def seq1080():
+    """BASELINE.json configs[3] geometry: one 1920x1080 stream (the 8-GPU config shards eight of them)."""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    return syn.Sequence(1920, 1080, n_tags=12, n_frames=5, seed=4, supersample=2)

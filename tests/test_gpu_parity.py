@@ -73,6 +73,13 @@ def test_lk_bit_exact_720(cvh, oracle, seq720):
     _assert_lk_equal(o, g)
 
 
+def test_lk_bit_exact_1080(cvh, oracle, seq1080):
+    """BASELINE.json configs[3] frame size"""
+    o, g = _lk_both(cvh, oracle, seq1080.frame(0), seq1080.frame(1), seq1080.corners(0), maxLevel=2)
+    _assert_lk_equal(o, g)
+    assert o[1].sum() == 48
+
+
 def test_lk_edge_cases(cvh, oracle, seq640):
     """points near / outside the border, flat regions (minEig reject), big jumps, level early-stop"""
     a, b = seq640.frame(0), seq640.frame(2)
