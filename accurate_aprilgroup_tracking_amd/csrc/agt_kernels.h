@@ -71,6 +71,7 @@ struct AgtTrackState {
     double prev[6];         // prev_transform
     double rot_vel[2][9];   // rot_velocities (oldest first)
     double tran_vel[2][3];  // tran_velocities
+    double prev_R[9];       // Rodrigues(prev rvec), kept from the solve that produced prev (device cache, not reference state)
     int has_guess;          // extrinsic_guess[0] is not None
     int has_prev;           // prev_transform[0] is not None
     int n_vel;              // len(rot_velocities)

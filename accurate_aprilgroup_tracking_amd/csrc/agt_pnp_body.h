@@ -17,6 +17,7 @@
 // kernel per batch of B independent problems.
 #pragma once
 #include <type_traits>
+#include <cstddef>
 #include "agt_device.h"
 #include "agt_kernels.h"
 
@@ -110,6 +111,21 @@ __device__ __forceinline__ void bfly_stage(double (&v)[32], bool upper)
         v[i] = keep + ddpp<CTRL>(send);
     }
 }
+// one double per lane summed over the wave, the total in every lane: four DPP row steps, then the two cross-row
+// steps with the gfx950 lane swaps (no LDS crossbar: __shfl_xor costs two ds_bpermute per step)
+__device__ __forceinline__ double wave_sum_f64(double v)
+{
+    v += ddpp<0xB1>(v);            // quad_perm [1,0,3,2]
+    v += ddpp<0x4E>(v);            // quad_perm [2,3,0,1]
+    v += ddpp<0x141>(v);           // row_half_mirror
+    v += ddpp<0x140>(v);           // row_mirror: every lane holds its row's sum
+    double o;
+    const double a = dswap16(v, v, o);     // a: (r0, r0, r2, r2), o: (r1, r1, r3, r3) per row
+    v = a + o;
+    const double c = dswap32(v, v, o);     // c: lower-half sums everywhere, o: upper-half sums
+    return c + o;
+}
+
 // vals[K] (K <= 32) summed over the wave; totals to sh.tot[0..K).  Ends with a barrier.
 template <int K>
 __device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpShared& sh, int lane)
@@ -129,13 +145,6 @@ __device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpSha
     __syncthreads();                               // earlier readers of sh.tot are done
     if (!(lane & 1) && (lane >> 1) < K) sh.tot[lane >> 1] = tot;
     __syncthreads();
-}
-
-__device__ __forceinline__ double wave_sum_f64(double v)
-{
-#pragma unroll
-    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
-    return v;
 }
 
 template <typename T>
@@ -232,16 +241,15 @@ __device__ inline void mat3_tvec(const double A[9], const double v[3], double o[
 // apply_vel_acc (303-349).  curr/prev = (rvec, tvec).  Called by EVERY lane of the wave with
 // uniform arguments (ts_in = the state as read before this frame); lane 0 stores the result.
 // Returns AGT_TRK_* flags (uniform).
+// Rc = Rodrigues(curr rvec) is the rotation of the solve's last evaluation; Rp = Rodrigues(prev rvec) was kept
+// from the solve that produced prev (AgtTrackState::prev_R).  `st` = LDS copy of { rot_vel[2][9], tran_vel[2][3],
+// prev_R[9] } taken when the solve started (the global loads are long done by now).
 __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const double curr[6], bool curr_t_f32,
-                                          const double prev[6], bool prev_t_f32)
+                                          const double prev[6], bool prev_t_f32, const double Rc[9], const double* st)
 {
-    // Rodrigues(prev) on lane 0, Rodrigues(curr) elsewhere: one pass for both
-    double rin[3], Rl[9], Rp[9], Rc[9];
+    double Rp[9];
 #pragma unroll
-    for (int i = 0; i < 3; i++) rin[i] = lane == 0 ? prev[i] : curr[i];
-    agt_rodrigues<false>(rin, Rl, nullptr);
-#pragma unroll
-    for (int i = 0; i < 9; i++) { Rp[i] = lane_bcast(Rl[i], 0); Rc[i] = lane_bcast(Rl[i], 1); }
+    for (int i = 0; i < 9; i++) Rp[i] = st[24 + i];
     // get_relative_trans (transform_helper.py:184): rot_mat.T @ (tvec0 - tvec1); numpy subtracts in
     // float32 when both operands are float32 arrays
     double d[3], tran_vel[3], rot_vel[9];
@@ -261,9 +269,9 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
     double old_rv[9], old_tv[3];
     const int old_slot = n_before >= 2 ? 1 : 0;  // the entry that becomes "previous velocity"
 #pragma unroll
-    for (int i = 0; i < 9; i++) old_rv[i] = ts->rot_vel[old_slot][i];
+    for (int i = 0; i < 9; i++) old_rv[i] = st[old_slot * 9 + i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) old_tv[i] = ts->tran_vel[old_slot][i];
+    for (int i = 0; i < 3; i++) old_tv[i] = st[18 + old_slot * 3 + i];
     const int n_after = n_before >= 2 ? 2 : n_before + 1;
     if (lane == 0) {
         if (n_before >= 2) {
@@ -360,6 +368,10 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         use_guess = had_guess && P.enhance_ape;
 #pragma unroll
         for (int i = 0; i < 6; i++) { unchanged_prev[i] = ts->prev[i]; param[i] = ts->guess[i]; }
+        // velocities and prev_R for the motion model: requested now, read from LDS after the solve
+        static_assert(offsetof(AgtTrackState, tran_vel) - offsetof(AgtTrackState, rot_vel) == 18 * sizeof(double) &&
+                      offsetof(AgtTrackState, prev_R) - offsetof(AgtTrackState, rot_vel) == 24 * sizeof(double), "state layout");
+        if (had_guess && P.enhance_ape && lane < 33) sh.vec[lane] = (&ts->rot_vel[0][0])[lane];
         if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
             if (lane == 0) {
                 ts->has_guess = 0; ts->frame++;
@@ -760,7 +772,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
         }
         if (accepted && had_guess && P.enhance_ape)
-            tflags |= motion_model_update(ts, lane, param, tvec_f32, unchanged_prev, prev_f32 != 0);
+            tflags |= motion_model_update(ts, lane, param, tvec_f32, unchanged_prev, prev_f32 != 0, Rlast, sh.vec);
         if (lane == 0) {
             if (accepted) {
                 if (!had_guess || !P.enhance_ape) {
@@ -769,6 +781,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 }
                 if (!(tflags & AGT_TRK_ZERO_VELOCITY)) {
                     for (int i = 0; i < 6; i++) ts->prev[i] = param[i];
+                    for (int i = 0; i < 9; i++) ts->prev_R[i] = Rlast[i];
                     ts->prev_t_f32 = tvec_f32 ? 1 : 0; ts->has_prev = 1;
                 }
             } else {

@@ -17,7 +17,7 @@ from .cv_hip import Context, _ptr, _host_f64
 class TrackState(C.Structure):
     """Mirror of csrc/agt_kernels.h AgtTrackState (tests read it back)."""
     _fields_ = [("guess", C.c_double * 6), ("prev", C.c_double * 6), ("rot_vel", (C.c_double * 9) * 2),
-                ("tran_vel", (C.c_double * 3) * 2), ("has_guess", C.c_int), ("has_prev", C.c_int),
+                ("tran_vel", (C.c_double * 3) * 2), ("prev_R", C.c_double * 9), ("has_guess", C.c_int), ("has_prev", C.c_int),
                 ("n_vel", C.c_int), ("frame", C.c_int), ("guess_t_f32", C.c_int), ("prev_t_f32", C.c_int),
                 ("pad", C.c_int * 2)]
 
