@@ -58,6 +58,8 @@ struct LkCfg {
     static constexpr int NSD = (DW * DW + T - 1) / T;   // derivative positions per thread
     // int32 partial sums stay exact over 2^SUM_STEPS lanes: NPX * 8160 * 4080 * 2^S < 2^31
     static constexpr int SUM_STEPS = NPX <= 2 ? 4 : (NPX <= 8 ? 3 : 2);
+    // the pair-packed reduction of the two mismatch sums adds one more lane doubling before the 4 row steps
+    static constexpr bool PAIR_OK = (long long)NPX * 8160 * 4080 * 32 < (1LL << 31);
     static_assert((long long)NPX * 8160 * 4080 * (1 << SUM_STEPS) < (1LL << 31), "int32 partial sums could overflow");
     static_assert(LEVEL_LDS % 16 == 0, "keep per-level slots 16-byte aligned");
 };
@@ -148,12 +150,26 @@ __device__ __forceinline__ long long wave_sum_exact(int v)
 }
 
 // Exact sum over the whole workgroup of NV ints per thread; identical in every thread.
-template <int NW, int STEPS, int NV>
+template <int NW, int STEPS, int NV, bool PAIR_OK = false>
 __device__ __forceinline__ void block_sum_exact(const int (&v)[NV], long long (&out)[NV], long long* slots, int& phase,
                                                 int wave, int lane)
 {
+    if constexpr (NV == 2 && PAIR_OK) {
+        // two sums in one chain: v_permlane32_swap leaves { v0 of lanes 0-31 | v1 of lanes 0-31 } and { v0 of lanes
+        // 32-63 | v1 of lanes 32-63 } side by side, so one add gives pair sums of v0 in the lower half-wave and of v1
+        // in the upper one; four DPP row steps (still < 2^31, checked by the caller's PAIR_OK) and four readlanes follow
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v[0], (unsigned)v[1], false, false);
+        int x = (int)sw[0] + (int)sw[1];
+        x += agt_dpp_i32<0xB1>(x);
+        x += agt_dpp_i32<0x4E>(x);
+        x += agt_dpp_i32<0x141>(x);
+        x += agt_dpp_i32<0x140>(x);
+        out[0] = (long long)__builtin_amdgcn_readlane(x, 0) + (long long)__builtin_amdgcn_readlane(x, 16);
+        out[1] = (long long)__builtin_amdgcn_readlane(x, 32) + (long long)__builtin_amdgcn_readlane(x, 48);
+    } else {
 #pragma unroll
-    for (int i = 0; i < NV; i++) out[i] = wave_sum_exact<STEPS>(v[i]);
+        for (int i = 0; i < NV; i++) out[i] = wave_sum_exact<STEPS>(v[i]);
+    }
     if (NW > 1) {
         long long* s = slots + phase * (NW * 4);
         if (lane == 0) {
@@ -400,7 +416,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
             window_pass(inx, iny, false, bsum);
             if (j == 1) STAMP(42);
             long long bt[2];
-            block_sum_exact<NW, C::SUM_STEPS, 2>(bsum, bt, slots, phase, wave, lane);
+            block_sum_exact<NW, C::SUM_STEPS, 2, C::PAIR_OK>(bsum, bt, slots, phase, wave, lane);
             if (j == 1) STAMP(43);
             const float fb1 = (float)(double)bt[0] * FLT_SCALE;
             const float fb2 = (float)(double)bt[1] * FLT_SCALE;
