@@ -20,7 +20,7 @@ def init(backend=None):
     rank, local_rank, world = env_rank()
     if world > 1 and not dist.is_initialized():
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
+            backend = os.environ.get("AGT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
@@ -42,6 +42,12 @@ def gather_poses(local, world=None):
         return local.unsqueeze(0)
     world = dist.get_world_size()
     local = local.contiguous()
+    if local.is_cuda and dist.get_backend() == "gloo":
+        # rehearsal of the multi-rank flow without RCCL (several ranks sharing one GPU): gather on the host
+        host = local.cpu()
+        out = torch.empty((world * host.shape[0],) + tuple(host.shape[1:]), dtype=host.dtype)
+        dist.all_gather_into_tensor(out, host)
+        return out.view((world,) + tuple(host.shape)).to(local.device)
     # concatenated along dim 0 (the layout both RCCL and gloo accept), viewed as [world, ...]
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)
@@ -56,6 +62,6 @@ def barrier():
 def max_over_ranks(value, device):
     if not dist.is_initialized() or dist.get_world_size() == 1:
         return value
-    t = torch.tensor([value], dtype=torch.float64, device=device)
+    t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())

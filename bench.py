@@ -133,8 +133,9 @@ def main():
     from accurate_aprilgroup_tracking_amd import distributed as D
     rank, local_rank, world = D.init()
     assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    dev_index = local_rank % max(torch.cuda.device_count(), 1)     # > 1 rank per GPU only in gloo rehearsals (AGT_DIST_BACKEND)
+    torch.cuda.set_device(dev_index)
+    dev = torch.device("cuda", dev_index)
 
     from accurate_aprilgroup_tracking_amd import hiplib as HL, synthetic as syn
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
