@@ -296,10 +296,21 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
     if (lane == 0) { ay = sing ? -rot_acc[5] : rot_acc[7]; ax = sing ? rot_acc[4] : rot_acc[8]; }
     else if (lane == 1) { ay = -rot_acc[6]; ax = sy; }
     else { ay = sing ? 0.0 : rot_acc[3]; ax = sing ? 1.0 : rot_acc[0]; }
-    const double ang = atan2(ay, ax) * 0.5;      // apply_vel_acc halves the Euler angles
-    // euler_angles_to_rotation_matrix (transform_helper.py:215-236): R = Rz Ry Rx, three sincos on three lanes
+    // apply_vel_acc halves the Euler angles and euler_angles_to_rotation_matrix (transform_helper.py:215-236,
+    // R = Rz Ry Rx) only needs sin / cos of the halves: with (c, s) = (ax, ay) / |(ax, ay)| = (cos, sin) of
+    // atan2(ay, ax), the half-angle identities give them without atan2 + sincos (two transcendental chains less):
+    //   c >= 0:  cos(t/2) = sqrt((1 + c) / 2),  sin(t/2) = s / (2 cos(t/2))
+    //   c <  0:  sin(t/2) = copysign(sqrt((1 - c) / 2), ay),  cos(t/2) = |s| / (2 |sin(t/2)|)
+    // (atan2's range (-pi, pi] makes cos(t/2) >= 0; atan2(+-0, negative) = +-pi keeps the sign of ay.)
     double sn, cs;
-    sincos(ang, &sn, &cs);
+    {
+        const double r = sqrt(ax * ax + ay * ay);
+        if (r > 0.0) {
+            const double ir = 1.0 / r, c = ax * ir, sv = ay * ir;
+            if (c >= 0.0) { cs = sqrt(0.5 * (1.0 + c)); sn = sv / (2.0 * cs); }
+            else { const double a = sqrt(0.5 * (1.0 - c)); sn = copysign(a, ay); cs = fabs(sv) / (2.0 * a); }
+        } else { cs = 1.0; sn = 0.0; }
+    }
     const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0);
     const double sy2 = lane_bcast(sn, 1), cy = lane_bcast(cs, 1);
     const double sz = lane_bcast(sn, 2), cz = lane_bcast(cs, 2);
