@@ -154,7 +154,7 @@ template <int NW, int STEPS, int NV, bool PAIR_OK = false>
 __device__ __forceinline__ void block_sum_exact(const int (&v)[NV], long long (&out)[NV], long long* slots, int& phase,
                                                 int wave, int lane)
 {
-    if constexpr (NV == 2 && PAIR_OK) {
+    if constexpr ((NV == 2 || NV == 3) && PAIR_OK) {
         // two sums in one chain: v_permlane32_swap leaves { v0 of lanes 0-31 | v1 of lanes 0-31 } and { v0 of lanes
         // 32-63 | v1 of lanes 32-63 } side by side, so one add gives pair sums of v0 in the lower half-wave and of v1
         // in the upper one; four DPP row steps (still < 2^31, checked by the caller's PAIR_OK) and four readlanes follow
@@ -166,6 +166,7 @@ __device__ __forceinline__ void block_sum_exact(const int (&v)[NV], long long (&
         x += agt_dpp_i32<0x140>(x);
         out[0] = (long long)__builtin_amdgcn_readlane(x, 0) + (long long)__builtin_amdgcn_readlane(x, 16);
         out[1] = (long long)__builtin_amdgcn_readlane(x, 32) + (long long)__builtin_amdgcn_readlane(x, 48);
+        if constexpr (NV == 3) out[2] = wave_sum_exact<STEPS>(v[2]);
     } else {
 #pragma unroll
         for (int i = 0; i < NV; i++) out[i] = wave_sum_exact<STEPS>(v[i]);
@@ -362,7 +363,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
             asum[0] += __mul24(Ix[k], Ix[k]); asum[1] += __mul24(Ix[k], Iy[k]); asum[2] += __mul24(Iy[k], Iy[k]);
         }
         long long at[3];
-        block_sum_exact<NW, C::SUM_STEPS, 3>(asum, at, slots, phase, wave, lane);
+        block_sum_exact<NW, C::SUM_STEPS, 3, C::PAIR_OK>(asum, at, slots, phase, wave, lane);     // |Ix Iy| <= 4080^2 < 8160 * 4080
         const float A11 = (float)(double)at[0] * FLT_SCALE;
         const float A12 = (float)(double)at[1] * FLT_SCALE;
         const float A22 = (float)(double)at[2] * FLT_SCALE;
