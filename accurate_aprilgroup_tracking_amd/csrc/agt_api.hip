@@ -492,36 +492,22 @@ static int launch_group(agt_ctx* c, int B)
         c->n_lk += cnt;
         any = true;
     }
-    // The PnP role rides in the fused launch while few corners are in flight (every role is latency-bound then).
-    // For big batches its 256 VGPRs would cap the other roles at one workgroup per CU, so it follows as its own
-    // launch(es) on the same stream -- the pyramid and LK roles still share one chip-filling launch.
-    const bool pnp_inside = agt_step_fits(c->trk_n, B);
-    long pnp_cnt = 0, pnp_first = 0;
     if (c->n_pnp < lk_before) {
-        pnp_cnt = lk_before - c->n_pnp;
-        if (pnp_cnt > F) pnp_cnt = F;
-        pnp_first = c->n_pnp + 1;
-        if (pnp_inside) {
-            const int slot = (int)(pnp_first % M);
-            fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
-            for (long k = 0; k < pnp_cnt; k++) {
-                const int q = (int)((pnp_first + k) % M);
-                T.pnp.img[k] = c->corners[q]; T.pnp.mask[k] = c->status[q]; T.pnp.so[k] = c->so_ring[q];
-            }
-            S.pnp_nf = (int)pnp_cnt;
-            S.n_pnp = B;
+        long cnt = lk_before - c->n_pnp;
+        if (cnt > F) cnt = F;
+        const int slot = (int)((c->n_pnp + 1) % M);
+        fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
+        for (long k = 0; k < cnt; k++) {
+            const int q = (int)((c->n_pnp + 1 + k) % M);
+            T.pnp.img[k] = c->corners[q]; T.pnp.mask[k] = c->status[q]; T.pnp.so[k] = c->so_ring[q];
         }
-        c->n_pnp += pnp_cnt;
+        S.pnp_nf = (int)cnt;
+        S.n_pnp = B;
+        c->n_pnp += cnt;
         any = true;
     }
     if (!any) return AGT_OK;
     hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win);
-    for (long k = 0; k < pnp_cnt && !pnp_inside && e == hipSuccess; k++) {
-        const int q = (int)((pnp_first + k) % M);
-        AgtPnpParams p;
-        fill_estimate(c, &p, c->corners[q], c->status[q], c->so_ring[q], nullptr);
-        e = agt_launch_pnp(c->stream, p, B);
-    }
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
@@ -579,7 +565,7 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
     // the fused launch pays off while the stages are latency-bound (few streams); the biggest batches fill
     // the chip per stage and run faster as separate launches with their own register budgets
-    if (c->pipeline && !c->reproject && agt_step_batch_fits(c->trk_n, B)) {
+    if (c->pipeline && !c->reproject && agt_step_fits(c->trk_n, B)) {
         // fused launch: the three spans collapse into one (span 2 = the whole step_kernel launch)
         if (pev) { (void)hipEventRecord(pev[0], c->stream); (void)hipEventRecord(pev[1], c->stream); (void)hipEventRecord(pev[2], c->stream); }
         int rc = step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);

@@ -145,6 +145,5 @@ int agt_dense_blocks(int M);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
-bool agt_step_fits(int n, int B);         // PnP role inside the fused launch (small, latency-bound launches)
-bool agt_step_batch_fits(int n, int B);   // fused pyramid + LK launch with PnP as its own launch behind it
+bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used up to 2048 corners in flight
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win);

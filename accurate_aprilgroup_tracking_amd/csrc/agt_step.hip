@@ -22,8 +22,6 @@ namespace {
 
 constexpr int STEP_THREADS = 256;
 
-// PNP = false: the launch carries no PnP role (big batches: the FP64 solver's 256 VGPRs would cap every role at
-// one workgroup per CU; it then runs as its own launch right behind this one)
 // OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).  The one-wave-per-corner
 // LK role of big batches wants 3, as the stand-alone LK kernel has.
 template <int WIN, int NW, int NLEV, bool PNP, int OCC>
@@ -146,13 +144,15 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (P.n_pnp > 0) { blocks += P.n_pnp; lds = lds > sizeof(agt_pnp::PnpShared) ? lds : sizeof(agt_pnp::PnpShared); }
     if (blocks == 0) return hipSuccess;
     const bool small = P.lk.max_level < 3;
-    if (P.n_pnp > 0) {
+    // OCC = 1: the FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU,
+    // best while <= 256 corners are in flight.  OCC = 2: registers capped at 256 (336 B of scratch for the PnP
+    // role), two workgroups per CU: +0.4 us on one stream, but 8 / 32 streams run at 23 / 49 us per step.
+    if ((long)P.lk.n * P.lk_B <= 256 || P.n_lk == 0) {
         if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
         else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     } else {
-        constexpr int OCC = NW == 1 ? 3 : 1;
-        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, false, OCC>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, false, OCC>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 2>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 2>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     }
     return hipGetLastError();
 }
@@ -160,17 +160,14 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 }  // namespace
 
 bool agt_step_supported(int win) { return win == 21; }
+// Fused launch (all roles in one kernel) up to 2048 corners in flight, measured on 48-corner streams: 1 / 4 / 8 / 16 /
+// 32 streams take 20 / 22 / 23 / 42 / 49 us per step against 41 / 42 / 46 / 53 / 67 as separate kernels; at 64 streams
+// (94 vs 85) the one-wave-per-corner LK role wants more than the two waves per SIMD the fused launch can hold.
 bool agt_step_fits(int n, int B)
 {
-    // measured (48 corners per stream): PnP inside the launch wins up to 4-5 streams (22 us/step at 4), from 8 on
-    // its register budget serialises the other roles and the two-launch form is faster
-    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 256L; }();   // tuning knob
+    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 2048L; }();   // tuning knob
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
-
-// two-launch form (pyramid + LK fused, PnP behind): measured faster than separate kernels up to ~32 streams of 48
-// corners (58 vs 67 us/step), slower at 64 (93 vs 85: the LK role then fills the chip on its own)
-bool agt_step_batch_fits(int n, int B) { return (long)n * B <= 2048; }
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win)
 {

@@ -148,7 +148,7 @@ def main():
     render_s = time.time() - t_r
     sq0 = seqs[0]
     trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
-    fused = B * NPTS <= 256            # PnP role inside the fused launch (agt_step_fits)
+    fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
     depth = max(1, min(args.depth, 8)) if fused else 1
     trk.pipeline(depth)
     fps, dt, state, gathered, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world)
