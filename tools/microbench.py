@@ -10,7 +10,7 @@ from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
 W, H = 1280, 720
 seq = syn.Sequence(W, H, n_frames=8, seed=0, supersample=2)
 fr = torch.from_numpy(seq.frames()).cuda()
-for B, pipe in [(b, p) for b in (1, 2, 4, 8, 16, 32, 64) for p in (0, 1)]:
+for B, pipe in [(b, p) for b in (1, 2, 4, 8, 16, 32, 64, 128) for p in (0, 1)]:
     ring = torch.stack([fr[(i % 8) if (i // 8) % 2 == 0 else 7 - (i % 8)].unsqueeze(0).expand(B, H, W) for i in range(32)]).contiguous()
     trk = StreamTracker(W, H, seq.obj, seq.K, None, n_streams=B)
     trk.pipeline(pipe)
