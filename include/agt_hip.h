@@ -159,14 +159,17 @@ int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const floa
  * min_points: corners needed to attempt a pose (default 8 = the reference's >= 2 tags, detect_pose.py:494-496).
  * gate_px: reprojection gate (default 2.0, detect_pose.py:539). */
 int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate_px);
-/* Software pipelining across frames (default on when reproject == 0): agt_track_frame issues ONE
- * fused launch in which pyramid stage s works on frame t-s, LK on frame t-(L-1) and PnP on frame
- * t-L (L = pyramid stages), so a step costs max(stage) instead of their sum; results are
- * bit-identical to the serial order.  Frame t's state record is therefore written L+1 calls
- * later; agt_tracker_join enqueues the remaining stages of all supplied frames (no host
- * synchronisation) and agt_synchronize joins and waits.  Frames handed to agt_track_frame must
- * stay valid until their pose has been produced (at most 4 frames are in flight). */
-int agt_tracker_pipeline(agt_ctx* ctx, int enable);
+/* Software pipelining across frames.  depth 0: separate launches per stage, the record of frame t is complete
+ * in stream order after its call.  depth F in 1..8 (default 1; needs reproject == 0 and at most 2048 corners in
+ * flight, otherwise the call falls back to depth 0 behaviour): agt_track_frame registers the frame and, every F
+ * calls, issues ONE fused launch in which every pipeline stage advances by F frames -- pyramid stage s works on
+ * frames t-sF.., LK on frames t-LF.., PnP on frames t-(L+1)F.. (L = pyramid stages) -- so a step costs max(stage)
+ * instead of their sum and the launch boundary is paid once per F frames; results are bit-identical to the serial
+ * order.  Frame t's state record is written about (L+2)*F calls later; agt_tracker_join enqueues the remaining
+ * stages of all supplied frames (no host synchronisation) and agt_synchronize joins and waits.  Frames handed to
+ * agt_track_frame must stay valid and unmodified until their pose has been produced ((L+2)*F + F frames are in
+ * flight at most), and the frames of one group must share pitch and batch stride.  Changing the depth joins first. */
+int agt_tracker_pipeline(agt_ctx* ctx, int depth);
 int agt_tracker_join(agt_ctx* ctx);
 /* PoseDetector._estimate_pose (detect_pose.py:467-574) for B streams with device-resident
  * state: d_img [B][n][2] f32 corners (detector- or LK-supplied), d_mask [B][n] u8 or NULL.
