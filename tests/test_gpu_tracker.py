@@ -306,3 +306,32 @@ def test_stream_1080p_and_240_corners(torch_cuda, oracle, seq1080):
                 assert st[k - 1, 0, H.ST_OK] == 1
                 assert np.abs(st[k - 1, 0, :3] - seq.rvecs[k]).max() < 3e-3 and np.abs(st[k - 1, 0, 3:6] - seq.tvecs[k]).max() < 3e-3
             pts = nx.astype(np.float32); pyr = npyr
+
+
+def test_group_with_changing_frame_pitch(torch_cuda, seq640):
+    """frames of one launch group must share pitch and batch stride; a stream that alternates between tight and padded
+    frame buffers makes the library cut its groups short -- the records stay those of the serial order"""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    H, W = s.height, s.width
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3]
+    padded = torch.zeros((len(order), 1, H, W + 64), dtype=torch.uint8, device="cuda")
+    outs = []
+    for depth in (0, 4):
+        trk = StreamTracker(W, H, s.obj, s.K, None, n_streams=1)
+        trk.pipeline(depth)
+        trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+        so = trk.new_state_buffer(len(order))
+        for i, k in enumerate(order):
+            if i % 3 == 1 or i in (10, 11, 12, 13, 14):
+                padded[i, 0, :, :W] = frames[k]
+                f = padded[i, :, :, :W]                     # pitch W + 64
+            else:
+                f = frames[k:k + 1]
+            trk.step(f, so[i])
+        trk.join()
+        outs.append(so.cpu().numpy())
+    assert np.array_equal(outs[0], outs[1])
+    assert outs[0][:, 0, 6].all()
