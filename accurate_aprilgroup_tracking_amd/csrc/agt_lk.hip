@@ -4,8 +4,10 @@
 
 namespace {
 
-template <int WIN, int NW, int NLEV>
-__global__ __launch_bounds__(AGT_WAVE * NW) void lk_kernel(const AgtLkParams P)
+// OCC: waves per SIMD the register allocation leaves room for.  The one-wave-per-corner 21x21 kernel sits 3
+// registers above the 128 that allow a fourth wave; big batches are throughput-bound, so it is held to 128.
+template <int WIN, int NW, int NLEV, int OCC>
+__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_kernel(const AgtLkParams P)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     agt_lk::LkFrameIo<NLEV> io;
@@ -20,8 +22,9 @@ hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p, int B)
 {
     const size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
     const dim3 grid(p.n, B), block(AGT_WAVE * NW);
-    if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS>), grid, block, lds, stream, p);
+    constexpr int OCC = (WIN == 21 && NW == 1) ? 4 : 1;
+    if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3, OCC>), grid, block, lds, stream, p);
+    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC>), grid, block, lds, stream, p);
     return hipGetLastError();
 }
 
@@ -40,6 +43,8 @@ bool agt_lk_wide(int n, int B)
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B)
 {
     switch (win) {
+    // (2 and 8 waves per corner were measured too: 2 loses to 1 on big batches -- 60 vs 42 us at 64 streams --, 8 loses
+    // to 4 on small ones -- 19.5 vs 17.8 us)
     case 21: return agt_lk_wide(p.n, B) ? launch_lk_t<21, 4>(stream, p, B) : launch_lk_t<21, 1>(stream, p, B);
     case 15: return launch_lk_t<15, 1>(stream, p, B);
     case 31: return launch_lk_t<31, 1>(stream, p, B);
