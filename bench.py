@@ -254,7 +254,7 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
         k = pingpong(n + 1, NF)
         pyr, pts, stt, er, cnt, r, t = cvo.track_frame(pyr, frames[k], pts, seq.obj, seq.K, None, r, t, nthreads=1)
         n += 1
-        if time.perf_counter() - t0 > 10.0 or n >= 4000:
+        if time.perf_counter() - t0 > 10.0 or n >= 20000:
             break
     dt = time.perf_counter() - t0
     # same chain with OpenMP over rows / points on every host core (as OpenCV's parallel_for_), ~5 s
