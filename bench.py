@@ -124,7 +124,9 @@ def main():
     ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (c2: 1, c3: 64)")
     ap.add_argument("--render-frames", type=int, default=24)
-    ap.add_argument("--depth", type=int, default=4, help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency)")
+    ap.add_argument("--depth", type=int, default=0,
+                    help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = 4 for >= 100 timed steps, "
+                         "2 for >= 40, else 1 (short runs are dominated by filling and draining the pipeline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-batch-extra", action="store_true", help="skip the 64-stream HBM-bound side measurement")
     args = ap.parse_args()
@@ -149,7 +151,8 @@ def main():
     sq0 = seqs[0]
     trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
-    depth = max(1, min(args.depth, 8)) if fused else 1
+    auto_depth = 4 if args.steps >= 100 else (2 if args.steps >= 40 else 1)
+    depth = max(1, min(args.depth or auto_depth, 8)) if fused else 1
     trk.pipeline(depth)
     fps, dt, state, gathered, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world)
     st = state.cpu().numpy()
@@ -158,7 +161,7 @@ def main():
 
     if rank == 0:
         ab = algorithmic_bytes()
-        M = min(K, 200) // depth * depth
+        M = max(depth, min(K, 200) // depth * depth)      # instrumented passes: whole launch groups, at least one
         # per-launch durations from HIP events on the launch stream, second (instrumented) pass
         stage_us = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, False)     # separate kernels
         names = ["pyramid", "lk", "pnp"]
