@@ -335,3 +335,32 @@ def test_group_with_changing_frame_pitch(torch_cuda, seq640):
         outs.append(so.cpu().numpy())
     assert np.array_equal(outs[0], outs[1])
     assert outs[0][:, 0, 6].all()
+
+
+def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
+    """BASELINE.json configs[2] size (64 x 1280x720 per step): every stream of a 64-stream batch (separate-kernel path,
+    one wave per corner) must produce bit-for-bit the record a single stream gets from the fused step (four waves per
+    corner, PnP role in the launch) -- the results may not depend on batching, kernel variant or pipelining."""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq720
+    frames = torch.from_numpy(s.frames()).cuda()
+    F = len(s)
+    order = list(range(1, F)) + list(range(F - 2, -1, -1)) + list(range(1, F))
+    recs = {}
+    for B, depth in ((1, 4), (64, 1), (8, 2)):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+        trk.pipeline(depth)
+        rep = lambda k: frames[k].unsqueeze(0).expand(B, -1, -1).contiguous()
+        trk.reset(rep(0), torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous())
+        so = trk.new_state_buffer(len(order))
+        keep = []
+        for i, k in enumerate(order):
+            f = rep(k); keep.append(f)
+            trk.step(f, so[i] if len(order) > 1 else so)
+        trk.join()
+        recs[B] = so.cpu().numpy().reshape(len(order), B, -1)
+    for B in (64, 8):
+        for b in range(B):
+            assert np.array_equal(recs[B][:, b], recs[1][:, 0]), "stream %d of %d" % (b, B)
+    assert recs[1][:, 0, 6].all()
