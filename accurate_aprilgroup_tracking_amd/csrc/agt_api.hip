@@ -30,6 +30,11 @@ struct agt_ctx {
     int pipeline;                            // 1 = software-pipelined fused step (agt_step.hip)
     int group;                               // frames per fused launch (1..AGT_MAX_GROUP)
     int live_ring;                           // ring modulus in use (<= ring): (L + 2) * group, at least AGT_SLOTS
+    // big batches: the three stages of a step run on three library-owned streams (stage kernels of different frames
+    // overlap: 57 us against 93 us back to back at 64 streams); events carry the exact dependencies
+    hipStream_t ms_stream[3];                // pyramid, LK, PnP
+    hipEvent_t ms_ev[4][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done
+    int ms_ready, ms_active;                 // streams / events exist; frames are in flight on them
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
@@ -51,6 +56,8 @@ struct agt_ctx {
     hipEvent_t* prof_ev;
     int prof_cap, prof_n;
 };
+
+static int ms_join(agt_ctx* c);
 
 namespace {
 
@@ -163,6 +170,11 @@ int agt_destroy(agt_ctx* c)
         for (int l = 1; l < AGT_MAX_LEVELS; l++) if (c->lmem[s][l]) (void)hipFree(c->lmem[s][l]);
         if (c->corners[s]) (void)hipFree(c->corners[s]);
         if (c->status[s]) (void)hipFree(c->status[s]);
+    }
+    if (c->ms_ready) {
+        for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->ms_stream[i]);
+        for (int k = 0; k < 4; k++) for (int i = 0; i < AGT_RING_MAX; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
+        for (int i = 0; i < 3; i++) (void)hipStreamDestroy(c->ms_stream[i]);
     }
     if (c->lkerr) (void)hipFree(c->lkerr);
     if (c->obj) (void)hipFree(c->obj);
@@ -531,6 +543,7 @@ int agt_tracker_join(agt_ctx* c)
 {
     if (!c) return AGT_ERR_ARG;
     if (c->trk_ready != 2) return AGT_OK;
+    if (c->ms_active) return ms_join(c);
     while (c->n_pnp < c->trk_frame) {
         int rc = launch_group(c, c->trk_B);
         if (rc) return rc;
@@ -549,6 +562,94 @@ int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int
     fill_estimate(c, &p, d_img, d_mask, d_state_out, nullptr);
     hipError_t e = agt_launch_pnp(c->stream, p, B);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// Big batches: pyramid, LK and PnP of one frame as separate kernels on three library-owned streams.  The host runs
+// ahead, so the pyramid of frame t+1 overlaps the LK of frame t and the PnP of frame t-1; every true dependency
+// (and every buffer reuse of the rings) is an event wait, nothing is assumed about timing.
+static int ms_init(agt_ctx* c)
+{
+    if (c->ms_ready) return AGT_OK;
+    for (int i = 0; i < 3; i++)
+        if (hipStreamCreateWithFlags(&c->ms_stream[i], hipStreamNonBlocking) != hipSuccess) return hip_fail(c, hipGetLastError());
+    for (int k = 0; k < 4; k++)
+        for (int i = 0; i < AGT_RING_MAX; i++)
+            if (hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) return hip_fail(c, hipGetLastError());
+    c->ms_ready = 1;
+    return AGT_OK;
+}
+
+#define AGT_MS_RING 8            // ring entries in multi-stream mode
+#define AGT_MS_GAP 4             // buffer-reuse waits are issued every AGT_MS_GAP frames, on the events of AGT_MS_GAP frames ago
+
+static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+{
+    int rc = ms_init(c);
+    if (rc) return rc;
+    const bool first = !c->ms_active;
+    if (first && c->live_ring != AGT_MS_RING) {
+        // (the caller joined: only the newest frame is live) eight ring entries let the reuse waits be sparse
+        rc = ensure_ring(c, AGT_MS_RING);
+        if (rc) return rc;
+        ring_move(c, c->trk_frame, c->live_ring, AGT_MS_RING);
+        c->live_ring = AGT_MS_RING;
+    }
+    const int R = c->live_ring;
+    const long t = c->trk_frame + 1;
+    const int slot = (int)(t % R), pslot = (int)((t - 1) % R);
+    hipStream_t sA = c->ms_stream[0], sB = c->ms_stream[1], sC = c->ms_stream[2];
+    hipEvent_t *evU = c->ms_ev[0], *evA = c->ms_ev[1], *evB = c->ms_ev[2], *evC = c->ms_ev[3];
+    // HIP event calls cost ~4 us of host time each, so only the waits that carry a real dependency are issued:
+    //   every frame   caller -> pyramid (the frame data), pyramid -> LK, LK -> PnP
+    //   first frame   caller -> LK, PnP too (corners and tracker state written by agt_tracker_reset / earlier modes)
+    //   every 4th     the ring-reuse guards, on the events of 4 frames ago: pyramid(t..t+3) overwrite the entries of
+    //                 frames t-8..t-5, last read by LK(t-7..t-4); LK(t..t+3) overwrite corner entries last read by
+    //                 PnP(t-8..t-5); both are complete once LK(t-4) / PnP(t-4) are (streams run in order)
+    const bool guard = t % AGT_MS_GAP == 0 && t - AGT_MS_GAP >= 1;
+    const int gslot = (int)((t - AGT_MS_GAP) % R);
+    hipError_t e = hipEventRecord(evU[slot], c->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sA, evU[slot], 0);
+    if (e == hipSuccess && first) e = hipStreamWaitEvent(sB, evU[slot], 0);
+    if (e == hipSuccess && first) e = hipStreamWaitEvent(sC, evU[slot], 0);
+    if (e == hipSuccess && guard) e = hipStreamWaitEvent(sA, evB[gslot], 0);
+    // ... and the caller's stream falls in behind LK(t-4) as well: frames handed over 9 or more calls ago are then
+    // dead for every later operation on that stream, which is what a stream-ordered allocator needs to recycle them
+    if (e == hipSuccess && guard) e = hipStreamWaitEvent(c->stream, evB[gslot], 0);
+    if (e != hipSuccess) return hip_fail(c, e);
+    rc = pyramid_build_on(c, sA, slot, d_frames, pitch, batch_stride, B);
+    if (rc) return rc;
+    e = hipEventRecord(evA[slot], sA);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sB, evA[slot], 0);
+    if (e == hipSuccess && guard) e = hipStreamWaitEvent(sB, evC[gslot], 0);
+    if (e != hipSuccess) return hip_fail(c, e);
+    rc = lk_track_on(c, sB, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr,
+                     c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+    if (rc) return rc;
+    e = hipEventRecord(evB[slot], sB);
+    if (e == hipSuccess) e = hipStreamWaitEvent(sC, evB[slot], 0);
+    if (e != hipSuccess) return hip_fail(c, e);
+    AgtPnpParams p;
+    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, nullptr);
+    e = agt_launch_pnp(sC, p, B);
+    if (e == hipSuccess && t % AGT_MS_GAP == 0) e = hipEventRecord(evC[slot], sC);
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->trk_frame = t; c->n_lk = c->n_pnp = t;
+    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
+    c->ms_active = 1;
+    return AGT_OK;
+}
+
+// the caller's stream waits for everything in flight on the library's streams: PnP of the newest frame comes after
+// its LK, which comes after its pyramid, and each stream runs in order
+static int ms_join(agt_ctx* c)
+{
+    if (!c->ms_active) return AGT_OK;
+    hipEvent_t ev = c->ms_ev[3][AGT_RING_MAX - 1];                   // entry never used by a frame (ring <= 8)
+    hipError_t e = hipEventRecord(ev, c->ms_stream[2]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->ms_active = 0;
+    return AGT_OK;
 }
 
 // One frame for B streams.
@@ -571,6 +672,12 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
         int rc = step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);
         if (pev && rc == AGT_OK) { (void)hipEventRecord(pev[3], c->stream); c->prof_n++; }
         return rc;
+    }
+
+    if (c->pipeline && !c->reproject && !pev) {
+        // more corners in flight than the fused launch takes: stage kernels, overlapped across frames on three streams
+        if (!c->ms_active) { int rj = agt_tracker_join(c); if (rj) return rj; }
+        return step_multistream(c, d_frames, pitch, batch_stride, B, d_state_out);
     }
 
     int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first

@@ -338,15 +338,16 @@ def test_group_with_changing_frame_pitch(torch_cuda, seq640):
 
 
 def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
-    """BASELINE.json configs[2] size (64 x 1280x720 per step): every stream of a 64-stream batch (separate-kernel path,
-    one wave per corner) must produce bit-for-bit the record a single stream gets from the fused step (four waves per
-    corner, PnP role in the launch) -- the results may not depend on batching, kernel variant or pipelining."""
+    """BASELINE.json configs[2] size (64 x 1280x720 per step): every stream of a 64-stream batch (stage kernels on
+    three overlapped streams, one wave per corner, ring-reuse guards every 4th frame) must produce bit-for-bit the
+    record a single stream gets from the fused step (four waves per corner, PnP role in the launch) -- the results may
+    not depend on batching, kernel variant or pipelining."""
     torch = torch_cuda
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
     s = seq720
     frames = torch.from_numpy(s.frames()).cuda()
     F = len(s)
-    order = list(range(1, F)) + list(range(F - 2, -1, -1)) + list(range(1, F))
+    order = (list(range(1, F)) + list(range(F - 2, -1, -1))) * 6 + list(range(1, F))      # 39 steps, never synchronised
     recs = {}
     for B, depth in ((1, 4), (64, 1), (8, 2)):
         trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
