@@ -346,7 +346,9 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (n < 4 || n > c->cfg.max_points) return AGT_ERR_NPOINTS;
     if (B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
     if (d_corners && c->built_B[slot] < B) return AGT_ERR_STATE;
-    int rc = fill_camera(K, dist, ndist, &c->cam);
+    int rc = agt_tracker_join(c);            // frames of an earlier run still in flight (fused pipeline or library streams)
+    if (rc) return rc;
+    rc = fill_camera(K, dist, ndist, &c->cam);
     if (rc) return rc;
     hipError_t e = hipSuccess;
     // the tracker's frame 0 lives in ring entry 0: adopt the caller's slot as pyramid slot 0

@@ -361,6 +361,18 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
             trk.step(f, so[i] if len(order) > 1 else so)
         trk.join()
         recs[B] = so.cpu().numpy().reshape(len(order), B, -1)
+        if B == 64:
+            # a reset while frames are still in flight on the library's streams (no join, no sync) starts a clean run
+            for i, k in enumerate(order[:7]):
+                f = rep(k); keep.append(f)
+                trk.step(f, so[i])
+            trk.reset(rep(0), torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous())
+            so2 = trk.new_state_buffer(6)
+            for i, k in enumerate(order[:6]):
+                f = rep(k); keep.append(f)
+                trk.step(f, so2[i])
+            trk.join()
+            assert np.array_equal(so2.cpu().numpy().reshape(6, B, -1), recs[64][:6])
     for B in (64, 8):
         for b in range(B):
             assert np.array_equal(recs[B][:, b], recs[1][:, 0]), "stream %d of %d" % (b, B)
