@@ -581,7 +581,7 @@ static int ms_init(agt_ctx* c)
     return AGT_OK;
 }
 
-#define AGT_MS_RING 8            // ring entries in multi-stream mode
+#define AGT_MS_RING 8            // ring entries multi-stream mode needs at least
 #define AGT_MS_GAP 4             // buffer-reuse waits are issued every AGT_MS_GAP frames, on the events of AGT_MS_GAP frames ago
 
 static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
@@ -589,8 +589,8 @@ static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, s
     int rc = ms_init(c);
     if (rc) return rc;
     const bool first = !c->ms_active;
-    if (first && c->live_ring != AGT_MS_RING) {
-        // (the caller joined: only the newest frame is live) eight ring entries let the reuse waits be sparse
+    if (first && c->live_ring < AGT_MS_RING) {
+        // (the caller joined: only the newest frame is live) at least eight ring entries let the reuse waits be sparse
         rc = ensure_ring(c, AGT_MS_RING);
         if (rc) return rc;
         ring_move(c, c->trk_frame, c->live_ring, AGT_MS_RING);
@@ -646,7 +646,7 @@ static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, s
 static int ms_join(agt_ctx* c)
 {
     if (!c->ms_active) return AGT_OK;
-    hipEvent_t ev = c->ms_ev[3][AGT_RING_MAX - 1];                   // entry never used by a frame (ring <= 8)
+    hipEvent_t ev = c->ms_ev[0][AGT_RING_MAX - 1];                   // (hand-over events are waited on immediately: the last entry is free)
     hipError_t e = hipEventRecord(ev, c->ms_stream[2]);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
     if (e != hipSuccess) return hip_fail(c, e);

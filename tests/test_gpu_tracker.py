@@ -377,3 +377,35 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
         for b in range(B):
             assert np.array_equal(recs[B][:, b], recs[1][:, 0]), "stream %d of %d" % (b, B)
     assert recs[1][:, 0, 6].all()
+
+
+def test_mode_changes_between_runs(torch_cuda, seq640):
+    """one context, several runs: 44-stream batch on the library's streams at depth 4, then (reset) a single stream on
+    the fused step at depth 4, then the batch again -- ring sizes and moduli follow; every run equals a fresh tracker"""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1]
+
+    def run(trk, B):
+        rep = lambda k: frames[k].unsqueeze(0).expand(B, -1, -1).contiguous()
+        trk.reset(rep(0), torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous())
+        so = torch.zeros((len(order), B, 16), dtype=torch.float64, device="cuda")
+        keep = []
+        for i, k in enumerate(order):
+            f = rep(k); keep.append(f)
+            trk.step(f, so[i])
+        trk.join()
+        return so.cpu().numpy()
+
+    ref = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+    ref.pipeline(0)
+    want = run(ref, 1)[:, 0]
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=44)     # 2112 corners: past the fused cut-off
+    trk.pipeline(4)
+    for B in (44, 1, 44, 3):
+        trk.B = B
+        got = run(trk, B)
+        for b in range(B):
+            assert np.array_equal(got[:, b], want), "B=%d stream %d" % (B, b)
