@@ -113,9 +113,15 @@ __device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int b
     for (int i = tid; i < SH * (TW / 8); i += NT) {
         const int r = i / (TW / 8), q = i - r * (TW / 8);
         const uint8_t* s = s_src + r * SW + 16 * (q + 1);
-        const uint32_t pm = *reinterpret_cast<const uint32_t*>(s - 4);        // bytes -4..-1
         const uint4 d = *reinterpret_cast<const uint4*>(s);                   // bytes 0..15
-        const uint32_t nx = *reinterpret_cast<const uint32_t*>(s + 16);       // bytes 16..19
+        // bytes -4..-1 and 16..19 are the neighbouring groups' last / first dword: the 16 groups of a row sit in one
+        // DPP row, so they come from the neighbour lanes; only the two edge groups read LDS.  (As LDS reads of every lane
+        // the two stride-16-byte dwords were 8-way bank conflicts: half of the kernel's LDS cycles.)
+        uint32_t pm = 0, nx = 0;
+        if (q == 0) pm = *reinterpret_cast<const uint32_t*>(s - 4);
+        if (q == TW / 8 - 1) nx = *reinterpret_cast<const uint32_t*>(s + 16);
+        pm = (uint32_t)__builtin_amdgcn_update_dpp((int)pm, (int)d.w, 0x111, 0xf, 0xf, false);    // row_shr:1
+        nx = (uint32_t)__builtin_amdgcn_update_dpp((int)nx, (int)d.x, 0x101, 0xf, 0xf, false);    // row_shl:1
         const uint32_t W4 = 0x04060401u;                                      // taps c-2, c-1, c, c+1
         // even outputs start two bytes before an aligned dword, odd outputs on one
         const uint32_t e0 = __builtin_amdgcn_alignbyte(d.x, pm, 2), e2 = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
