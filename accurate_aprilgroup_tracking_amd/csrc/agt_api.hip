@@ -51,7 +51,7 @@ struct agt_ctx {
     // undistortion maps of the pre-processing stage (built once per camera)
     short2* map1; unsigned short* map2; int map_w, map_h;
     // scratch of the dense refinement: per-block partial sums and the per-stream done words
-    double* dense_partials; int* dense_done; size_t dense_cap;
+    double* dense_partials; int* dense_done; size_t dense_cap; int dense_done_B;   // capacities: doubles / streams
     // optional per-kernel timing (agt_profile_begin/end)
     hipEvent_t* prof_ev;
     int prof_cap, prof_n;
@@ -95,6 +95,28 @@ int ensure_ring(agt_ctx* c, int want)
         ok = ok && hipMemsetAsync(c->status[s], 1, B * N, c->stream) == hipSuccess;
         if (!ok) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }      // partial entry is freed by agt_destroy
         c->ring = s + 1;
+    }
+    return AGT_OK;
+}
+
+// scratch of the dense refinement: `need` doubles of block partials and one done word per stream; the two
+// capacities are tracked separately (a later call may bring more streams with fewer samples)
+int dense_scratch(agt_ctx* c, size_t need, int B)
+{
+    if (need <= c->dense_cap && B <= c->dense_done_B) return AGT_OK;
+    hipError_t e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(c, e);
+    if (need > c->dense_cap) {
+        if (c->dense_partials) (void)hipFree(c->dense_partials);
+        c->dense_partials = nullptr; c->dense_cap = 0;
+        if (hipMalloc((void**)&c->dense_partials, need * sizeof(double)) != hipSuccess) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }
+        c->dense_cap = need;
+    }
+    if (B > c->dense_done_B) {
+        if (c->dense_done) (void)hipFree(c->dense_done);
+        c->dense_done = nullptr; c->dense_done_B = 0;
+        if (hipMalloc((void**)&c->dense_done, (size_t)B * sizeof(int) + 64) != hipSuccess) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }
+        c->dense_done_B = B;
     }
     return AGT_OK;
 }
@@ -239,6 +261,10 @@ static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint
 int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B)
 {
     if (!c || slot < 0 || slot > 1) return AGT_ERR_ARG;
+    // slots 0 / 1 are ring entries of the tracker too: frames still in flight (fused pipeline groups not yet
+    // launched, stage kernels on the library's streams) are enqueued / ordered in front of this build first
+    int rc = agt_tracker_join(c);
+    if (rc) return rc;
     return pyramid_build_on(c, c->stream, slot, d_frames, pitch, batch_stride, B);
 }
 
@@ -267,7 +293,7 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 }
 
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
-                       const float* d_prev_pts, float* d_next_pts, uint8_t* d_status, float* d_err,
+                       const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
                        int n, int B, int crit_type, int crit_max_count, double crit_eps,
                        int flags, double min_eig_threshold)
 {
@@ -288,7 +314,7 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     p.eps2 = eps * eps;
     p.flags = flags;
     p.min_eig_threshold = min_eig_threshold;
-    p.prev_pts = d_prev_pts; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
+    p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
     hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
@@ -299,7 +325,7 @@ int agt_lk_track(agt_ctx* c, int prev_slot, int next_slot,
                  int flags, double min_eig_threshold)
 {
     if (!c || prev_slot < 0 || prev_slot > 1 || next_slot < 0 || next_slot > 1) return AGT_ERR_ARG;
-    return lk_track_on(c, c->stream, prev_slot, next_slot, d_prev_pts, d_next_pts, d_status, d_err, n, B,
+    return lk_track_on(c, c->stream, prev_slot, next_slot, d_prev_pts, nullptr, d_next_pts, d_status, d_err, n, B,
                        crit_type, crit_max_count, crit_eps, flags, min_eig_threshold);
 }
 
@@ -413,16 +439,16 @@ int agt_tracker_pipeline(agt_ctx* c, int depth)
 }
 
 static void fill_estimate(const agt_ctx* c, AgtPnpParams* p, const float* d_img, const uint8_t* d_mask,
-                          double* d_state_out, float* corners_rw)
+                          double* d_state_out, float* corners_rw, uint8_t* status_rw = nullptr)
 {
     memset(p, 0, sizeof(*p));
     p->obj = c->obj; p->obj_bstride = 0; p->img = d_img; p->mask = d_mask; p->dtype = AGT_F32;
     p->n = c->trk_n; p->cam = c->cam; p->pose = c->pose;
-    p->track = c->tstate; p->state_out = d_state_out; p->corners_rw = corners_rw;
+    p->track = c->tstate; p->state_out = d_state_out; p->corners_rw = corners_rw; p->status_rw = status_rw;
     p->enhance_ape = c->enhance_ape; p->reproject = c->reproject; p->min_points = c->min_points; p->gate_px = c->gate_px;
 }
 
-static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slot, const float* d_prev, float* d_next,
+static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slot, const float* d_prev, const uint8_t* d_prev_status, float* d_next,
                    uint8_t* d_status, float* d_err, int n, int crit_type, int crit_max_count, double crit_eps,
                    int flags, double min_eig_threshold)
 {
@@ -437,7 +463,7 @@ static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slo
     p->eps2 = eps * eps;
     p->flags = flags;
     p->min_eig_threshold = min_eig_threshold;
-    p->prev_pts = d_prev; p->next_pts = d_next; p->status = d_status; p->err = d_err;
+    p->prev_pts = d_prev; p->prev_status = d_prev_status; p->next_pts = d_next; p->status = d_status; p->err = d_err;
     return AGT_OK;
 }
 
@@ -494,7 +520,7 @@ static int launch_group(agt_ctx* c, int B)
             if (c->l0_pitch[q] != c->l0_pitch[a] || c->l0_bstride[q] != c->l0_bstride[a]) { cnt = k > 1 ? k - 1 : 1; break; }
         }
         const int pslot = (int)(f0 % M), slot = (int)((f0 + 1) % M);
-        fill_lk(c, &S.lk, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr, c->trk_n,
+        fill_lk(c, &S.lk, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr, c->trk_n,
                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
         S.lk_nf = (int)cnt;
         for (long k = 0; k <= cnt; k++) {
@@ -624,7 +650,7 @@ static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, s
     if (e == hipSuccess) e = hipStreamWaitEvent(sB, evA[slot], 0);
     if (e == hipSuccess && guard) e = hipStreamWaitEvent(sB, evC[gslot], 0);
     if (e != hipSuccess) return hip_fail(c, e);
-    rc = lk_track_on(c, sB, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr,
+    rc = lk_track_on(c, sB, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
     e = hipEventRecord(evB[slot], sB);
@@ -691,12 +717,12 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
     if (rc) return rc;
     if (pev) (void)hipEventRecord(pev[1], M);
-    rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->corners[slot], c->status[slot], nullptr,
+    rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
     if (pev) (void)hipEventRecord(pev[2], M);
     AgtPnpParams p;
-    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot]);
+    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
     hipError_t e = agt_launch_pnp(M, p, B);
     if (e != hipSuccess) return hip_fail(c, e);
     if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
@@ -839,9 +865,7 @@ int agt_undistort_init(agt_ctx* c, const double* K, const double* dist, int ndis
     if (c->map_w != w || c->map_h != h) {
         hipError_t e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(c, e);
-        if (c->dense_partials) (void)hipFree(c->dense_partials);
-    if (c->dense_done) (void)hipFree(c->dense_done);
-    if (c->map1) (void)hipFree(c->map1);
+        if (c->map1) (void)hipFree(c->map1);
         if (c->map2) (void)hipFree(c->map2);
         c->map1 = nullptr; c->map2 = nullptr; c->map_w = c->map_h = 0;
         if (hipMalloc((void**)&c->map1, (size_t)w * h * sizeof(short2)) != hipSuccess ||
@@ -905,16 +929,8 @@ int agt_dense_refine(agt_ctx* c, const uint8_t* d_img, size_t pitch, size_t batc
     int rc = fill_camera(K, dist, ndist, &cam);
     if (rc) return rc;
     const size_t need = (size_t)B * (size_t)(agt_dense_blocks(M) > 0 ? agt_dense_blocks(M) : 1) * 32;
-    if (need > c->dense_cap) {
-        hipError_t e = hipStreamSynchronize(c->stream);
-        if (e != hipSuccess) return hip_fail(c, e);
-        if (c->dense_partials) (void)hipFree(c->dense_partials);
-        if (c->dense_done) (void)hipFree(c->dense_done);
-        c->dense_partials = nullptr; c->dense_done = nullptr; c->dense_cap = 0;
-        if (hipMalloc((void**)&c->dense_partials, need * sizeof(double)) != hipSuccess ||
-            hipMalloc((void**)&c->dense_done, (size_t)B * sizeof(int) + 64) != hipSuccess) return AGT_ERR_ALLOC;
-        c->dense_cap = need;
-    }
+    rc = dense_scratch(c, need, B);
+    if (rc) return rc;
     hipError_t e = agt_launch_dense(c->stream, d_img, (long)pitch, (long)batch_stride, w, h, d_model_xyz, d_model_t, M,
                                     d_obj, d_img_pts, d_mask, N, cam, d_pose, c->dense_partials, d_stats, c->dense_done,
                                     B, iters, photo_weight, 1e-3);

@@ -31,6 +31,7 @@ struct AgtLkParams {
     int flags;
     double min_eig_threshold;
     const float* prev_pts;    // [B][n][2]
+    const uint8_t* prev_status;   // [B][n] or null: tracker mode, a corner lost in an earlier frame stays lost (position carried)
     float* next_pts;          // [B][n][2]
     uint8_t* status;          // [B][n]
     float* err;               // [B][n] or null
@@ -58,6 +59,7 @@ struct AgtPnpParams {
     struct AgtTrackState* track;   // [B]
     double* state_out;             // [B][AGT_STATE_STRIDE] or null
     float* corners_rw;             // [B][n][2] corner set to refresh by reprojection, or null
+    uint8_t* status_rw;            // [B][n] LK status revived together with corners_rw, or null
     int enhance_ape;
     int reproject;
     int min_points;                // corners needed to attempt a pose (8 = two tags)

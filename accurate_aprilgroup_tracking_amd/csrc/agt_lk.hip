@@ -12,9 +12,9 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     agt_lk::LkFrameIo<NLEV> io;
     io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
-    io.have_pos = false; io.px = io.py = 0.f;
-    float ox, oy;
-    agt_lk::lk_body<WIN, NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ox, oy);
+    io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
+    float ox, oy; int ost;
+    agt_lk::lk_body<WIN, NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ox, oy, ost);
 }
 
 template <int WIN, int NW>
@@ -36,7 +36,11 @@ bool agt_lk_window_supported(int win) { return win == 21 || win == 15 || win == 
 // matters), 1 for large batches (throughput matters)
 bool agt_lk_wide(int n, int B)
 {
-    static const long cap = [] { const char* e = getenv("AGT_LK_WIDE_MAX"); return e ? atol(e) : 1024L; }();   // tuning knob
+#ifdef AGT_DEBUG_KNOBS
+    static const long cap = [] { const char* e = getenv("AGT_LK_WIDE_MAX"); return e ? atol(e) : 1024L; }();
+#else
+    const long cap = 1024;
+#endif
     return (long)n * B <= cap;
 }
 

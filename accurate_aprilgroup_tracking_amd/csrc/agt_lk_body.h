@@ -207,7 +207,7 @@ struct LkFrameIo {
     const uint8_t* imgJ[NLEV];      // next image, per level
     bool grouped;
     const float* prev_pts; float* next_pts; uint8_t* status; float* err;
-    bool have_pos; float px, py;
+    bool have_pos; float px, py; int pst;       // pst: the corner's status after the previous frame (with have_pos)
 };
 
 // Track corner `pt` of stream `b` through one frame.  Called by all 64*NW threads of a workgroup; lds:
@@ -224,7 +224,7 @@ __device__ __forceinline__ AgtLevel get_level(const LV& L)
 // PP: pointer to the parameters -- `const AgtLkParams*` (stand-alone launch) or a pointer into the kernel-argument
 // segment (fused step, where the level tables are indexed with run-time levels inside a frame loop).
 template <int WIN, int NW, int NLEV, typename PP>
-__device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float& ox, float& oy)
+__device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float& ox, float& oy, int& ost)
 {
     using C = LkCfg<WIN, NW>;
     constexpr int T = C::T;
@@ -253,6 +253,22 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float ppx = io.have_pos ? io.px : io.prev_pts[pidx * 2], ppy = io.have_pos ? io.py : io.prev_pts[pidx * 2 + 1];
+    // tracker mode: a corner that was lost (left the image, flat patch) is not picked up again by whatever texture
+    // sits at its last position -- it stays lost, position carried, until the corner set is re-seeded
+    {
+        int pst = 1;
+        if (io.have_pos) pst = io.pst;
+        else if (P->prev_status) pst = P->prev_status[pidx];
+        if (!agt_uniform(pst)) {
+            if (tid == 0) {
+                io.next_pts[pidx * 2] = ppx; io.next_pts[pidx * 2 + 1] = ppy;
+                io.status[pidx] = 0;
+                if (io.err) io.err[pidx] = 0.f;
+            }
+            ox = ppx; oy = ppy; ost = 0;
+            return;
+        }
+    }
     float outx = 0.f, outy = 0.f;              // nextPts[ptidx]
     if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
     const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;     // where the search is expected to start
@@ -462,7 +478,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         io.status[pidx] = (uint8_t)st;
         if (io.err) io.err[pidx] = errv;
     }
-    ox = outx; oy = outy;
+    ox = outx; oy = outy; ost = st;
 }
 
 }  // namespace agt_lk

@@ -819,6 +819,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 agt_project<false>(cam, R, G, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2],
                                    u, v, nullptr, nullptr);
                 cw[i * 2] = (float)u; cw[i * 2 + 1] = (float)v;
+                if (P.status_rw) P.status_rw[(long)b * n + i] = 1;       // lost corners are re-seeded: trackable again
             }
         }
         return;

@@ -81,10 +81,10 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
             }
         }
         // consecutive frames of this corner: its position is carried in registers from frame to frame
-        float px = 0.f, py = 0.f;
+        float px = 0.f, py = 0.f; int pst = 1;
         for (int k = 0; k < S.lk_nf; k++) {
             agt_lk::LkFrameIo<NLEV> io;
-            io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py;
+            io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py; io.pst = pst;
             if (k == 0) {
 #pragma unroll
                 for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
                 for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
                 io.next_pts = tab->next[k]; io.status = tab->status[k];
             }
-            agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py);
+            agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
         }
         return;
     }
@@ -128,8 +128,10 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
-    { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();   // EXPERIMENT
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only (make dbg): drop roles from the launch to time the others
+    { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();
       if (skip & 1) P.n_pnp = 0; if (skip & 2) P.n_lk = 0; if (skip & 4) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.n_pyr[s] = 0; } }
+#endif
     size_t lds = 0;
     int blocks = 0;
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) if (P.n_pyr[s] > 0) { blocks += P.n_pyr[s]; lds = lds > (size_t)agt_pyr::PYR_LDS_BYTES ? lds : (size_t)agt_pyr::PYR_LDS_BYTES; }
@@ -165,7 +167,11 @@ bool agt_step_supported(int win) { return win == 21; }
 // (94 vs 85) the one-wave-per-corner LK role wants more than the two waves per SIMD the fused launch can hold.
 bool agt_step_fits(int n, int B)
 {
-    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 2048L; }();   // tuning knob
+#ifdef AGT_DEBUG_KNOBS
+    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 2048L; }();
+#else
+    const long cap = 2048;
+#endif
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
 

@@ -48,6 +48,7 @@ class StreamTracker:
         """frames: cuda u8 [B,H,W] in which `corners` (cuda f32 [B,n,2]) were seen.  With both None
         only `estimate_pose` (detector-supplied corners) can be used afterwards."""
         self.ctx.use_current_stream()
+        self.join()                 # frames in flight come first: slot 0 is a ring entry of the running tracker
         if frames is not None:
             self.ctx.pyramid_build(0, frames)
             assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)

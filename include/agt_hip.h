@@ -109,7 +109,10 @@ int agt_pyr_down_u8(agt_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t s
                     uint8_t* d_dst, size_t dpitch, size_t dbatch, int B);
 /* Build slot (0/1) of the context's pyramid from B frames of cfg.width x cfg.height.
  * Level 0 aliases d_frames: the caller keeps those frames valid and unmodified until
- * the last agt_lk_track / agt_track_frame that reads the slot has completed. */
+ * the last agt_lk_track / agt_track_frame that reads the slot has completed.  The two slots are ring
+ * entries of the tracker as well: the call first joins a running tracker (agt_tracker_join), so the build
+ * is ordered behind every frame in flight; building a slot invalidates the tracker's own use of that entry
+ * until the next agt_tracker_reset. */
 int agt_pyramid_build(agt_ctx* ctx, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B);
 /* Introspection (tests): device pointer and geometry of one level of a built slot. */
 int agt_pyramid_level(const agt_ctx* ctx, int slot, int level, const uint8_t** d_ptr,
@@ -183,7 +186,9 @@ int agt_estimate_pose(agt_ctx* ctx, const float* d_img, const uint8_t* d_mask, i
 int agt_tracker_state_size(void);
 int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronises the stream */
 /* One frame for B streams: pyramid(new frames) -> LK(prev corners) -> solvePnP(guess) ->
- * reprojection gate -> motion-model guess update.  d_state_out: [B][AGT_STATE_STRIDE] f64 or NULL
+ * reprojection gate -> motion-model guess update.  LK status is sticky: a corner whose status dropped to 0
+ * (left the image, flat patch) is not tracked again -- its position is carried and it stays masked out of the
+ * PnP -- until agt_tracker_reset re-seeds the corner set (or, with the reproject option, an accepted pose does).  d_state_out: [B][AGT_STATE_STRIDE] f64 or NULL
  * (device memory; read it back whenever convenient).  No host synchronisation. */
 int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out);

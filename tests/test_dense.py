@@ -146,3 +146,38 @@ def test_config5_sizes_240_corners_61440_samples(oracle):
     assert np.abs(pose[:3] - r).max() < 1e-9 and np.abs(pose[3:] - t).max() < 1e-9
     assert np.abs(pose[:3] - s.rvecs[1]).max() < 1e-4 and np.abs(pose[3:] - s.tvecs[1]).max() < 1e-4
     assert stats.cpu().numpy()[0, 4] == 240
+
+
+@pytest.mark.gpu
+def test_scratch_survives_undistort_init_and_batch_growth(oracle, scene):
+    """ADVICE r1: (1) agt_undistort_init must not touch the dense scratch (it freed it without resetting the capacity);
+    (2) the per-stream done words have their own capacity: B = 1 with many samples followed by B = 64 with few."""
+    import torch
+    from accurate_aprilgroup_tracking_amd import cv_hip
+    s, mx = scene
+    T = _template(s, mx, 1)
+    start = np.concatenate([s.rvecs[1] + 0.002, s.tvecs[1] - 0.0004])
+    want_r, want_t, _ = oracle.dense_refine(s.frame(1), mx, T, None, None, None, s.K, None, start[:3], start[3:], iters=4, photo_weight=1.0)
+    ctx = cv_hip.Context(s.width, s.height, max_level=0)
+    mxg, Tg = torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda()
+
+    def run(B, m=None):
+        frames = torch.from_numpy(np.stack([s.frame(1)] * B)).cuda()
+        pose = torch.from_numpy(np.repeat(start[None], B, 0).copy()).cuda()
+        a, b = (mxg, Tg) if m is None else (mxg[:m].contiguous(), Tg[:m].contiguous())
+        pose, _ = ctx.dense_refine(frames, a, b, pose, s.K, None, iters=4, photo_weight=1.0)
+        return pose.cpu().numpy()
+
+    def check(p):
+        assert np.abs(p[:, :3] - want_r).max() < 1e-9 and np.abs(p[:, 3:] - want_t).max() < 1e-9
+
+    check(run(1))
+    ctx.undistort_init(s.K, syn.MILD_DIST, None, s.width, s.height)        # first map build: map size changes from 0
+    m1 = ctx.undistort_maps()[0].copy()
+    check(run(1))
+    ctx.undistort_init(s.K, syn.MILD_DIST, None, s.width, s.height)
+    assert np.array_equal(ctx.undistort_maps()[0], m1)                        # maps were not clobbered by the dense scratch
+    small = run(64, 256)                                                   # more streams, fewer samples than the first call
+    r, t, _ = oracle.dense_refine(s.frame(1), mx[:256], T[:256], None, None, None, s.K, None, start[:3], start[3:], iters=4, photo_weight=1.0)
+    assert np.abs(small[:, :3] - r).max() < 1e-9 and np.abs(small[:, 3:] - t).max() < 1e-9
+    check(run(1))

@@ -409,3 +409,94 @@ def test_mode_changes_between_runs(torch_cuda, seq640):
         got = run(trk, B)
         for b in range(B):
             assert np.array_equal(got[:, b], want), "B=%d stream %d" % (B, b)
+
+
+@pytest.mark.parametrize("B,depth", [(64, 1), (1, 4), (2, 1)])
+def test_reset_mid_flight_at_every_ring_phase(torch_cuda, seq640, B, depth):
+    """StreamTracker.reset builds its frame into ring entry 0 -- with frames still in flight (library
+    streams at B = 64, unlaunched groups of the fused pipeline otherwise) that build must be ordered behind them, at
+    every phase of the ring (a reset after 5..12 un-joined frames covers the newest frame sitting in entry 0)."""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    rep = lambda k: frames[k].unsqueeze(0).expand(B, -1, -1).contiguous()
+    c0 = torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5]
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+    trk.pipeline(depth)
+    want = None
+    keep = []
+    for pre in (0, 5, 6, 7, 8, 9, 10, 11, 12):
+        if pre:
+            trk.reset(rep(0), c0)
+            for k in order[:pre]:
+                f = rep(k); keep.append(f)
+                trk.step(f, None)                      # left in flight: no join, no sync
+        trk.reset(rep(0), c0)
+        so = trk.new_state_buffer(6)
+        for i, k in enumerate(order[:6]):
+            f = rep(k); keep.append(f)
+            trk.step(f, so[i])
+        trk.join()
+        got = so.cpu().numpy().reshape(6, B, -1)
+        if want is None:
+            want = got
+            assert want[:, 0, 6].all()
+        assert np.array_equal(got, want), "reset after %d frames in flight" % pre
+
+
+def test_lost_corner_stays_lost(torch_cuda, oracle, seq640):
+    """LK status is sticky in the tracker.  Two corners are pushed out of the image for one frame (their
+    positions are overwritten in the live corner buffer); afterwards the texture under their last position would let
+    LK 'track' again -- the tracker must keep them masked (status 0, position carried) in every later frame, in every
+    launch mode, and the pose must equal the oracle chain with the same rule."""
+    torch = torch_cuda
+    import ctypes as C
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    F = len(s)
+    c0 = s.corners(0).copy()
+    lost = [5, 17]
+    c0[lost[0]] = (-40.0, 100.0)           # window wholly outside: status 0 at level 0
+    c0[lost[1]] = (s.width + 35.0, 50.0)
+    # oracle chain with the sticky rule
+    pts = c0.copy(); alive = np.ones(48, bool); pyr = oracle.Pyramid(s.frame(0))
+    ref_status, ref_pts = [], []
+    for k in range(1, F):
+        npyr = oracle.Pyramid(s.frame(k))
+        nx, st, _ = oracle.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
+        nx = nx.reshape(-1, 2); st = st.ravel().astype(bool)
+        nx[~alive] = pts[~alive]
+        alive &= st
+        ref_status.append(alive.copy()); ref_pts.append(nx.copy())
+        pts = nx.astype(np.float32); pyr = npyr
+    assert not ref_status[0][lost].any()
+    outs = []
+    for depth in (0, 1, 4):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+        trk.pipeline(depth)
+        trk.reset(frames[0:1].contiguous(), torch.from_numpy(c0[None]).cuda().contiguous())
+        so = trk.new_state_buffer(F - 1)
+        for k in range(1, F):
+            trk.step(frames[k:k + 1], so[k - 1])
+        trk.join()
+        st = so.cpu().numpy()
+        outs.append(st)
+        for k in range(1, F):
+            assert int(st[k - 1, 0, H.ST_NTRACK]) == int(ref_status[k - 1].sum())
+        cp, sp = trk.corners()
+        torch.cuda.synchronize()
+        got_c = np.zeros((48, 2), np.float32); got_s = np.zeros(48, np.uint8)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes, 2) == 0
+        assert hip.hipMemcpy(got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes, 2) == 0
+        assert np.array_equal(got_s.astype(bool), ref_status[-1])
+        assert np.array_equal(got_c.view(np.uint32), ref_pts[-1].astype(np.float32).view(np.uint32))
+        ok = ref_status[-1]
+        _, r, t = oracle.solvePnP(s.obj[ok].astype(np.float32), ref_pts[-1][ok].astype(np.float32), s.K, None,
+                                  s.rvecs[F - 1], s.tvecs[F - 1], True)
+        assert np.abs(st[-1, 0, :3] - r.ravel()).max() < 1e-6 and np.abs(st[-1, 0, 3:6] - t.ravel()).max() < 1e-6
+    assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
