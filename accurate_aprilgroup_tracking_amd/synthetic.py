@@ -15,6 +15,7 @@ from scipy.ndimage import gaussian_filter
 from scipy.spatial.transform import Rotation
 
 MILD_DIST = np.array([[0.05, -0.1, 1e-3, -1e-3, 0.02]], dtype=np.float64)
+DENSE_Z0 = 0.47          # object distance (m) of the 60-tag model
 
 
 def camera_matrix(width, height):
@@ -33,18 +34,18 @@ def _cap_directions(n, max_polar_rad):
     return np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), -cos_t], axis=1)
 
 
-def make_april_group(n_tags=12, tag_size=0.020, max_polar_deg=46.0, seed=0):
+def make_april_group(n_tags=12, tag_size=0.020, max_polar_deg=46.0, seed=0, sep=1.8):
     """AprilGroup on a spherical cap.  Returns the april_group.json dict.
 
-    The sphere radius is the smallest one that keeps tag centres >= 1.8 * tag_size apart,
-    so the tags (with their 1-cell quiet zone) never overlap.
+    The sphere radius is the smallest one that keeps tag centres >= sep * tag_size apart,
+    so the tags (with their 1-cell quiet zone, 1.25 * tag_size across) never overlap.
     """
     d = _cap_directions(n_tags, np.deg2rad(max_polar_deg))
     if n_tags > 1:
         g = d @ d.T
         np.fill_diagonal(g, -1.0)
         min_ang = np.arccos(np.clip(g.max(), -1.0, 1.0))
-        radius = 1.8 * tag_size / (2.0 * np.sin(min_ang / 2.0))
+        radius = sep * tag_size / (2.0 * np.sin(min_ang / 2.0))
     else:
         radius = 0.0
     rng = np.random.default_rng(seed)
@@ -172,9 +173,11 @@ def background(width, height, seed=0):
     return (128.0 + n).astype(np.float32)
 
 
-def render_frame(group, bits, rvec, tvec, K, dist, width, height, bg, supersample=4):
+def render_frame(group, bits, rvec, tvec, K, dist, width, height, bg, supersample=4, cover_out=None):
     """Render one u8 gray frame: every front-facing tag as a warped 8x8-cell pattern
-    (1-cell black border, 1-cell white quiet zone), box-filtered over supersample^2 taps."""
+    (1-cell black border, 1-cell white quiet zone), box-filtered over supersample^2 taps.
+    cover_out: optional float32 (H, W) array that receives the SUM of the tags' coverage (a value above 1 marks
+    pixels painted by two tags: the layout check of the 60-tag model)."""
     img = bg.astype(np.float32).copy()
     R_o = Rotation.from_rotvec(np.asarray(rvec, float).reshape(3)).as_matrix()
     t_o = np.asarray(tvec, float).reshape(3)
@@ -220,6 +223,8 @@ def render_frame(group, bits, rvec, tvec, K, dist, width, height, bg, supersampl
         cover = inside.astype(np.float32)
         acc = (val * cover).mean(axis=(2, 3)); cov = cover.mean(axis=(2, 3))
         img[y0:y1, x0:x1] = img[y0:y1, x0:x1] * (1 - cov) + acc
+        if cover_out is not None:
+            cover_out[y0:y1, x0:x1] += cov
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
@@ -227,12 +232,19 @@ class Sequence:
     """A seeded synthetic stream: model, camera, trajectory, lazily rendered frames."""
 
     def __init__(self, width=1280, height=720, n_tags=12, n_frames=8, seed=0, dist=None,
-                 supersample=4, speed=1.0, z0=0.30, group_seed=None):
+                 supersample=4, speed=1.0, z0=None, group_seed=None, tag_size=None, sep=None):
         """seed drives trajectory and background; group_seed (default: seed) the AprilGroup model, so
-        several streams can show the SAME object along different trajectories."""
+        several streams can show the SAME object along different trajectories.
+        Defaults: up to 12 tags of 20 mm at 0.30 m (the dodeca-like model of configs 1-4); more tags (the 60-tag
+        model of BASELINE config 5) are 10 mm, 2.2 tag sizes apart, seen from DENSE_Z0 so that every tag of the cap
+        is inside a 1280x720 frame and no two tags touch in the image (test_synthetic_60_tag_layout)."""
         self.width, self.height, self.seed = width, height, seed
         gs = seed if group_seed is None else group_seed
-        self.group = make_april_group(n_tags=n_tags, seed=gs)
+        dense = n_tags > 12
+        tag_size = (0.010 if dense else 0.020) if tag_size is None else tag_size
+        sep = (2.2 if dense else 1.8) if sep is None else sep
+        z0 = (DENSE_Z0 if dense else 0.30) if z0 is None else z0
+        self.group = make_april_group(n_tags=n_tags, tag_size=tag_size, seed=gs, sep=sep)
         self.bits = tag_bits(n_tags, gs)
         self.obj = group_object_points(self.group)                 # (4T, 3) f64
         self.K = camera_matrix(width, height)
@@ -257,3 +269,10 @@ class Sequence:
 
     def frames(self):
         return np.stack([self.frame(k) for k in range(len(self))])
+
+    def coverage(self, k):
+        """(H, W) float32: sum of the tags' pixel coverage in frame k (> 1 where two tags overlap in the image)"""
+        cov = np.zeros((self.height, self.width), np.float32)
+        render_frame(self.group, self.bits, self.rvecs[k], self.tvecs[k], self.K, self.dist, self.width, self.height,
+                     self.bg, 1, cover_out=cov)
+        return cov

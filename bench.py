@@ -1,14 +1,25 @@
 #!/usr/bin/env python3
 """bench.py -- frames/sec of the LK + iterative-PnP hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "c2"): ONE 1280x720 synthetic dodeca stream per GPU,
+Default workload (BASELINE.json configs[1], "c2"): ONE 1280x720 synthetic dodeca stream per GPU,
 12 tags / 48 corners, 3-level LK pyramid (maxLevel=2), 21x21 window, COUNT+EPS (30, 0.01),
-iterative PnP with the motion-model extrinsic guess.  A step = one frame of the stream:
+iterative PnP with the motion-model extrinsic guess.  A step = one frame of every stream of the rank:
 pyramid(new frame) -> LK(prev corners) -> solvePnP(guess) -> gate -> motion model, all on
 the device (agt_track_frame), frames already resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3]
-    N > 1: python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c4|c5]
+
+    --gpus N > 1 invoked plainly: this process starts N fresh ranks (python -m torch.distributed.run, rendezvous on
+    127.0.0.1) BEFORE anything touches a GPU, relays rank 0's JSON line and exits with the job's code.  Launched by
+    torch.distributed.run itself (WORLD_SIZE set) it is one of the ranks.
+
+Workloads: c2 = 1 x 1280x720 stream (configs[1], the metric's configuration); c3 = 64 x 1280x720 per step (configs[2], the
+HBM-bound one); c4 = 1 x 1920x1080 stream per GPU (configs[3]); c5 = 1280x720, 60 tags / 240 corners + dense photometric
+refinement per frame (configs[4]).
+
+Timing: W untimed warm-up steps, then R blocks (default 15) of EXACTLY K steps each, every block bracketed by barrier +
+torch.cuda.synchronize() on both sides and including the pipeline drain and the one pose gather; the per-block time is the MAX
+over ranks.  ms_per_step / value come from the MEDIAN block; p10 / p90 are reported beside it.
 
 Prints ONE JSON line on rank 0 (contract: task prompt, section 4).
 """
@@ -16,6 +27,8 @@ import argparse
 import ctypes as C
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -24,17 +37,29 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-REDETECT = 600            # frames between detector refreshes of the corner set (drift control, see time_tracker)
+REDETECT = 600            # frames between detector refreshes of the corner set (drift control, see Bench.refresh)
 HBM_PEAK_GBS = 8000.0     # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-W, H, NTAGS, NPTS, LEVELS, WIN = 1280, 720, 12, 48, 3, 21
+LEVELS, WIN = 3, 21
+
+WORKLOADS = {
+    #        frame size    tags  streams/GPU
+    "c2": dict(W=1280, H=720, ntags=12, B=1, dense=False,
+               label="c2: %d x 1280x720 stream(s) per GPU, 12 tags/48 corners, 3-level LK 21x21, iterative PnP with motion-model guess"),
+    "c3": dict(W=1280, H=720, ntags=12, B=64, dense=False,
+               label="c3: %d x 1280x720 independent streams per step, 48 corners each (LK HBM-bandwidth run)"),
+    "c4": dict(W=1920, H=1080, ntags=12, B=1, dense=False,
+               label="c4: %d x 1920x1080 stream(s) per GPU (one per GPU across the node), 48 corners, 3-level LK 21x21, iterative PnP"),
+    "c5": dict(W=1280, H=720, ntags=60, B=1, dense=True,
+               label="c5: %d x 1280x720 stream(s), 60 tags/240 corners, LK + iterative PnP + dense photometric refinement (61,440 samples)"),
+}
 
 
-def algorithmic_bytes():
-    """SURVEY.md 8d per-unit figures (1280x720, L=3, N=48), per launch of each kernel."""
+def algorithmic_bytes(W, H, npts):
+    """SURVEY.md 8d per-unit figures (L = 3), per launch of each kernel and per streamed frame."""
     pyr = sum((W >> l) * (H >> l) + (W >> (l + 1)) * (H >> (l + 1)) for l in range(LEVELS - 1))   # read l, write l+1
-    lk = NPTS * LEVELS * (24 * 24 + 32 * 32) + NPTS * (8 + 8 + 1 + 4)
-    pnp = NPTS * 20 + 48
-    return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + NPTS * LEVELS * 1600 + NPTS * 21}
+    lk = npts * LEVELS * (24 * 24 + 32 * 32) + npts * (8 + 8 + 1 + 4)
+    pnp = npts * 20 + 48
+    return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + npts * LEVELS * 1600 + npts * 21}
 
 
 def pmc_traffic(kernel):
@@ -62,73 +87,179 @@ def pingpong(i, nf):
     return j if j < nf else 2 * nf - 2 - j
 
 
-def build_stream_ring(torch, syn, dev, rank, B, NF):
-    """Render NF frames for up to 4 seeds and lay a ping-pong sequence over an HBM ring that exceeds the
-    256 MiB Infinity Cache, so every step reads cold addresses."""
-    nseq = min(B, 4)
-    seqs = [syn.Sequence(W, H, n_tags=NTAGS, n_frames=NF, seed=1000 * rank + s, supersample=3, group_seed=0) for s in range(nseq)]
-    rendered = np.stack([sq.frames() for sq in seqs], axis=1)          # [NF, nseq, H, W]
-    period = 2 * NF - 2
-    ring_slots = period * max(1, -(-(300 << 20) // (period * B * W * H)))
-    ring = torch.empty((ring_slots, B, H, W), dtype=torch.uint8, device=dev)
-    src = torch.from_numpy(rendered).to(dev)
-    for i in range(ring_slots):
-        f = src[pingpong(i, NF)]
-        for b in range(B):
-            ring[i, b] = f[b % nseq]       # streams beyond the rendered seeds are copies at distinct HBM addresses
-    corners0 = np.stack([seqs[b % nseq].corners(0) for b in range(B)])
-    # ground-truth corners of every frame of the ping-pong period: what a detector pass on that frame would return
-    truth = np.stack([np.stack([seqs[b % nseq].corners(pingpong(i, NF)) for b in range(B)]) for i in range(period)])
-    build_stream_ring.truth = torch.from_numpy(truth).to(dev).contiguous()
-    return seqs, rendered, ring, ring_slots, corners0
+def percentiles(samples):
+    a = np.sort(np.asarray(samples, np.float64))
+    return float(np.median(a)), float(np.percentile(a, 10)), float(np.percentile(a, 90))
 
 
-def time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world):
-    """W warm-up + K timed steps between barrier + synchronize pairs; returns (fps, dt, state[K+W,B,16])."""
-    state = torch.zeros((Wm + K, B, HL.STATE_STRIDE), dtype=torch.float64, device=dev)
-
-    truth = build_stream_ring.truth
-    since = [0]
-
-    def run(n_steps, first, st):
-        # Raw LK chaining drifts (the reference re-detects the tags on every frame): after REDETECT frames the corners
-        # are refreshed from the detector's answer for the current frame (ground truth here), as a hybrid pipeline would.
-        for k in range(n_steps):
-            if since[0] >= REDETECT:
-                j = (first + k - 1) % ring_slots
-                trk.join()
-                trk.reset(ring[j], truth[j % truth.shape[0]])
-                since[0] = 0
-            trk.step(ring[(first + k) % ring_slots], st[k] if st is not None else None)
-            since[0] += 1
-    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-    run(Wm, 1, state[:Wm])
-    trk.join()
-    D.gather_poses(state[:Wm])                    # warm the communicator outside the timed region
-    torch.cuda.synchronize(); D.barrier()
-    t0 = time.perf_counter()
-    run(K, 1 + Wm, state[Wm:])
-    trk.join()                                    # enqueue the last pipeline stages of the frames in flight
-    # the only collective: the per-frame state records (128 B per stream-frame), once per chunk of
-    # K frames.  state[Wm:] is already contiguous: no torch kernel runs inside the timed region.
-    gathered = D.gather_poses(state[Wm:])
-    torch.cuda.synchronize(); D.barrier()
-    dt = D.max_over_ranks(time.perf_counter() - t0, dev)
-    return world * B * K / dt, dt, state, gathered, run
+# ---------------------------------------------------------------------------------------------------------------
+def self_launch(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as fresh processes.  Nothing in this (parent)
+    process has touched a GPU: torch is imported only to COUNT devices (does not initialise the runtime)."""
+    import torch
+    ndev = torch.cuda.device_count()
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.dry_run:
+        env["AGT_DIST_BACKEND"] = "gloo"
+    elif ndev < args.gpus and "AGT_DIST_BACKEND" not in env:
+        if args.gpus > 6:
+            print("bench.py: --gpus %d on a host with %d GPU(s): more ranks than may share one card" % (args.gpus, ndev), file=sys.stderr)
+            sys.exit(2)
+        # rehearsal of the multi-rank flow: ranks share the card(s), gather over gloo (RCCL needs one GPU per rank)
+        env["AGT_DIST_BACKEND"] = "gloo"
+        print("bench.py: %d GPU(s) for %d ranks -> REHEARSAL (ranks share GPUs, gloo gather); not a scaling measurement"
+              % (ndev, args.gpus), file=sys.stderr)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
-def event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, pipeline):
-    """average HIP-event spans (us) of M steps, recorded on the launch stream by the library"""
-    trk.pipeline(pipeline)
-    trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-    run(Wm, 1, None)
-    trk.join()
-    HL.check(trk.ctx.L.agt_profile_begin(trk.ctx.h, M), "agt_profile_begin")
-    run(M, 1 + Wm, None)
-    ms = np.zeros((M, HL.PROF_SPANS), np.float32); nrec = C.c_int(0)
-    HL.check(trk.ctx.L.agt_profile_end(trk.ctx.h, ms.ctypes.data_as(C.c_void_p), C.byref(nrec)), "agt_profile_end")
-    trk.join()
-    return ms[:nrec.value].mean(axis=0) * 1e3
+class StubTracker:
+    """--dry-run only (tests/test_distributed.py): stands in for StreamTracker on a host without a GPU so that the launcher,
+    the rendezvous, the block timing and the pose gather of THIS file run under gloo.  Writes (rank, frame index) records."""
+
+    def __init__(self, rank):
+        self.rank, self.t = rank, 0
+
+    def pipeline(self, depth):
+        pass
+
+    def reset(self, frames=None, corners=None):
+        self.t = 0
+
+    def step(self, frames, out=None):
+        self.t += 1
+        if out is not None:
+            out.zero_()
+            out[:, 0] = self.rank; out[:, 1] = self.t; out[:, 6] = 1.0
+
+    def join(self):
+        pass
+
+
+class Bench:
+    """One rank's streams: rendered frames laid over an HBM ring, a StreamTracker, and the timed blocks."""
+
+    def __init__(self, torch, wl, args, rank, world, dev):
+        from accurate_aprilgroup_tracking_amd import synthetic as syn
+        from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+        self.torch, self.dev, self.rank, self.world = torch, dev, rank, world
+        self.W, self.H, self.B = wl["W"], wl["H"], args.streams or wl["B"]
+        self.K, self.Wm, self.NF = args.steps, args.warmup, args.render_frames
+        self.sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
+        W, H, B, NF = self.W, self.H, self.B, self.NF
+        t_r = time.time()
+        if args.dry_run:
+            self.period = self.ring_slots = 4
+            self.ring = torch.zeros((4, B, 8, 8), dtype=torch.uint8)
+            self.truth = torch.zeros((4, B, 48, 2))
+            self.npts, self.render_s, self.seqs, self.rendered = 48, 0.0, [], None
+            self.trk = StubTracker(rank)
+            self.pos = self.since = 0
+            return
+        # up to 4 rendered seeds; further streams are copies at distinct HBM addresses.  The ring exceeds the 256 MiB
+        # Infinity Cache, so every step reads cold addresses.
+        nseq = min(B, 4)
+        self.seqs = [syn.Sequence(W, H, n_tags=wl["ntags"], n_frames=NF, seed=1000 * rank + s, supersample=3, group_seed=0)
+                     for s in range(nseq)]
+        self.rendered = np.stack([sq.frames() for sq in self.seqs], axis=1)          # [NF, nseq, H, W]
+        self.period = 2 * NF - 2
+        self.ring_slots = self.period * max(1, -(-(300 << 20) // (self.period * B * W * H)))
+        self.ring = torch.empty((self.ring_slots, B, H, W), dtype=torch.uint8, device=dev)
+        src = torch.from_numpy(self.rendered).to(dev)
+        for i in range(self.ring_slots):
+            f = src[pingpong(i, NF)]
+            for b in range(B):
+                self.ring[i, b] = f[b % nseq]
+        del src
+        self.npts = self.seqs[0].obj.shape[0]
+        # ground-truth corners of every frame of the ping-pong period: what a detector pass on that frame would return
+        truth = np.stack([np.stack([self.seqs[b % nseq].corners(pingpong(i, NF)) for b in range(B)]) for i in range(self.period)])
+        self.truth = torch.from_numpy(truth).to(dev).contiguous()
+        self.render_s = time.time() - t_r
+        sq0 = self.seqs[0]
+        self.trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+        self.pos = 0            # ring index of the newest frame handed to the tracker
+        self.since = 0          # frames since the corner set was last refreshed
+
+    # -- stream control
+    def restart(self):
+        self.trk.reset(self.ring[0], self.truth[0])
+        self.pos, self.since = 0, 0
+
+    def refresh(self):
+        """Raw LK chaining drifts (the reference re-detects the tags on every frame): the corners are refreshed from the
+        detector's answer for the current frame (ground truth here), as a hybrid pipeline would."""
+        self.trk.join()
+        self.trk.reset(self.ring[self.pos % self.ring_slots], self.truth[self.pos % self.period])
+        self.since = 0
+
+    def run(self, n, out):
+        """n steps; out: [n, B, 16] state records or None.  A detector refresh falls inside only when n > REDETECT."""
+        for k in range(n):
+            if self.since >= 2 * REDETECT:
+                self.refresh()
+            self.pos += 1
+            self.trk.step(self.ring[self.pos % self.ring_slots], out[k] if out is not None else None)
+            self.since += 1
+
+    # -- the measurement the contract asks for
+    def timed_blocks(self, D, R):
+        torch, K = self.torch, self.K
+        state_w = torch.zeros((max(self.Wm, 1), self.B, 16), dtype=torch.float64, device=self.dev)
+        state = torch.zeros((K, self.B, 16), dtype=torch.float64, device=self.dev)
+        self.restart()
+        self.run(self.Wm, state_w[:self.Wm])
+        self.trk.join()
+        D.gather_poses(state_w)                       # warm the communicator outside the timed region
+        first = None
+        dts = []
+        for r in range(R):
+            if r > 0 and self.since + K > REDETECT:
+                self.refresh()                        # detector work: between blocks, outside the timers
+            self.sync(); D.barrier()
+            t0 = time.perf_counter()
+            self.run(K, state)
+            self.trk.join()                           # enqueue the last pipeline stages of the frames in flight
+            # the only collective: the per-frame state records (128 B per stream-frame), once per block of K frames
+            gathered = D.gather_poses(state)
+            self.sync(); D.barrier()
+            dts.append(D.max_over_ranks(time.perf_counter() - t0, self.dev))
+            if first is None:
+                first = state.cpu().numpy().copy()
+        st_last = state.cpu().numpy()
+        return dts, state_w.cpu().numpy(), first, st_last, gathered
+
+    def launch_period_us(self, depth, M):
+        """average launch period of the fused step from two HIP events on the launch stream around M steps (steady
+        state: every launch carries `depth` frames of each pipeline stage)"""
+        torch = self.torch
+        self.trk.pipeline(depth)
+        self.restart()
+        n_w = max(self.Wm // depth, 1) * depth
+        self.run(n_w, None)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        n = max(M // depth, 1) * depth
+        e0.record(); self.run(n, None); e1.record()
+        self.trk.join(); torch.cuda.synchronize()
+        return e0.elapsed_time(e1) * 1e3 / n * depth
+
+    def stage_spans_us(self, HL, M):
+        """average HIP-event spans (us) of the separate stage kernels over M steps, recorded on the launch stream"""
+        self.trk.pipeline(0)
+        self.restart()
+        self.run(self.Wm, None)
+        self.trk.join()
+        HL.check(self.trk.ctx.L.agt_profile_begin(self.trk.ctx.h, M), "agt_profile_begin")
+        self.run(M, None)
+        ms = np.zeros((M, HL.PROF_SPANS), np.float32); nrec = C.c_int(0)
+        HL.check(self.trk.ctx.L.agt_profile_end(self.trk.ctx.h, ms.ctypes.data_as(C.c_void_p), C.byref(nrec)), "agt_profile_end")
+        self.trk.join()
+        return ms[:nrec.value].mean(axis=0) * 1e3
 
 
 def main():
@@ -136,135 +267,270 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
-    ap.add_argument("--workload", default="c2", choices=["c2", "c3"])
-    ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (c2: 1, c3: 64)")
+    ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--blocks", type=int, default=15, help="timed blocks of --steps steps each (median / p10 / p90 over them)")
+    ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (default: the workload's)")
     ap.add_argument("--render-frames", type=int, default=24)
     ap.add_argument("--depth", type=int, default=0,
                     help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = 4 for >= 100 timed steps, "
-                         "2 for >= 40, else 1 (short runs are dominated by filling and draining the pipeline)")
+                         "2 for >= 40, else 1 (short blocks are dominated by filling and draining the pipeline)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="TEST HOOK (CPU, gloo): launcher + rendezvous + block timing + gather with a stub tracker; the line it prints "
+                         "is marked data = dry-run and is not a measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-batch-extra", action="store_true", help="skip the 64-stream HBM-bound side measurement")
+    ap.add_argument("--no-extras", "--no-batch-extra", dest="no_extras", action="store_true",
+                    help="skip the side measurements (64-stream HBM-bound step, H2D-inclusive rate, per-call latencies)")
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        self_launch(args)                         # does not return
 
     import torch
     from accurate_aprilgroup_tracking_amd import distributed as D
     rank, local_rank, world = D.init()
-    assert world == args.gpus or world == 1 and args.gpus == 1, "launch with torch.distributed.run for --gpus > 1"
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d" % (args.gpus, world))
+    if args.dry_run:
+        return dry_run(args, torch, D, rank, world)
     dev_index = local_rank % max(torch.cuda.device_count(), 1)     # > 1 rank per GPU only in gloo rehearsals (AGT_DIST_BACKEND)
     torch.cuda.set_device(dev_index)
     dev = torch.device("cuda", dev_index)
+    rehearsal = world > 1 and os.environ.get("AGT_DIST_BACKEND") == "gloo"
 
-    from accurate_aprilgroup_tracking_amd import hiplib as HL, synthetic as syn
-    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
-
-    B = args.streams or (1 if args.workload == "c2" else 64)
-    K, Wm, NF = args.steps, args.warmup, args.render_frames
-
-    t_r = time.time()
-    seqs, rendered, ring, ring_slots, corners0 = build_stream_ring(torch, syn, dev, rank, B, NF)
-    render_s = time.time() - t_r
-    sq0 = seqs[0]
-    trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+    from accurate_aprilgroup_tracking_amd import hiplib as HL
+    wl = WORKLOADS[args.workload]
+    if wl["dense"]:
+        from bench_c5 import main_c5                     # configs[4]: its step has a fourth stage (bench_c5.py)
+        return main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal)
+    bench = Bench(torch, wl, args, rank, world, dev)
+    B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
-    auto_depth = 4 if args.steps >= 100 else (2 if args.steps >= 40 else 1)
+    auto_depth = 4 if K >= 100 else (2 if K >= 40 else 1)
     depth = max(1, min(args.depth or auto_depth, 8)) if fused else 1
-    trk.pipeline(depth)
-    fps, dt, state, gathered, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, world)
-    st = state.cpu().numpy()
-    accepted = float(st[Wm:, :, HL.ST_OK].mean())
-    iters = float(st[Wm:, :, HL.ST_ITERS].mean())
+    bench.trk.pipeline(depth)
+    dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
+    med, p10, p90 = percentiles(dts)
+    fps = world * B * K / med
+    accepted = float(st_last[:, :, HL.ST_OK].mean())
+    iters = float(st_last[:, :, HL.ST_ITERS].mean())
 
     if rank == 0:
-        ab = algorithmic_bytes()
+        ab = algorithmic_bytes(bench.W, bench.H, NPTS)
         M = max(depth, min(K, 200) // depth * depth)      # instrumented passes: whole launch groups, at least one
-        # per-launch durations from HIP events on the launch stream, second (instrumented) pass
-        stage_us = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, M, False)     # separate kernels
+        stage_us = bench.stage_spans_us(HL, M)            # separate kernels, second (instrumented) pass
         names = ["pyramid", "lk", "pnp"]
         if fused:
-            # one launch per `depth` steps: average launch period from two HIP events around M / depth launches on
-            # the launch stream (steady state: every launch carries depth frames of each pipeline stage)
-            def fused_period(d):
-                trk.pipeline(d)
-                trk.reset(ring[0], torch.from_numpy(corners0).to(dev).contiguous())
-                run(Wm // d * d, 1, None)
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record(); run(M // d * d, 1 + Wm // d * d, None); e1.record()
-                trk.join(); torch.cuda.synchronize()
-                return e0.elapsed_time(e1) * 1e3 / (M // d * d) * d
-            launch_us = fused_period(depth)
-            launch_us_d1 = fused_period(1) if depth != 1 else launch_us
+            launch_us = bench.launch_period_us(depth, M)
+            launch_us_d1 = bench.launch_period_us(1, M) if depth != 1 else launch_us
             achieved = depth * B * ab["frame"] / (launch_us * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: PnP | LK | pyrDown x2, %d consecutive frames of each stage per launch)" % depth,
+            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: PnP | LK | pyrDown, %d consecutive frames of each stage per launch)" % depth,
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth) if B == 1 else None,
+                    "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth) if (B == 1 and args.workload == "c2") else None,
                     "frac_of_measured_copy_6290GBs": round(achieved / 6290.0, 6),
                     "avg_launch_us": round(launch_us, 3), "frames_per_launch": depth, "bytes_per_launch": int(depth * B * ab["frame"]),
                     "one_frame_per_launch": {"avg_launch_us": round(launch_us_d1, 3), "frames_per_s": round(B / (launch_us_d1 * 1e-6), 1)},
-                    "note": "latency-bound by construction: one 720p stream is a serial chain of ~10 LK and 4 LM iterations"}
+                    "note": "latency-bound by construction: one stream is a serial chain of ~10 LK and 4 LM iterations per frame"}
         else:
             dom = int(np.argmax(stage_us))
             launches = {"pyramid": LEVELS - 1, "lk": 1, "pnp": 1}[names[dom]]
             kernel_us = float(stage_us[dom]) / launches
             achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down_kernel", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
+            whole = B * ab["frame"] / (med / K) / 1e9
+            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down kernels", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": None, "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(B * ab[names[dom]] / launches)}
+                    "traffic": None, "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(B * ab[names[dom]] / launches),
+                    "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 4),
+                                   "bytes_per_step": int(B * ab["frame"])}}
         roof["separate_kernel_spans_us"] = {n: round(float(v), 3) for n, v in zip(names, stage_us)}
 
-        extra = None
-        if args.workload == "c2" and world == 1 and not args.no_batch_extra:
-            extra = batch_extra(torch, D, HL, syn, StreamTracker, dev, rank, NF)
+        extras = {}
+        if args.workload == "c2" and world == 1 and not args.no_extras:
+            bench.trk.pipeline(depth)
+            extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
+            del bench.ring
+            torch.cuda.empty_cache()
+            extras["batch64_hbm"] = batch_extra(torch, D, HL, args, rank, dev)
+            extras["per_call_latency_us"] = per_call_latency(bench)
 
         cpu = pose_err = None
         if not args.no_cpu_baseline and world == 1:
-            cpu, pose_err = cpu_baseline(seqs[0], rendered[:, 0], st[:, 0], Wm, K, NF)
+            cpu, pose_err = cpu_baseline(bench.seqs[0], bench.rendered[:, 0], np.concatenate([st_warm[:Wm, 0], st_first[:, 0]]), Wm, K, bench.NF)
         out = {"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(fps, 2), "unit": "frames/s",
-               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(dt / K * 1e3, 5),
+               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(med / K * 1e3, 5),
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP)",
                "data": "synthetic",
-               "config": {"workload": "%s: %d x 1280x720 stream(s) per GPU, 12 tags/48 corners, 3-level LK 21x21, "
-                                      "iterative PnP with motion-model guess" % (args.workload, B),
-                          "streams_per_gpu": B, "frames_resident": "HBM ring %d slots (%.0f MiB)" % (ring_slots, ring.numel() / 2**20),
-                          "parallelism": "stream-per-GPU x%d, RCCL all_gather of poses once" % world,
+               "config": {"workload": wl["label"] % B, "streams_per_gpu": B,
+                          "frames_resident": "HBM ring %d slots (%.0f MiB)" % (bench.ring_slots, bench.ring_slots * B * bench.W * bench.H / 2**20),
+                          "parallelism": "stream-per-GPU x%d, %s all_gather of poses once per block" % (world, "gloo (REHEARSAL: ranks share GPUs)" if rehearsal else "RCCL"),
                           "launch": ("fused software-pipelined step, %d frames per launch (record of frame t written ~%d steps later)"
-                                     % (depth, (LEVELS + 1) * depth)) if fused else "separate kernels per stage"},
+                                     % (depth, LEVELS * depth)) if fused else "stage kernels per step"},
+               "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
+                          "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5),
+                          "value_p10": round(world * B * K / p90, 2), "value_p90": round(world * B * K / p10, 2)},
                "roofline": roof, "cpu_baseline": cpu,
                "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
-               "batch64_hbm": extra, "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape)}
+               "render_s": round(bench.render_s, 1), "gathered_shape": list(gathered.shape)}
+        out.update(extras)
+        if rehearsal:
+            out["rehearsal"] = True
         print(json.dumps(out), flush=True)
     D.barrier()
 
 
-def batch_extra(torch, D, HL, syn, StreamTracker, dev, rank, NF):
-    """BASELINE.json configs[2]-style side measurement: 64 independent 1280x720 streams per step (stage kernels on three
-    overlapped library streams; the spans come from a second, serial pass).  Reports whole-step frames/s and the pyrDown
-    kernel's HBM rate."""
-    B, K, Wm = 64, 60, 10
-    seqs, rendered, ring, ring_slots, corners0 = build_stream_ring(torch, syn, dev, rank, B, min(NF, 8))
-    trk = StreamTracker(W, H, seqs[0].obj, seqs[0].K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
-    fps, dt, state, _, run = time_tracker(torch, D, HL, trk, ring, ring_slots, corners0, dev, B, K, Wm, 1)
-    spans = event_spans(trk, HL, run, ring, corners0, torch, dev, Wm, 40, False)
-    ab = algorithmic_bytes()
-    pyr_gbs = B * ab["pyramid"] / (float(spans[0]) * 1e-6) / 1e9
-    ok = float(state.cpu().numpy()[Wm:, :, HL.ST_OK].mean())
-    del ring
+def dry_run(args, torch, D, rank, world):
+    """--dry-run: the multi-rank flow of this file without a GPU (see StubTracker)."""
+    bench = Bench(torch, WORKLOADS[args.workload], args, rank, world, torch.device("cpu"))
+    dts, _, first, last, gathered = bench.timed_blocks(D, max(1, args.blocks))
+    med, p10, p90 = percentiles(dts)
+    g = gathered.cpu().numpy()
+    # every rank's block came back from the gather, in rank order, with the frame numbers of the LAST block
+    ok = g.shape[0] == world and all((g[r, :, :, 0] == r).all() for r in range(world)) and (np.diff(g[0, :, 0, 1]) == 1).all()
+    if rank == 0:
+        print(json.dumps({"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(world * bench.B * bench.K / med, 2),
+                          "unit": "frames/s", "n_gpus": world, "steps": bench.K, "warmup": bench.Wm, "ms_per_step": round(med / bench.K * 1e3, 5),
+                          "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (stub tracker, no GPU work: NOT a measurement)",
+                          "config": {"workload": "dry-run"}, "timing": {"blocks": len(dts), "steps_per_block": bench.K},
+                          "gathered_shape": list(gathered.shape), "gather_ok": bool(ok), "dry_run": True}), flush=True)
+    D.barrier()
+    if not ok:
+        raise SystemExit(3)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def h2d_inclusive(torch, bench, K):
+    """the rate INCLUDING the upload of every frame from pinned host memory (the reference's frames originate
+    on the host, detect_pose.py:669-681).  A copy stream uploads chunk c+1 (G frames, one hipMemcpyAsync) while the tracker
+    works on chunk c; events order upload -> step and step -> buffer reuse.  Never `value`."""
+    W, H, B = bench.W, bench.H, bench.B
+    G, NB = 2, 8                                    # frames per upload, chunk buffers on the device
+    P = bench.period - bench.period % G
+    host = torch.empty((P, B, H, W), dtype=torch.uint8).pin_memory()
+    host.copy_(bench.ring[1:P + 1].cpu())           # stream order: frame k of the run is ring[(k + 1) % slots]
+    devb = torch.empty((NB, G, B, H, W), dtype=torch.uint8, device=bench.dev)
+    copy_s = torch.cuda.Stream()
+    up = [torch.cuda.Event() for _ in range(NB)]
+    done = [torch.cuda.Event() for _ in range(NB)]
+    main_s = torch.cuda.current_stream()
+    n = (max(K, 200) // P) * P or P
+    bench.trk.pipeline(1)
+    bench.restart()
+    state = torch.zeros((n, B, 16), dtype=torch.float64, device=bench.dev)
+
+    def go(chunks, out, c0):
+        for c in range(c0, c0 + chunks):
+            cb = c % NB
+            with torch.cuda.stream(copy_s):
+                # a frame is dead three launches after its own (LK of the next frame reads it last): chunk c - NB is dead once
+                # chunk c - NB + 2 has run, whose `done` event was recorded NB - 2 chunks ago
+                if c - c0 >= NB:
+                    copy_s.wait_event(done[(c - NB + 2) % NB])
+                h0 = (c * G) % P
+                devb[cb].copy_(host[h0:h0 + G], non_blocking=True)
+                up[cb].record(copy_s)
+            main_s.wait_event(up[cb])
+            for g in range(G):
+                k = (c - c0) * G + g
+                bench.trk.step(devb[cb, g], out[k] if out is not None else None)
+                bench.since += 1
+            done[cb].record(main_s)
+    go(20, None, 0)
+    bench.trk.join(); torch.cuda.synchronize()
+    bench.restart()                                  # frame 0 again: host[0] is frame 1 of the stream
+    t0 = time.perf_counter()
+    go(n // G, state, 0)
+    bench.trk.join(); torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ok = float(state.cpu().numpy()[:, :, 6].mean())
+    t1 = time.perf_counter()
+    for k in range(32):
+        devb[k % NB].copy_(host[(k * G) % P:(k * G) % P + G], non_blocking=True)
+    torch.cuda.synchronize()
+    up_dt = (time.perf_counter() - t1) / (32 * G)
+    del host, devb
+    return {"frames_per_s": round(B * n / dt, 1), "ms_per_step": round(dt / n * 1e3, 5), "accepted_frac": round(ok, 4),
+            "upload_only_us_per_frame": round(up_dt * 1e6, 2), "upload_GBs": round(B * W * H / up_dt / 1e9, 2),
+            "note": "pinned host frames uploaded %d per copy on a copy stream (%d device buffers), depth-1 fused step; PCIe Gen5 x16 = 63 GB/s spec"
+                    % (G, NB * G)}
+
+
+def batch_extra(torch, D, HL, args, rank, dev):
+    """BASELINE.json configs[2] side measurement: 64 independent 1280x720 streams per step."""
+    a = argparse.Namespace(**vars(args))
+    a.steps, a.warmup, a.streams, a.render_frames = 60, 10, 64, min(args.render_frames, 8)
+    wl = WORKLOADS["c3"]
+    b = Bench(torch, wl, a, rank, 1, dev)
+    b.trk.pipeline(1)
+    dts, _, _, st, _ = b.timed_blocks(D, 7)
+    med, p10, p90 = percentiles(dts)
+    spans = b.stage_spans_us(HL, 40)
+    ab = algorithmic_bytes(b.W, b.H, b.npts)
+    step_bytes = 64 * ab["frame"]
+    pyr_gbs = 64 * ab["pyramid"] / (float(spans[0]) * 1e-6) / 1e9
+    ok = float(st[:, :, HL.ST_OK].mean())
+    del b
     torch.cuda.empty_cache()
-    return {"workload": "64 x 1280x720 streams per step, stage kernels overlapped on three streams (span_us: serial pass)", "frames_per_s": round(fps, 1),
-            "ms_per_step": round(dt / K * 1e3, 4), "span_us": {"pyramid(2 launches)": round(float(spans[0]), 2),
-                                                                "lk": round(float(spans[1]), 2), "pnp": round(float(spans[2]), 2)},
+    return {"workload": wl["label"] % 64 + " (span_us: serial pass of the stage kernels)", "frames_per_s": round(64 * 60 / med, 1),
+            "ms_per_step": round(med / 60 * 1e3, 4), "ms_per_step_p10": round(p10 / 60 * 1e3, 4), "ms_per_step_p90": round(p90 / 60 * 1e3, 4),
+            "whole_step_algorithmic_GBs": round(step_bytes / (med / 60) / 1e9, 1), "whole_step_frac_of_8TBs": round(step_bytes / (med / 60) / 1e9 / HBM_PEAK_GBS, 4),
+            "span_us": {"pyramid": round(float(spans[0]), 2), "lk": round(float(spans[1]), 2), "pnp": round(float(spans[2]), 2)},
             "pyr_down_algorithmic_GBs": round(pyr_gbs, 1), "pyr_down_frac_of_8TBs": round(pyr_gbs / HBM_PEAK_GBS, 4),
             "accepted_frac": round(ok, 4)}
 
 
+_native = []
+
+
+def native_oracle():
+    """the CPU oracle, rebuilt -O3 -march=native on this host the first time it is needed (cpu_baseline legs only)"""
+    from oracle import cvoracle as cvo
+    if not _native:
+        _native.append(cvo.select_native() if cvo._lib is None else cvo.BUILD_FLAGS)
+        cvo.build()
+    return cvo, _native[0]
+
+
+def per_call_latency(bench):
+    """INTEGRATION.md section 1 ("smallest change"): the synchronous numpy-in / numpy-out cv_hip calls a maintainer swaps in
+    for cv2, next to the same calls answered by the CPU oracle on this host (median of 60 calls each, us)."""
+    from accurate_aprilgroup_tracking_amd import cv_hip
+    cvo = native_oracle()[0]
+    sq = bench.seqs[0]
+    a, b, pts = sq.frame(0), sq.frame(1), sq.corners(0)
+    obj = sq.obj.astype(np.float32)
+    nx = sq.corners(1)
+
+    def med(fn, n=60):
+        fn(); fn()
+        ts = []
+        for _ in range(n):
+            t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
+        return round(float(np.median(ts)) * 1e6, 1)
+    r0, t0_ = sq.rvecs[0].copy(), sq.tvecs[0].copy()
+    out = {
+        "solvePnP_guess_N48": {"hip": med(lambda: cv_hip.solvePnP(obj, nx, sq.K, None, r0.copy(), t0_.copy(), True)),
+                               "cpu_oracle": med(lambda: cvo.solvePnP(obj, nx, sq.K, None, r0.copy(), t0_.copy(), True))},
+        "solvePnP_noguess_N48": {"hip": med(lambda: cv_hip.solvePnP(obj, nx, sq.K, None)),
+                                 "cpu_oracle": med(lambda: cvo.solvePnP(obj, nx, sq.K, None))},
+        "projectPoints_N48": {"hip": med(lambda: cv_hip.projectPoints(sq.obj, r0, t0_, sq.K, None)),
+                              "cpu_oracle": med(lambda: cvo.projectPoints(sq.obj, r0, t0_, sq.K, None))},
+        "calcOpticalFlowPyrLK_%dx%d_N48" % (bench.W, bench.H): {
+            "hip": med(lambda: cv_hip.calcOpticalFlowPyrLK(a, b, pts, maxLevel=2), 30),
+            "cpu_oracle": med(lambda: cvo.calcOpticalFlowPyrLK(a, b, pts, maxLevel=2), 30)},
+        "note": "one synchronous call: host arrays in, kernel(s), host arrays out; the device-resident StreamTracker is the throughput path",
+    }
+    return out
+
+
 def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
-    """Reference CPU path stand-in ("port"): the oracle's cvo_track_frame (full padded pyramids,
-    full-frame Scharr image per level, per-point LK, FP64 LM) on ONE host core, on a bounded
-    sample of the same stream; plus the pose difference HIP vs CPU chain on identical frames."""
+    """Reference CPU path stand-in ("port"): the oracle's cvo_track_frame (full padded pyramids, full-frame Scharr image
+    per level, per-point LK, FP64 LM; OpenCV's dataflow), compiled -O3 -march=native ON THIS HOST, on a bounded sample of the same
+    stream: ~10 s on ONE core, ~5 s with the full-frame passes and the point loop threaded.  Plus the pose difference HIP
+    vs the CPU chain on identical frames."""
     import logging, tempfile
-    from oracle import cvoracle as cvo, cv2_shim
+    from oracle import cv2_shim
     from accurate_aprilgroup_tracking_amd import hiplib as HL
     from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
-    cvo.build()
+    cvo, flags = native_oracle()
+    H_, W_ = frames[0].shape
     # -- timing: ~10 s of CPU work
     pyr = cvo.Pyramid(frames[0]); pts = seq.corners(0)
     r, t = seq.rvecs[0].copy(), seq.tvecs[0].copy()
@@ -276,12 +542,11 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
         if time.perf_counter() - t0 > 10.0 or n >= 20000:
             break
     dt = time.perf_counter() - t0
-    # same chain with OpenMP over rows / points on every host core (as OpenCV's parallel_for_), ~5 s
     try:
         nthr = len(os.sched_getaffinity(0))
     except AttributeError:
         nthr = os.cpu_count() or 1
-    nthr = max(1, min(nthr, 16))          # the GPU box grants about 16 cores per GPU; 48 corners do not scale further anyway
+    nthr = max(1, min(nthr, 16))          # the GPU box grants about 16 cores per GPU
     pyr2 = cvo.Pyramid(frames[0]); pts2 = seq.corners(0)
     r2, t2 = seq.rvecs[0].copy(), seq.tvecs[0].copy()
     n2 = 0; t1 = time.perf_counter()
@@ -289,14 +554,15 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
         k = pingpong(n2 + 1, NF)
         pyr2, pts2, _, _, _, r2, t2 = cvo.track_frame(pyr2, frames[k], pts2, seq.obj, seq.K, None, r2, t2, nthreads=nthr)
         n2 += 1
-        if time.perf_counter() - t1 > 5.0 or n2 >= 4000:
+        if time.perf_counter() - t1 > 5.0 or n2 >= 8000:
             break
     dt2 = time.perf_counter() - t1
     cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same 1280x720 stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores"
-                     % (n, dt, os.cpu_count()),
-           "cpu_model": cpu_model(),
-           "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr, "sample": "%d frames, %.1f s" % (n2, dt2)} if n2 else None}
+           "sample": "%d frames of the same %dx%d stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores"
+                     % (n, W_, H_, dt, os.cpu_count()),
+           "cpu_model": cpu_model(), "build": flags,
+           "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr,
+                         "sample": "%d frames, %.1f s; pyrDown / Scharr in %d bands of rows, LK over points (OpenMP)" % (n2, dt2, nthr)} if n2 else None}
     # -- parity: reference-validated state machine on the oracle backend over the first frames
     tmp = tempfile.mkdtemp()
     open(os.path.join(tmp, "april_group.json"), "w").write(json.dumps(seq.group))
@@ -306,15 +572,18 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
     log = logging.getLogger("bench"); log.setLevel(logging.CRITICAL)
     det = Det(log, seq.K, None, True, cv=cv2_shim.make_cv2())
     obj32 = seq.obj.astype(np.float32)
+    npts = obj32.shape[0]
     pyr = cvo.Pyramid(frames[0]); pts = seq.corners(0)
-    nchk = min(Wm + K, 60)
+    alive = np.ones(npts, bool)
+    nchk = min(len(gpu_state), 60)
     dr = dtv = 0.0
     for i in range(nchk):
         npyr = cvo.Pyramid(frames[pingpong(i + 1, NF)])
         nx, status, _ = cvo.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
-        nx = nx.reshape(-1, 2); status = status.ravel()
-        il = [nx[j].reshape(1, 1, 2) for j in range(len(nx)) if status[j]]
-        ol = [obj32[j].reshape(1, 3) for j in range(len(nx)) if status[j]]
+        nx = nx.reshape(-1, 2); status = status.ravel().astype(bool)
+        nx[~alive] = pts[~alive]; alive &= status              # the tracker's sticky status
+        il = [nx[j].reshape(1, 1, 2) for j in range(npts) if alive[j]]
+        ol = [obj32[j].reshape(1, 3) for j in range(npts) if alive[j]]
         det._estimate_pose(il if len(il) >= 8 else [], ol if len(il) >= 8 else [])
         if det.last_pose[0] is not None and gpu_state[i, HL.ST_OK]:
             dr = max(dr, float(np.linalg.norm(gpu_state[i, :3] - det.last_pose[0].ravel())))

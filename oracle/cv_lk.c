@@ -37,6 +37,13 @@ struct cvo_pyramid {
     struct cvo_level lv[CVO_MAX_LEVELS];
 };
 
+/* threads for the full-frame passes (pyrDown, Scharr, the derivative buffer's zero fill): bands of rows, as OpenCV's
+ * parallel_for_ stripes.  Set by cvo_set_num_threads / cvo_track_frame; 1 = serial.  Band edges do not change any
+ * value: every output row depends on its own source rows only. */
+static int g_frame_threads = 1;
+void cvo_set_num_threads(int n) { g_frame_threads = n > 0 ? n : 1; }
+int cvo_get_num_threads(void) { return g_frame_threads; }
+
 /* cv::borderInterpolate(p, len, BORDER_REFLECT_101) */
 static inline int reflect101(int p, int len)
 {
@@ -56,15 +63,23 @@ int cvo_pyr_down_u8(const uint8_t* src, int sw, int sh, int sstride,
 {
     if (!src || !dst || sw <= 0 || sh <= 0) return -1;
     const int dw = (sw + 1) / 2, dh = (sh + 1) / 2;
-    int* ring = (int*)malloc((size_t)5 * dw * sizeof(int));
+    int nb = g_frame_threads < dh / 8 ? g_frame_threads : dh / 8;
+    if (nb < 1) nb = 1;
+    int* rings = (int*)malloc((size_t)nb * 5 * dw * sizeof(int));
     int* xtab = (int*)malloc((size_t)5 * dw * sizeof(int));
-    if (!ring || !xtab) { free(ring); free(xtab); return -2; }
-    int slot_row[5] = { -1, -1, -1, -1, -1 };
+    if (!rings || !xtab) { free(rings); free(xtab); return -2; }
     for (int x = 0; x < dw; x++)
         for (int k = 0; k < 5; k++)
             xtab[x * 5 + k] = reflect101(2 * x - 2 + k, sw);
 
-    for (int y = 0; y < dh; y++) {
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nb) schedule(static)
+#endif
+    for (int band = 0; band < nb; band++) {
+    int* ring = rings + (size_t)band * 5 * dw;
+    int slot_row[5] = { -1, -1, -1, -1, -1 };
+    const int y_lo = (int)((long)dh * band / nb), y_hi = (int)((long)dh * (band + 1) / nb);
+    for (int y = y_lo; y < y_hi; y++) {
         const int* rows[5];
         for (int k = 0; k < 5; k++) {
             int sy = reflect101(2 * y - 2 + k, sh);
@@ -87,7 +102,8 @@ int cvo_pyr_down_u8(const uint8_t* src, int sw, int sh, int sstride,
             d[x] = (uint8_t)((v + 128) >> 8);   /* FixPtCast<uchar, 8> */
         }
     }
-    free(ring); free(xtab);
+    }
+    free(rings); free(xtab);
     return 0;
 }
 
@@ -181,11 +197,19 @@ int cvo_scharr_deriv(const uint8_t* src, int w, int h, int sstride,
                      int16_t* dst, int dstride)
 {
     if (!src || !dst || w <= 0 || h <= 0) return -1;
-    int16_t* buf = (int16_t*)malloc((size_t)2 * (w + 2) * sizeof(int16_t));
-    if (!buf) return -2;
+    int nb = g_frame_threads < h / 8 ? g_frame_threads : h / 8;
+    if (nb < 1) nb = 1;
+    int16_t* bufs = (int16_t*)malloc((size_t)nb * 2 * (w + 2) * sizeof(int16_t));
+    if (!bufs) return -2;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nb) schedule(static)
+#endif
+    for (int band = 0; band < nb; band++) {
+    int16_t* buf = bufs + (size_t)band * 2 * (w + 2);
     int16_t* trow0 = buf + 1;
     int16_t* trow1 = buf + (w + 2) + 1;
-    for (int y = 0; y < h; y++) {
+    const int y_lo = (int)((long)h * band / nb), y_hi = (int)((long)h * (band + 1) / nb);
+    for (int y = y_lo; y < y_hi; y++) {
         const uint8_t* srow0 = src + (size_t)(y > 0 ? y - 1 : h > 1 ? 1 : 0) * sstride;
         const uint8_t* srow1 = src + (size_t)y * sstride;
         const uint8_t* srow2 = src + (size_t)(y < h - 1 ? y + 1 : h > 1 ? h - 2 : 0) * sstride;
@@ -205,7 +229,8 @@ int cvo_scharr_deriv(const uint8_t* src, int w, int h, int sstride,
             drow[x * 2] = t0; drow[x * 2 + 1] = t1;
         }
     }
-    free(buf);
+    }
+    free(bufs);
     return 0;
 }
 
@@ -413,7 +438,16 @@ int cvo_lk_on_pyramids(const cvo_pyramid* prev_pyr, const cvo_pyramid* next_pyr,
         const struct cvo_level* J = &next_pyr->lv[level];
         int dstep = (I->w + 2 * win_w) * 2;
         /* copyMakeBorder(derivI, _derivI, ..., BORDER_CONSTANT): zero padding */
-        memset(dbuf, 0, (size_t)dstep * (I->h + 2 * win_h) * sizeof(int16_t));
+        {
+            const int rows = I->h + 2 * win_h, nbz = g_frame_threads < rows / 8 ? (g_frame_threads > 0 ? g_frame_threads : 1) : 1;
+#ifdef _OPENMP
+#pragma omp parallel for num_threads(nbz) schedule(static)
+#endif
+            for (int band = 0; band < nbz; band++) {
+                const int r0 = (int)((long)rows * band / nbz), r1 = (int)((long)rows * (band + 1) / nbz);
+                memset(dbuf + (size_t)r0 * dstep, 0, (size_t)dstep * (r1 - r0) * sizeof(int16_t));
+            }
+        }
         int16_t* dorg = dbuf + (size_t)win_h * dstep + win_w * 2;
         cvo_scharr_deriv(level_origin(I), I->w, I->h, I->stride, dorg, dstep);
 

@@ -152,6 +152,10 @@ int cvo_svd(const double* A, int m, int n, double* w, double* u, double* vt);
 int cvo_solve_svd(const double* A, const double* b, int n, double* x);
 
 /* ---- whole reference CPU frame step, for the timed baseline ---- */
+/* threads used by the full-frame passes (pyrDown, Scharr) -- bands of rows, results independent of the count */
+void cvo_set_num_threads(int n);
+int cvo_get_num_threads(void);
+
 /* pyramid(next) + LK(prev_pyr -> next) + solvePnP(guess) on status==1 points.
  * Returns number of tracked points used (<0 on error). next_pyr_out receives the new pyramid. */
 int cvo_track_frame(const cvo_pyramid* prev_pyr, const uint8_t* next_img, int w, int h, int stride,

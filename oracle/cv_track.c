@@ -11,7 +11,7 @@
 #include "cv_oracle.h"
 #include <stdlib.h>
 
-int cvo_track_frame(const cvo_pyramid* prev_pyr, const uint8_t* next_img, int w, int h, int stride,
+static int track_frame_impl(const cvo_pyramid* prev_pyr, const uint8_t* next_img, int w, int h, int stride,
                     const float* prev_pts, float* next_pts, uint8_t* status, float* err, int npoints,
                     const double* obj, const double K[9], const double* dist, int ndist,
                     double rvec[3], double tvec[3], int use_guess,
@@ -48,4 +48,20 @@ int cvo_track_frame(const cvo_pyramid* prev_pyr, const uint8_t* next_img, int w,
     free(o);
     if (next_pyr_out) *next_pyr_out = N; else cvo_pyramid_free(N);
     return cnt;
+}
+
+int cvo_track_frame(const cvo_pyramid* prev_pyr, const uint8_t* next_img, int w, int h, int stride,
+                    const float* prev_pts, float* next_pts, uint8_t* status, float* err, int npoints,
+                    const double* obj, const double K[9], const double* dist, int ndist,
+                    double rvec[3], double tvec[3], int use_guess,
+                    int win, int max_level, int crit_max_count, double crit_eps,
+                    int acc_mode, int nthreads, cvo_pyramid** next_pyr_out)
+{
+    /* the full-frame passes (pyrDown, Scharr) run in `nthreads` bands of rows, the per-point loop over points */
+    const int old = cvo_get_num_threads();
+    cvo_set_num_threads(nthreads);
+    const int rc = track_frame_impl(prev_pyr, next_img, w, h, stride, prev_pts, next_pts, status, err, npoints, obj, K, dist, ndist,
+                                    rvec, tvec, use_guess, win, max_level, crit_max_count, crit_eps, acc_mode, nthreads, next_pyr_out);
+    cvo_set_num_threads(old);
+    return rc;
 }

@@ -28,6 +28,24 @@ def build(force=False):
     return _LIB_PATH
 
 
+BUILD_FLAGS = "-O3 -march=x86-64-v3 -ffp-contract=off -fopenmp (portable build)"
+
+
+def select_native():
+    """bench.py's cpu_baseline: rebuild the same sources with -march=native ON THE HOST THAT RUNS THEM and bind that
+    library instead (must be called before the first lib() of the process).  Falls back to the portable build when
+    the host has no compiler.  Returns the flags in use."""
+    global _LIB_PATH, BUILD_FLAGS
+    assert _lib is None, "select_native() after the oracle was loaded"
+    try:
+        subprocess.check_call(["make", "-C", _HERE, "-s", "-B", "native"], stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+        _LIB_PATH = os.path.join(_HERE, "_native", "libcvoracle_native.so")
+        BUILD_FLAGS = "-O3 -march=native -ffp-contract=off -fopenmp (built on this host)"
+    except (subprocess.CalledProcessError, OSError):
+        pass
+    return BUILD_FLAGS
+
+
 _lib = None
 
 

@@ -131,7 +131,7 @@ def test_config5_sizes_240_corners_61440_samples(oracle):
     """BASELINE configs[4]: 60 tags / 240 corners + 60 x 32 x 32 dense samples on a 1280x720 frame"""
     import torch
     from accurate_aprilgroup_tracking_amd import cv_hip
-    s = syn.Sequence(1280, 720, n_tags=60, n_frames=2, seed=8, supersample=2, z0=0.62)
+    s = syn.Sequence(1280, 720, n_tags=60, n_frames=2, seed=8, supersample=2)
     mx = syn.model_samples(s.group, 32)
     assert mx.shape[0] == 61440 and s.obj.shape[0] == 240
     T = np.nan_to_num(syn.sample_bilinear(s.frame(1), syn.project(mx, s.rvecs[1], s.tvecs[1], s.K)), nan=128.0).astype(np.float32)

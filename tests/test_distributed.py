@@ -61,3 +61,45 @@ def test_single_process_is_passthrough():
     t = torch.arange(24, dtype=torch.float64).reshape(3, 1, 8)
     assert torch.equal(D.gather_poses(t), t.unsqueeze(0))
     assert D.max_over_ranks(2.5, torch.device("cpu")) == 2.5
+
+
+def _bench_json(cmd, env=None):
+    import json, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    p = subprocess.run(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+    assert p.returncode == 0, p.stderr[-2000:]
+    lines = [l for l in p.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]              # ONE JSON line, from rank 0 only
+    return json.loads(lines[0])
+
+
+def test_bench_self_launch_world2_gloo():
+    """`python bench.py --gpus 2` invoked PLAINLY (how the driver calls it) must start its own ranks
+    before touching a GPU, run the block timing (barrier / max over ranks) and the pose gather, and relay one JSON line.
+    --dry-run swaps the tracker for a stub so this runs on the CPU under gloo."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    j = _bench_json([sys.executable, "bench.py", "--gpus", "2", "--steps", "6", "--warmup", "2", "--blocks", "4", "--dry-run"], env)
+    assert j["n_gpus"] == 2 and j["steps"] == 6 and j["warmup"] == 2 and j["dry_run"] and j["gather_ok"]
+    assert j["gathered_shape"] == [2, 6, 1, 16] and j["timing"]["blocks"] == 4
+    assert "dry-run" in j["data"]
+
+
+def test_bench_under_torchrun_world2_gloo():
+    """the driver's N > 1 form: python -m torch.distributed.run ... bench.py --gpus 2 (ranks given by the launcher)"""
+    import sys
+    env = dict(os.environ, AGT_DIST_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE"):
+        env.pop(k, None)
+    j = _bench_json([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                     "--master-port", str(_free_port()), "bench.py", "--gpus", "2", "--steps", "5", "--warmup", "1", "--blocks", "2", "--dry-run"], env)
+    assert j["n_gpus"] == 2 and j["gather_ok"] and j["gathered_shape"] == [2, 5, 1, 16]
+
+
+def test_bench_rejects_world_mismatch():
+    import subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, "bench.py", "--gpus", "2", "--dry-run", "--steps", "2"], cwd=root, env=env,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=300, text=True)
+    assert p.returncode != 0 and "WORLD_SIZE" in p.stderr

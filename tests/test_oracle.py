@@ -179,3 +179,22 @@ def test_end_to_end_pose_from_rendered_frames(oracle, seq640):
         pyr, pts, st, er, cnt, r, t = oracle.track_frame(pyr, s.frame(k), pts, s.obj, s.K, None, r, t)
         assert cnt == 48
         assert np.abs(r - s.rvecs[k]).max() < 2e-3 and np.abs(t - s.tvecs[k]).max() < 2e-3
+
+
+def test_threaded_full_frame_passes_are_band_invariant(oracle):
+    """the cpu_baseline threads pyrDown / Scharr in bands of rows: every band count must give the serial bytes"""
+    rng = np.random.default_rng(3)
+    img = rng.integers(0, 256, (243, 317), dtype=np.uint8)
+    L = oracle.lib()
+    ref_s = oracle.scharr(img)
+    ref_p = [oracle.Pyramid(img, max_level=3).level(l) for l in range(4)]
+    try:
+        for nt in (2, 3, 8, 64):
+            L.cvo_set_num_threads(nt)
+            assert L.cvo_get_num_threads() == nt
+            assert np.array_equal(oracle.scharr(img), ref_s)
+            p = oracle.Pyramid(img, max_level=3)
+            for l in range(4):
+                assert np.array_equal(p.level(l), ref_p[l])
+    finally:
+        L.cvo_set_num_threads(1)
