@@ -52,9 +52,12 @@ struct agt_ctx {
     short2* map1; unsigned short* map2; int map_w, map_h;
     // scratch of the dense refinement: per-block partial sums and the per-stream done words
     double* dense_partials; int* dense_done; size_t dense_cap; int dense_done_B;   // capacities: doubles / streams
+    // dense stage of the tracker (agt_tracker_dense): model retained by pointer
+    const float* dn_xyz; const float* dn_t; int dn_M, dn_iters, dn_reseed; double dn_weight;
     // optional per-kernel timing (agt_profile_begin/end)
     hipEvent_t* prof_ev;
     int prof_cap, prof_n;
+    int* prof_dense;                         // per recorded frame: dense iterations whose launches carry events
 };
 
 static int ms_join(agt_ctx* c);
@@ -209,6 +212,7 @@ int agt_destroy(agt_ctx* c)
     if (c->prof_ev) {
         for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
         delete[] c->prof_ev;
+        delete[] c->prof_dense;
     }
     delete c;
     return AGT_OK;
@@ -680,6 +684,49 @@ static int ms_join(agt_ctx* c)
     return AGT_OK;
 }
 
+// pyrDown.. -> LK -> PnP (+ dense stage) as separate launches on the context's stream: pose complete in stream order
+static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                       double* d_state_out, double* d_dense_out, hipEvent_t* pev)
+{
+    int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first
+    if (rc) return rc;
+    const long t = c->trk_frame + 1;
+    const int slot = (int)(t % c->live_ring), pslot = (int)((t - 1) % c->live_ring);
+    hipStream_t M = c->stream;
+    if (pev) (void)hipEventRecord(pev[0], M);
+    rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
+    if (rc) return rc;
+    if (pev) (void)hipEventRecord(pev[1], M);
+    rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
+                     c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+    if (rc) return rc;
+    if (pev) (void)hipEventRecord(pev[2], M);
+    AgtPnpParams p;
+    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
+    if (d_dense_out) {
+        const size_t need = (size_t)B * (size_t)(agt_dense_blocks(c->dn_M) > 0 ? agt_dense_blocks(c->dn_M) : 1) * 32;
+        rc = dense_scratch(c, need, B);
+        if (rc) return rc;
+        p.dense_pose = c->pose; p.dense_done = c->dense_done; p.dense_rec = d_dense_out;
+    }
+    hipError_t e = agt_launch_pnp(M, p, B);
+    if (e != hipSuccess) return hip_fail(c, e);
+    if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
+    if (d_dense_out) {
+        // dense photometric + geometric refinement of the frame's accepted pose, then (reseed) the corner set from it
+        e = agt_launch_dense(M, d_frames, (long)pitch, (long)batch_stride, c->cfg.width, c->cfg.height, c->dn_xyz, c->dn_t, c->dn_M,
+                             c->obj, c->corners[slot], c->status[slot], c->trk_n, c->cam, c->pose, c->dense_partials, nullptr,
+                             c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX);
+        if (pev) c->prof_dense[c->prof_n - 1] = c->dn_iters < AGT_PROF_DENSE_MAX ? c->dn_iters : AGT_PROF_DENSE_MAX;
+        if (e == hipSuccess && c->dn_reseed)
+            e = agt_launch_dense_reseed(M, d_dense_out, c->obj, c->trk_n, c->cam, c->corners[slot], c->status[slot], B);
+        if (e != hipSuccess) return hip_fail(c, e);
+    }
+    c->trk_frame = t; c->n_lk = c->n_pnp = t;
+    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
+    return AGT_OK;
+}
+
 // One frame for B streams.
 //   pipeline on  (default, needs reproject == 0): ONE fused launch; frame t's pose is produced
 //                 L+1 launches later (or by agt_tracker_join / agt_synchronize).
@@ -708,27 +755,7 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
         return step_multistream(c, d_frames, pitch, batch_stride, B, d_state_out);
     }
 
-    int rc = agt_tracker_join(c);            // a mode switch drains the pipeline first
-    if (rc) return rc;
-    const long t = c->trk_frame + 1;
-    const int slot = (int)(t % c->live_ring), pslot = (int)((t - 1) % c->live_ring);
-    hipStream_t M = c->stream;
-    if (pev) (void)hipEventRecord(pev[0], M);
-    rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
-    if (rc) return rc;
-    if (pev) (void)hipEventRecord(pev[1], M);
-    rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
-                     c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
-    if (rc) return rc;
-    if (pev) (void)hipEventRecord(pev[2], M);
-    AgtPnpParams p;
-    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
-    hipError_t e = agt_launch_pnp(M, p, B);
-    if (e != hipSuccess) return hip_fail(c, e);
-    if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
-    c->trk_frame = t; c->n_lk = c->n_pnp = t;
-    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
-    return AGT_OK;
+    return step_serial(c, d_frames, pitch, batch_stride, B, d_state_out, nullptr, pev);
 }
 
 int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }
@@ -933,8 +960,31 @@ int agt_dense_refine(agt_ctx* c, const uint8_t* d_img, size_t pitch, size_t batc
     if (rc) return rc;
     hipError_t e = agt_launch_dense(c->stream, d_img, (long)pitch, (long)batch_stride, w, h, d_model_xyz, d_model_t, M,
                                     d_obj, d_img_pts, d_mask, N, cam, d_pose, c->dense_partials, d_stats, c->dense_done,
-                                    B, iters, photo_weight, 1e-3);
+                                    B, iters, photo_weight, 1e-3, nullptr);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// dense stage of the per-frame step (BASELINE configs[4]); semantics in include/agt_hip.h
+int agt_tracker_dense(agt_ctx* c, const float* d_model_xyz, const float* d_model_t, int M, int iters, double photo_weight, int reseed)
+{
+    if (!c || M < 0 || iters < 0 || iters > 1000 || !(photo_weight >= 0.0)) return AGT_ERR_ARG;
+    if (M > 0 && (!d_model_xyz || !d_model_t || iters == 0)) return AGT_ERR_ARG;
+    int rc = agt_tracker_join(c);
+    if (rc) return rc;
+    c->dn_xyz = M ? d_model_xyz : nullptr; c->dn_t = M ? d_model_t : nullptr; c->dn_M = M;
+    c->dn_iters = iters; c->dn_weight = photo_weight; c->dn_reseed = reseed ? 1 : 0;
+    return AGT_OK;
+}
+
+int agt_track_frame_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                          double* d_state_out, double* d_dense_out)
+{
+    if (!c || !d_frames || !d_dense_out) return AGT_ERR_ARG;
+    if (c->trk_ready != 2 || c->dn_M <= 0) return AGT_ERR_STATE;
+    if (B <= 0 || B != c->trk_B) return AGT_ERR_ARG;
+    if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
+    hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
+    return step_serial(c, d_frames, pitch, batch_stride, B, d_state_out, d_dense_out, pev);
 }
 
 int agt_profile_begin(agt_ctx* c, int max_frames)
@@ -951,6 +1001,9 @@ int agt_profile_begin(agt_ctx* c, int max_frames)
             return hip_fail(c, e);
         }
     }
+    c->prof_dense = new (std::nothrow) int[max_frames];
+    if (!c->prof_dense) { for (size_t j = 0; j < n; j++) (void)hipEventDestroy(c->prof_ev[j]); delete[] c->prof_ev; c->prof_ev = nullptr; return AGT_ERR_ALLOC; }
+    for (int i = 0; i < max_frames; i++) c->prof_dense[i] = 0;
     c->prof_cap = max_frames; c->prof_n = 0;
     return AGT_OK;
 }
@@ -961,15 +1014,27 @@ int agt_profile_end(agt_ctx* c, float* ms_out, int* n_frames)
     hipError_t e = hipStreamSynchronize(c->stream);
     int rc = e == hipSuccess ? AGT_OK : hip_fail(c, e);
     if (rc == AGT_OK && ms_out)
-        for (int f = 0; f < c->prof_n && rc == AGT_OK; f++)
-            for (int k = 0; k < AGT_PROF_SPANS; k++) {
-                hipEvent_t* ev = c->prof_ev + (size_t)f * AGT_PROF_EVENTS;
+        for (int f = 0; f < c->prof_n && rc == AGT_OK; f++) {
+            hipEvent_t* ev = c->prof_ev + (size_t)f * AGT_PROF_EVENTS;
+            for (int k = 0; k < 3; k++) {
                 e = hipEventElapsedTime(&ms_out[f * AGT_PROF_SPANS + k], ev[k], ev[k + 1]);
                 if (e != hipSuccess) { rc = hip_fail(c, e); break; }
             }
+            // dense stage: ev[3] = its start, ev[4 + 2 i] after accumulate launch i, ev[5 + 2 i] after update launch i
+            float acc = 0.f, upd = 0.f;
+            for (int i = 0; i < c->prof_dense[f] && rc == AGT_OK; i++) {
+                float a = 0.f, u = 0.f;
+                e = hipEventElapsedTime(&a, ev[3 + 2 * i], ev[4 + 2 * i]);
+                if (e == hipSuccess) e = hipEventElapsedTime(&u, ev[4 + 2 * i], ev[5 + 2 * i]);
+                if (e != hipSuccess) { rc = hip_fail(c, e); break; }
+                acc += a; upd += u;
+            }
+            ms_out[f * AGT_PROF_SPANS + 3] = acc; ms_out[f * AGT_PROF_SPANS + 4] = upd;
+        }
     if (n_frames) *n_frames = c->prof_n;
     for (size_t i = 0; i < (size_t)c->prof_cap * AGT_PROF_EVENTS; i++) (void)hipEventDestroy(c->prof_ev[i]);
     delete[] c->prof_ev; c->prof_ev = nullptr; c->prof_cap = c->prof_n = 0;
+    delete[] c->prof_dense; c->prof_dense = nullptr;
     return rc;
 }
 

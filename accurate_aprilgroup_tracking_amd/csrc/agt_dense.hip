@@ -34,7 +34,9 @@ struct DenseParams {
     double* pose;                      // [B][6]
     double* partials;                  // [B][nblk][DROW]
     int nblk;
-    double* stats;                     // [B][8]
+    double* stats;                     // [B][stats_stride]: 5 values written per iteration
+    int stats_stride;
+    double* rec;                       // tracker stage: per-frame record [B][AGT_DENSE_STRIDE] (pose, refined flag, stats) or null
     int* done;                         // [B]
     double photo_weight, mu;
     int iter;
@@ -199,36 +201,79 @@ __global__ __launch_bounds__(256) void dense_update_kernel(const DenseParams P)
 #pragma unroll
     for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
     if (lane == 0) {
-        double* st = P.stats + (long)b * 8;
+        double* st = P.stats + (long)b * P.stats_stride;
         st[0] = pht[28] > 0.0 ? sqrt(pht[27] / pht[28]) : 0.0;
         st[1] = n_used > 0 ? sqrt(acc[27] / (2.0 * n_used)) : 0.0;
-        st[2] = pht[28]; st[3] = (double)(P.iter + 1); st[4] = (double)n_used; st[5] = st[6] = st[7] = 0.0;
+        st[2] = pht[28]; st[3] = (double)(P.iter + 1); st[4] = (double)n_used;
+        if (!P.rec) st[5] = st[6] = st[7] = 0.0;
         if (ok) {
 #pragma unroll
             for (int q = 0; q < 6; q++) P.pose[(long)b * 6 + q] = param[q] - dx[q];
+            if (P.rec) {
+                double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
+#pragma unroll
+                for (int q = 0; q < 6; q++) rc[q] = param[q] - dx[q];
+                rc[AGT_DN_REFINED] = 1.0;
+            }
         }
         if (!ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON) P.done[b] = 1;
     }
 }
 
+// tracker stage, after the last iteration: streams whose pose was refined get their corner set re-seeded with
+// projectPoints(all object points; refined pose) and every corner trackable again (stops the drift of raw LK chaining)
+__global__ __launch_bounds__(64) void dense_reseed_kernel(const double* __restrict__ rec, const float* __restrict__ obj, int n,
+                                                          const AgtCameraHost camh, float* __restrict__ corners, uint8_t* __restrict__ status)
+{
+    const int b = blockIdx.x, lane = threadIdx.x;
+    const double* rc = rec + (long)b * AGT_DENSE_STRIDE;
+    if (rc[AGT_DN_REFINED] == 0.0) return;
+    AgtCamera cam;
+    agt_pnp::load_cam<float>(camh, cam);
+    double param[6], R[9], G[9];
+#pragma unroll
+    for (int k = 0; k < 6; k++) param[k] = rc[k];
+    agt_rodrigues<false>(param, R, G);
+    for (int i = lane; i < n; i += AGT_WAVE) {
+        double u, v;
+        agt_project<false>(cam, R, G, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2], u, v, nullptr, nullptr);
+        corners[((long)b * n + i) * 2] = (float)u; corners[((long)b * n + i) * 2 + 1] = (float)v;
+        status[(long)b * n + i] = 1;
+    }
+}
+
 }  // namespace
 
+hipError_t agt_launch_dense_reseed(hipStream_t stream, const double* rec, const float* obj, int n, const AgtCameraHost& cam,
+                                   float* corners, uint8_t* status, int B)
+{
+    hipLaunchKernelGGL(dense_reseed_kernel, dim3(B), dim3(64), 0, stream, rec, obj, n, cam, corners, status);
+    return hipGetLastError();
+}
+
+// rec == null: plain agt_dense_refine (done words cleared here, stats [B][8]).  rec != null: stage of the tracker -- the
+// done words and the start poses were written by the PnP epilogue of the same frame (done = pose not accepted), the
+// statistics go into the record.
 hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,
                             const float* mxyz, const float* mt, int M,
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
-                            int B, int iters, double photo_weight, double mu)
+                            int B, int iters, double photo_weight, double mu, double* rec, hipEvent_t* ev, int n_ev)
 {
     DenseParams P;
+    P.rec = rec; P.stats_stride = rec ? AGT_DENSE_STRIDE : 8;
+    if (rec) stats = rec + AGT_DN_PHOTO_RMS;
     P.img = img; P.pitch = pitch; P.ibatch = ibatch; P.w = w; P.h = h;
     P.mxyz = mxyz; P.mt = mt; P.M = M; P.obj = obj; P.ipts = ipts; P.mask = mask; P.N = N;
     P.cam = cam; P.pose = pose; P.partials = partials; P.nblk = (M + 255) / 256; P.stats = stats; P.done = done;
     P.photo_weight = photo_weight; P.mu = mu;
-    hipError_t e = hipMemsetAsync(done, 0, (size_t)B * sizeof(int), stream);
+    hipError_t e = rec ? hipSuccess : hipMemsetAsync(done, 0, (size_t)B * sizeof(int), stream);
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
         if (P.nblk > 0) hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk, B), dim3(256), sizeof(DenseShared), stream, P);
+        if (ev && 2 * it < n_ev) (void)hipEventRecord(ev[2 * it], stream);                // profiling only
         hipLaunchKernelGGL(dense_update_kernel, dim3(B), dim3(256), 0, stream, P);
+        if (ev && 2 * it + 1 < n_ev) (void)hipEventRecord(ev[2 * it + 1], stream);
         e = hipGetLastError();
     }
     return e;

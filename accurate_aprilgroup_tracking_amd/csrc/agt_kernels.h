@@ -60,6 +60,10 @@ struct AgtPnpParams {
     double* state_out;             // [B][AGT_STATE_STRIDE] or null
     float* corners_rw;             // [B][n][2] corner set to refresh by reprojection, or null
     uint8_t* status_rw;            // [B][n] LK status revived together with corners_rw, or null
+    // dense stage hand-over (agt_track_frame_dense): start pose, done word (1 = pose not accepted: skip) and the frame's record
+    double* dense_pose;            // [B][6] or null
+    int* dense_done;               // [B]
+    double* dense_rec;             // [B][AGT_DENSE_STRIDE]
     int enhance_ape;
     int reproject;
     int min_points;                // corners needed to attempt a pose (8 = two tags)
@@ -142,7 +146,9 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
                             const float* mxyz, const float* mt, int M,
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
-                            int B, int iters, double photo_weight, double mu);
+                            int B, int iters, double photo_weight, double mu, double* rec, hipEvent_t* ev = nullptr, int n_ev = 0);
+hipError_t agt_launch_dense_reseed(hipStream_t stream, const double* rec, const float* obj, int n, const AgtCameraHost& cam,
+                                   float* corners, uint8_t* status, int B);
 int agt_dense_blocks(int M);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);

@@ -386,6 +386,10 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
             if (lane == 0) {
                 ts->has_guess = 0; ts->frame++;
+                if (P.dense_pose) {
+                    for (int i = 0; i < AGT_DENSE_STRIDE; i++) P.dense_rec[(long)b * AGT_DENSE_STRIDE + i] = 0.0;
+                    P.dense_done[b] = 1;
+                }
                 if (so_p) {
                     double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
@@ -544,6 +548,10 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             if (lane == 0 && P.err) P.err[b] = 0.0;
             if (lane == 0 && ts) {
                 ts->has_guess = 0; ts->frame++;
+                if (P.dense_pose) {
+                    for (int i = 0; i < AGT_DENSE_STRIDE; i++) P.dense_rec[(long)b * AGT_DENSE_STRIDE + i] = 0.0;
+                    P.dense_done[b] = 1;
+                }
                 if (so_p) {
                     double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
@@ -800,6 +808,12 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             }
             ts->frame++;
             PSTAMP(5);
+            if (P.dense_pose) {                   // hand-over to the dense stage of the same frame
+                double* rc = P.dense_rec + (long)b * AGT_DENSE_STRIDE;
+                for (int i = 0; i < 6; i++) { P.dense_pose[(long)b * 6 + i] = param[i]; rc[i] = param[i]; }
+                for (int i = 6; i < AGT_DENSE_STRIDE; i++) rc[i] = 0.0;
+                P.dense_done[b] = accepted ? 0 : 1;
+            }
             if (so_p) {
                 double* so = so_p + (long)b * AGT_STATE_STRIDE;
                 for (int i = 0; i < 6; i++) so[i] = param[i];

@@ -22,7 +22,9 @@ PNP_SINGULAR, PNP_PLANAR, PNP_TOO_FEW = 1, 2, 4
 STATE_STRIDE = 16
 ST_RVEC, ST_TVEC, ST_OK, ST_ERR, ST_NTRACK, ST_ITERS, ST_GUESS, ST_FLAGS, ST_TVEC_F32 = 0, 3, 6, 7, 8, 9, 10, 11, 12
 TRK_ZERO_VELOCITY = 256
-PROF_SPANS = 3
+PROF_SPANS = 5
+DENSE_STRIDE = 16
+DN_RVEC, DN_TVEC, DN_REFINED, DN_PHOTO_RMS, DN_GEO_RMS, DN_VALID, DN_ITERS, DN_CORNERS = 0, 3, 6, 7, 8, 9, 10, 11
 
 # every symbol include/agt_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
@@ -33,7 +35,7 @@ SYMBOLS = [
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
-    "agt_preprocess_bgr", "agt_dense_refine",
+    "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense",
 ]
 
 
@@ -100,6 +102,8 @@ def lib():
     L.agt_undistort_bgr.argtypes = [vp, vp, sz, sz, vp, sz, sz, i32]
     L.agt_preprocess_bgr.argtypes = [vp, vp, sz, sz, i32, i32, i32, i32, i32, i32, i32, i32, vp, sz, sz]
     L.agt_dense_refine.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f64, vp]
+    L.agt_tracker_dense.argtypes = [vp, vp, vp, i32, i32, f64, i32]
+    L.agt_track_frame_dense.argtypes = [vp, vp, sz, sz, i32, vp, vp]
     L.agt_profile_begin.argtypes = [vp, i32]
     L.agt_profile_end.argtypes = [vp, vp, C.POINTER(i32)]
     _lib = L

@@ -78,6 +78,33 @@ class StreamTracker:
             del self._alive[0]
         return state_out
 
+    def dense_model(self, model_xyz, model_t, iters=5, photo_weight=0.05, reseed=True):
+        """BASELINE configs[4]: register the dense model (cuda f32 [M,3] object-frame samples, cuda f32 [M] template
+        intensities; kept alive here) -- step_dense() then refines every accepted pose photometrically on the device.
+        model_xyz None disables the stage."""
+        if model_xyz is None:
+            H.check(self.ctx.L.agt_tracker_dense(self.ctx.h, None, None, 0, 0, 0.0, 0), "agt_tracker_dense")
+            self._dense = None
+            return
+        assert model_xyz.dtype == torch.float32 and model_xyz.is_cuda and model_xyz.is_contiguous() and model_xyz.shape[1] == 3
+        assert model_t.dtype == torch.float32 and model_t.is_cuda and model_t.is_contiguous() and model_t.shape[0] == model_xyz.shape[0]
+        H.check(self.ctx.L.agt_tracker_dense(self.ctx.h, _ptr(model_xyz), _ptr(model_t), model_xyz.shape[0], int(iters),
+                                             float(photo_weight), int(bool(reseed))), "agt_tracker_dense")
+        self._dense = (model_xyz, model_t)
+
+    def step_dense(self, frames, state_out=None, dense_out=None):
+        """One frame with the dense stage: pyramid -> LK -> solvePnP(guess) + gate + motion model -> dense refinement of the
+        accepted pose (-> corner re-seed).  dense_out: cuda f64 [B, DENSE_STRIDE] (created when None).  Enqueues only."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
+        if dense_out is None:
+            dense_out = torch.zeros((self.B, H.DENSE_STRIDE), dtype=torch.float64, device=self.dev)
+        H.check(self.ctx.L.agt_track_frame_dense(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
+                                                 _ptr(state_out), _ptr(dense_out)), "agt_track_frame_dense")
+        self._alive.append(frames)
+        if len(self._alive) > self._keep_frames:
+            del self._alive[0]
+        return dense_out
+
     def join(self):
         """Enqueue the remaining pipeline stages of every supplied frame (no host synchronisation)."""
         H.check(self.ctx.L.agt_tracker_join(self.ctx.h), "agt_tracker_join")

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 100
+#define AGT_VERSION 200
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -224,6 +224,29 @@ int agt_dense_refine(agt_ctx* ctx, const uint8_t* d_img, size_t pitch, size_t ba
                      const double* K, const double* dist, int ndist,
                      double* d_pose, int B, int iters, double photo_weight, double* d_stats);
 
+/* ---- dense refinement as a stage of the per-frame step (BASELINE configs[4]: 60 tags / 240 corners + dense photometric
+ * residuals) ----
+ * agt_tracker_dense registers the dense model with the tracker (the two arrays are RETAINED by pointer until the stage is
+ * disabled with M = 0 or the context is destroyed).  agt_track_frame_dense then runs, per frame and without any host round
+ * trip: pyramid -> LK -> solvePnP(guess) + gate + motion model (exactly agt_track_frame, stage kernels in stream order) ->
+ * `iters` damped Gauss-Newton iterations of agt_dense_refine started from the frame's ACCEPTED PnP pose, over the frame, the
+ * model samples and the LK corners (mask = LK status) -> with reseed != 0, the corner set of the frame is replaced by
+ * projectPoints(object points; refined pose) and every corner made trackable again, so LK of the next frame starts from the
+ * refined geometry (raw LK chaining drifts).  The tracker's state machine (guess, prev_transform, velocities) is the
+ * reference's and is NOT altered by the refinement.  d_dense_out: [B][AGT_DENSE_STRIDE] f64 per frame. */
+#define AGT_DENSE_STRIDE 16
+#define AGT_DN_RVEC      0    /* 0..2 refined rvec (the PnP pose when AGT_DN_REFINED is 0) */
+#define AGT_DN_TVEC      3    /* 3..5 */
+#define AGT_DN_REFINED   6    /* 1.0 = the PnP pose was accepted and at least one GN step was applied */
+#define AGT_DN_PHOTO_RMS 7    /* photometric RMS at the last linearisation point */
+#define AGT_DN_GEO_RMS   8    /* geometric RMS there (px) */
+#define AGT_DN_VALID     9    /* valid model samples there */
+#define AGT_DN_ITERS     10   /* GN iterations executed */
+#define AGT_DN_CORNERS   11   /* corners used */
+int agt_tracker_dense(agt_ctx* ctx, const float* d_model_xyz, const float* d_model_t, int M, int iters, double photo_weight, int reseed);
+int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                          double* d_state_out, double* d_dense_out);
+
 /* ---- per-kernel timing of agt_track_frame with HIP events on the context's stream ---- */
 /* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its
  * four launches (pyrDown L0->L1, pyrDown L1->L2.., LK, PnP) into the next of max_frames
@@ -231,8 +254,10 @@ int agt_dense_refine(agt_ctx* ctx, const uint8_t* d_img, size_t pitch, size_t ba
  * frames recorded, and releases the events.  With the fused software-pipelined step the frame is
  * ONE launch: spans 0 and 1 are ~0 and span 2 is the step_kernel launch.  Recording perturbs
  * timing: never leave it on in a throughput measurement. */
-#define AGT_PROF_EVENTS 4
-#define AGT_PROF_SPANS  3          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine */
+#define AGT_PROF_DENSE_MAX 16      /* dense GN iterations timed individually per frame (agt_track_frame_dense) */
+#define AGT_PROF_EVENTS (4 + 2 * AGT_PROF_DENSE_MAX)
+#define AGT_PROF_SPANS  5          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine,
+                                      3: sum of the dense accumulate launches of the frame, 4: sum of its dense update launches (0 without the stage) */
 int agt_profile_begin(agt_ctx* ctx, int max_frames);
 int agt_profile_end(agt_ctx* ctx, float* ms_out, int* n_frames);
 

@@ -181,3 +181,85 @@ def test_scratch_survives_undistort_init_and_batch_growth(oracle, scene):
     r, t, _ = oracle.dense_refine(s.frame(1), mx[:256], T[:256], None, None, None, s.K, None, start[:3], start[3:], iters=4, photo_weight=1.0)
     assert np.abs(small[:, :3] - r).max() < 1e-9 and np.abs(small[:, 3:] - t).max() < 1e-9
     check(run(1))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("reseed", [False, True])
+def test_c5_stream_matches_oracle_chain(oracle, reseed, tmp_path):
+    """BASELINE configs[4] as a STREAM: 1280x720, 60 tags / 240 corners, 61,440 dense samples.  Every frame runs
+    LK(240) -> solvePnP(240, guess) + gate + motion model -> dense refinement of the accepted pose (-> corner re-seed)
+    on the device with no host round trip (StreamTracker.step_dense); the CPU chain is the oracle LK (sticky status), the
+    reference-validated PoseDetector mirror on the oracle backend and oracle.dense_refine, frame by frame."""
+    import json, logging
+    import torch
+    from oracle import cv2_shim
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = syn.Sequence(1280, 720, n_tags=60, n_frames=6, seed=8, supersample=2)
+    n = s.obj.shape[0]
+    assert n == 240 and s.coverage(0).max() <= 1.0 + 1e-6           # no two tags overlap in the image
+    mx = syn.model_samples(s.group, 32)
+    T = _template(s, mx, 0)                                         # template captured at the initial (known) pose
+    iters, pw = 4, 0.05
+    tol = 1e-6 if reseed else 1e-8        # re-seeded corners are rounded to float32: an ulp flip costs ~1e-7 downstream
+    F = len(s)
+    frames = torch.from_numpy(s.frames()).cuda()
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+    mxg, Tg = torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda()
+    trk.dense_model(mxg, Tg, iters=iters, photo_weight=pw, reseed=reseed)
+    trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+    so = trk.new_state_buffer(F - 1)
+    do = torch.zeros((F - 1, 1, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
+    for k in range(1, F):
+        trk.step_dense(frames[k:k + 1], so[k - 1], do[k - 1])        # never synchronised in between
+    torch.cuda.synchronize()
+    st, dn = so.cpu().numpy()[:, 0], do.cpu().numpy()[:, 0]
+
+    (tmp_path / "april_group.json").write_text(json.dumps(s.group))
+
+    class Det(PoseDetector):
+        DIRPATH = str(tmp_path)
+    log = logging.getLogger("c5"); log.setLevel(logging.CRITICAL)
+    det = Det(log, s.K, None, True, cv=cv2_shim.make_cv2())
+    obj32 = s.obj.astype(np.float32)
+    pts = s.corners(0); alive = np.ones(n, bool); pyr = oracle.Pyramid(s.frame(0))
+    for k in range(1, F):
+        npyr = oracle.Pyramid(s.frame(k))
+        nx, status, _ = oracle.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
+        nx = nx.reshape(-1, 2); status = status.ravel().astype(bool)
+        nx[~alive] = pts[~alive]; alive &= status
+        il = [nx[i].reshape(1, 1, 2) for i in range(n) if alive[i]]
+        ol = [obj32[i].reshape(1, 3) for i in range(n) if alive[i]]
+        det._estimate_pose(il if len(il) >= 8 else [], ol if len(il) >= 8 else [])
+        accepted = det.last_error is not None and det.last_error < 2
+        assert int(st[k - 1, H.ST_NTRACK]) == int(alive.sum()) and int(st[k - 1, H.ST_OK]) == int(accepted)
+        assert accepted and alive.sum() == n, "the 60-tag scene keeps all 240 corners trackable"
+        r0 = det.last_pose[0].ravel().astype(np.float64); t0 = det.last_pose[1].ravel().astype(np.float64)
+        assert np.abs(st[k - 1, :3] - r0).max() < tol and np.abs(st[k - 1, 3:6] - t0).max() < tol, "frame %d PnP pose" % k
+        r, t, info = oracle.dense_refine(s.frame(k), mx, T, s.obj, nx.astype(np.float32), alive.astype(np.uint8), s.K, None, r0, t0,
+                                         iters=iters, photo_weight=pw)
+        assert dn[k - 1, H.DN_REFINED] == 1.0
+        assert np.abs(dn[k - 1, :3] - r).max() < tol and np.abs(dn[k - 1, 3:6] - t).max() < tol, "frame %d refined pose" % k
+        assert int(dn[k - 1, H.DN_VALID]) == info["valid"] and int(dn[k - 1, H.DN_ITERS]) == info["iters"] and int(dn[k - 1, H.DN_CORNERS]) == info["used"]
+        assert abs(dn[k - 1, H.DN_PHOTO_RMS] - info["photo_rms"]) < 1e-5 and abs(dn[k - 1, H.DN_GEO_RMS] - info["geo_rms"]) < 1e-5
+        # the refinement must not be worse than the PnP pose against the generator's truth
+        e_pnp = max(np.abs(r0 - s.rvecs[k]).max(), np.abs(t0 - s.tvecs[k]).max())
+        e_ref = max(np.abs(r - s.rvecs[k]).max(), np.abs(t - s.tvecs[k]).max())
+        assert e_ref < 2e-3 and e_ref < e_pnp + 2e-4
+        if reseed:
+            pp, _ = oracle.projectPoints(s.obj, r, t, s.K, None)
+            pts = pp.reshape(-1, 2).astype(np.float32); alive[:] = True
+        else:
+            pts = nx.astype(np.float32)
+        pyr = npyr
+
+
+def test_synthetic_60_tag_layout():
+    """the 60-tag model of configs[4]: every tag inside a 1280x720 frame along the trajectory, none overlapping another"""
+    s = syn.Sequence(1280, 720, n_tags=60, n_frames=120, seed=8, supersample=1)
+    assert s.obj.shape == (240, 3)
+    for k in (0, 40, 80, 119):
+        c = s.corners(k)
+        assert c[:, 0].min() > 12 and c[:, 0].max() < 1280 - 12 and c[:, 1].min() > 12 and c[:, 1].max() < 720 - 12
+        assert s.coverage(k).max() <= 1.0 + 1e-6

@@ -4,7 +4,7 @@ import os, sys, time
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from accurate_aprilgroup_tracking_amd import cv_hip, synthetic as syn
-s = syn.Sequence(1280, 720, n_tags=60, n_frames=2, seed=8, supersample=2, z0=0.62)
+s = syn.Sequence(1280, 720, n_tags=60, n_frames=2, seed=8, supersample=2)
 mx = syn.model_samples(s.group, 32)
 T = np.nan_to_num(syn.sample_bilinear(s.frame(1), syn.project(mx, s.rvecs[1], s.tvecs[1], s.K)), nan=128.0).astype(np.float32)
 ctx = cv_hip.Context(64, 64, max_level=0)
