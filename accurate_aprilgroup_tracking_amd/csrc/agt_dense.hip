@@ -5,13 +5,15 @@
 // damped Gauss-Newton (mu = 1e-3 on the diagonal, no step rejection), FP64 throughout.
 //
 // Mapping (the "large-N Jacobian reduce" of config 5: 61,440 samples, 29 sums each):
-//   dense_accum_kernel  grid (ceil(M / 256), B): a thread owns one sample -- projection + 2x6
+//   dense_accum_kernel  grid (ceil(M / 256) + 1, B): a thread owns one sample -- projection + 2x6
 //       Jacobian in FP64, four bilinear taps + the eight central-difference taps of the gradient
 //       straight from the frame (u8, L2/HBM), 21 + 6 + 1 + 1 partial sums.  Each wave reduces
 //       through a transposed LDS slab (as the PnP kernel), the four waves through LDS again, and
-//       the block writes ONE row of 32 doubles: no atomics, bit-reproducible.
+//       the block writes ONE row of 32 doubles: no atomics, bit-reproducible.  The last block of a stream
+//       evaluates the corner (geometric) rows instead, one corner per thread, into a row of the same layout
+//       (round 1 did them serially inside the update kernel: 16 us per iteration at 240 corners, now 4).
 //   dense_update_kernel one block per stream: sums the block rows (8 interleaved groups, fixed order), adds the corner
-//       (geometric) rows evaluated in place, solves the damped 6x6 system, updates the pose and
+//       row, solves the damped 6x6 system, updates the pose and
 //       raises a `done` word when the relative step falls under FLT_EPSILON (later launches of
 //       the same call then fall through).
 // One Gauss-Newton iteration = two launches; a call enqueues 2 * iters launches and never
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     const int b = blockIdx.y;
     if (P.done[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int i = blockIdx.x * 256 + tid;
+    const bool geo = (int)blockIdx.x == P.nblk;        // the last block of a stream evaluates the corner (geometric) rows
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
     bool has_dist = false;
@@ -69,37 +71,62 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     double acc[DN];
 #pragma unroll
     for (int k = 0; k < DN; k++) acc[k] = 0.0;
-    if (i < P.M) {
-        const double X = (double)P.mxyz[(long)i * 3], Y = (double)P.mxyz[(long)i * 3 + 1], Z = (double)P.mxyz[(long)i * 3 + 2];
-        double u, v, jr[6], jt[6];
-        if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-        else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-        const double fx0 = floor(u), fy0 = floor(v);
-        if (fx0 >= 1.0 && fx0 <= (double)(P.w - 3) && fy0 >= 1.0 && fy0 <= (double)(P.h - 3)) {
-            const int x0 = (int)fx0, y0 = (int)fy0;
-            const double a = u - fx0, bb = v - fy0;
-            const uint8_t* p = P.img + (long)b * P.ibatch + (long)y0 * P.pitch + x0;
-            const long s = P.pitch;
-            // the 4 x 4 neighbourhood minus its corners
-            const double pm0 = p[-1], p00 = p[0], p10 = p[1], p20 = p[2];
-            const double pm1 = p[s - 1], p01 = p[s], p11 = p[s + 1], p21 = p[s + 2];
-            const double p0m = p[-s], p1m = p[-s + 1], p02 = p[2 * s], p12 = p[2 * s + 1];
-            const double w00 = (1 - a) * (1 - bb), w01 = a * (1 - bb), w10 = (1 - a) * bb, w11 = a * bb;
-            const double I = w00 * p00 + w01 * p10 + w10 * p01 + w11 * p11;
-            const double gx = w00 * (p10 - pm0) * 0.5 + w01 * (p20 - p00) * 0.5 + w10 * (p11 - pm1) * 0.5 + w11 * (p21 - p01) * 0.5;
-            const double gy = w00 * (p01 - p0m) * 0.5 + w01 * (p11 - p1m) * 0.5 + w10 * (p02 - p00) * 0.5 + w11 * (p12 - p10) * 0.5;
-            const double r = I - (double)P.mt[i];
-            const double J[6] = { gx * jr[0] + gy * jr[3], gx * jr[1] + gy * jr[4], gx * jr[2] + gy * jr[5],
-                                  gx * jt[0] + gy * jt[3], gx * jt[1] + gy * jt[4], gx * jt[2] + gy * jt[5] };
+    if (!geo) {
+        const int i = blockIdx.x * 256 + tid;
+        if (i < P.M) {
+            const double X = (double)P.mxyz[(long)i * 3], Y = (double)P.mxyz[(long)i * 3 + 1], Z = (double)P.mxyz[(long)i * 3 + 2];
+            double u, v, jr[6], jt[6];
+            if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            const double fx0 = floor(u), fy0 = floor(v);
+            if (fx0 >= 1.0 && fx0 <= (double)(P.w - 3) && fy0 >= 1.0 && fy0 <= (double)(P.h - 3)) {
+                const int x0 = (int)fx0, y0 = (int)fy0;
+                const double a = u - fx0, bb = v - fy0;
+                const uint8_t* p = P.img + (long)b * P.ibatch + (long)y0 * P.pitch + x0;
+                const long s = P.pitch;
+                // the 4 x 4 neighbourhood minus its corners
+                const double pm0 = p[-1], p00 = p[0], p10 = p[1], p20 = p[2];
+                const double pm1 = p[s - 1], p01 = p[s], p11 = p[s + 1], p21 = p[s + 2];
+                const double p0m = p[-s], p1m = p[-s + 1], p02 = p[2 * s], p12 = p[2 * s + 1];
+                const double w00 = (1 - a) * (1 - bb), w01 = a * (1 - bb), w10 = (1 - a) * bb, w11 = a * bb;
+                const double I = w00 * p00 + w01 * p10 + w10 * p01 + w11 * p11;
+                const double gx = w00 * (p10 - pm0) * 0.5 + w01 * (p20 - p00) * 0.5 + w10 * (p11 - pm1) * 0.5 + w11 * (p21 - p01) * 0.5;
+                const double gy = w00 * (p01 - p0m) * 0.5 + w01 * (p11 - p1m) * 0.5 + w10 * (p02 - p00) * 0.5 + w11 * (p12 - p10) * 0.5;
+                const double r = I - (double)P.mt[i];
+                const double J[6] = { gx * jr[0] + gy * jr[3], gx * jr[1] + gy * jr[4], gx * jr[2] + gy * jr[5],
+                                      gx * jt[0] + gy * jt[3], gx * jt[1] + gy * jt[4], gx * jt[2] + gy * jt[5] };
+                int idx = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) {
+#pragma unroll
+                    for (int c = q; c < 6; c++) acc[idx++] = P.photo_weight * J[q] * J[c];
+                    acc[21 + q] = P.photo_weight * J[q] * r;
+                }
+                acc[27] = r * r;
+                acc[28] = 1.0;
+            }
+        }
+    } else {
+        // geometric rows, one corner per thread per trip (N <= 256: one trip); same row layout, unweighted,
+        // [27] = sum of squared residuals, [28] = corners used
+        for (int i = tid; i < P.N; i += 256) {
+            if (P.mask && !P.mask[(long)b * P.N + i]) continue;
+            double u, v, jr[6], jt[6];
+            const double X = (double)P.obj[i * 3], Y = (double)P.obj[i * 3 + 1], Z = (double)P.obj[i * 3 + 2];
+            if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            const double ex = u - (double)P.ipts[((long)b * P.N + i) * 2], ey = v - (double)P.ipts[((long)b * P.N + i) * 2 + 1];
+            const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
+            const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };
             int idx = 0;
 #pragma unroll
             for (int q = 0; q < 6; q++) {
 #pragma unroll
-                for (int c = q; c < 6; c++) acc[idx++] = P.photo_weight * J[q] * J[c];
-                acc[21 + q] = P.photo_weight * J[q] * r;
+                for (int c = q; c < 6; c++) acc[idx++] += Jx[q] * Jx[c] + Jy[q] * Jy[c];
+                acc[21 + q] += Jx[q] * ex + Jy[q] * ey;
             }
-            acc[27] = r * r;
-            acc[28] = 1.0;
+            acc[27] += ex * ex + ey * ey;
+            acc[28] += 1.0;
         }
     }
     // wave: transposed slab (two lanes per sum, 32 adds each); block: four wave rows
@@ -119,92 +146,54 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     __syncthreads();
     if (tid < DROW) {
         const double t = tid < DN ? ((sh.wtot[0][tid] + sh.wtot[1][tid]) + (sh.wtot[2][tid] + sh.wtot[3][tid])) : 0.0;
-        P.partials[((long)b * P.nblk + blockIdx.x) * DROW + tid] = t;
+        P.partials[((long)b * (P.nblk + 1) + blockIdx.x) * DROW + tid] = t;
     }
 }
 
+// one block per stream: sums the photometric block rows (8 interleaved groups, fixed order), adds the geometric row, solves
+// the damped 6x6 system, updates the pose (every lane of wave 0 redundantly; lane 0 stores)
 __global__ __launch_bounds__(256) void dense_update_kernel(const DenseParams P)
 {
-    __shared__ agt_pnp::PnpShared sh;
     __shared__ double s_rows[8][DROW];
+    __shared__ double s_tot[2][DROW];
     const int b = blockIdx.x, lane = threadIdx.x & 63;
     if (P.done[b]) return;
-    // photometric block rows: 8 interleaved groups of rows are summed concurrently (independent loads in
-    // flight), then combined in a fixed order -> reproducible, and short even for hundreds of rows
+    const double* rows = P.partials + (long)b * (P.nblk + 1) * DROW;
     {
         const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-        const double* row = P.partials + (long)b * P.nblk * DROW + k;
         double s = 0.0;
-        for (int j = g; j < P.nblk; j += 8) s += row[(long)j * DROW];
+        for (int j = g; j < P.nblk; j += 8) s += rows[(long)j * DROW + k];
         s_rows[g][k] = s;
     }
     __syncthreads();
     if (threadIdx.x >= AGT_WAVE) return;
-    AgtCamera cam;
-    agt_pnp::load_cam<float>(P.cam, cam);
-    bool has_dist = false;
-#pragma unroll
-    for (int k = 0; k < 12; k++) has_dist |= cam.k[k] != 0.0;
+    if (lane < DROW) {
+        s_tot[0][lane] = ((s_rows[0][lane] + s_rows[1][lane]) + (s_rows[2][lane] + s_rows[3][lane])) +
+                         ((s_rows[4][lane] + s_rows[5][lane]) + (s_rows[6][lane] + s_rows[7][lane]));
+        s_tot[1][lane] = P.N > 0 ? rows[(long)P.nblk * DROW + lane] : 0.0;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     double param[6];
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
-
-    double ph = 0.0;
-    if (lane < DROW)
-        ph = ((s_rows[0][lane] + s_rows[1][lane]) + (s_rows[2][lane] + s_rows[3][lane])) +
-             ((s_rows[4][lane] + s_rows[5][lane]) + (s_rows[6][lane] + s_rows[7][lane]));
-    // geometric rows
-    double acc[agt_pnp::NACC];
-#pragma unroll
-    for (int k = 0; k < agt_pnp::NACC; k++) acc[k] = 0.0;
-    int used = 0;
-    if (P.N > 0) {
-        double R[9], G[9];
-        agt_rodrigues<true>(param, R, G);
-        for (int i = lane; i < P.N; i += AGT_WAVE) {
-            if (P.mask && !P.mask[(long)b * P.N + i]) continue;
-            used++;
-            double u, v, jr[6], jt[6];
-            const double X = (double)P.obj[i * 3], Y = (double)P.obj[i * 3 + 1], Z = (double)P.obj[i * 3 + 2];
-            if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-            else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-            const double ex = u - (double)P.ipts[((long)b * P.N + i) * 2], ey = v - (double)P.ipts[((long)b * P.N + i) * 2 + 1];
-            const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
-            const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };
-            int idx = 0;
-#pragma unroll
-            for (int q = 0; q < 6; q++) {
-#pragma unroll
-                for (int c = q; c < 6; c++) acc[idx++] += Jx[q] * Jx[c] + Jy[q] * Jy[c];
-                acc[21 + q] += Jx[q] * ex + Jy[q] * ey;
-            }
-            acc[27] += ex * ex + ey * ey;
-        }
-    }
-    agt_pnp::wave_reduce_slab<agt_pnp::NACC>(acc, sh, lane);
-    const int n_used = (int)agt_wave_sum_i64(used);
-    // combine: every lane gets all 29 photometric totals
-    double pht[DN];
-#pragma unroll
-    for (int k = 0; k < DN; k++) pht[k] = agt_pnp::lane_bcast(ph, k);
-
     double A[36], g[6], dx[6];
     int idx = 0;
 #pragma unroll
     for (int q = 0; q < 6; q++)
 #pragma unroll
-        for (int c = q; c < 6; c++) { const double v = acc[idx] + pht[idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
+        for (int c = q; c < 6; c++) { const double v = s_tot[1][idx] + s_tot[0][idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
 #pragma unroll
-    for (int q = 0; q < 6; q++) { g[q] = acc[21 + q] + pht[21 + q]; A[q * 7] *= 1.0 + P.mu; }
+    for (int q = 0; q < 6; q++) { g[q] = s_tot[1][21 + q] + s_tot[0][21 + q]; A[q * 7] *= 1.0 + P.mu; }
     const bool ok = agt_solve6(A, g, dx);
     double dn = 0.0, pn = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
     if (lane == 0) {
+        const double ph_r2 = s_tot[0][27], ph_n = s_tot[0][28], geo_r2 = s_tot[1][27], n_used = s_tot[1][28];
         double* st = P.stats + (long)b * P.stats_stride;
-        st[0] = pht[28] > 0.0 ? sqrt(pht[27] / pht[28]) : 0.0;
-        st[1] = n_used > 0 ? sqrt(acc[27] / (2.0 * n_used)) : 0.0;
-        st[2] = pht[28]; st[3] = (double)(P.iter + 1); st[4] = (double)n_used;
+        st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
+        st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
+        st[2] = ph_n; st[3] = (double)(P.iter + 1); st[4] = n_used;
         if (!P.rec) st[5] = st[6] = st[7] = 0.0;
         if (ok) {
 #pragma unroll
@@ -270,7 +259,7 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
     hipError_t e = rec ? hipSuccess : hipMemsetAsync(done, 0, (size_t)B * sizeof(int), stream);
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
-        if (P.nblk > 0) hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk, B), dim3(256), sizeof(DenseShared), stream, P);
+        hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk + (N > 0 ? 1 : 0), B), dim3(256), sizeof(DenseShared), stream, P);
         if (ev && 2 * it < n_ev) (void)hipEventRecord(ev[2 * it], stream);                // profiling only
         hipLaunchKernelGGL(dense_update_kernel, dim3(B), dim3(256), 0, stream, P);
         if (ev && 2 * it + 1 < n_ev) (void)hipEventRecord(ev[2 * it + 1], stream);
@@ -279,4 +268,5 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
     return e;
 }
 
-int agt_dense_blocks(int M) { return (M + 255) / 256; }
+// rows of block partials per stream: the photometric blocks and one geometric (corner) block
+int agt_dense_blocks(int M) { return (M + 255) / 256 + 1; }
