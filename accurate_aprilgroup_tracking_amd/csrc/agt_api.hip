@@ -77,8 +77,11 @@ int hip_fail(agt_ctx* c, hipError_t e)
 int fill_camera(const double* K, const double* dist, int ndist, AgtCameraHost* cam)
 {
     if (!K) return AGT_ERR_ARG;
-    if (!(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12)) return AGT_ERR_DIST;
+    if (!(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12 || ndist == 14)) return AGT_ERR_DIST;
     if (ndist > 0 && !dist) return AGT_ERR_ARG;
+    // 14 coefficients = the 12 + the tilted-sensor angles (tau_x, tau_y): accepted when the tilt is zero (what
+    // calibrateCamera returns unless CALIB_TILTED_MODEL is set); a tilted sensor model is not built
+    if (ndist == 14 && (dist[12] != 0.0 || dist[13] != 0.0)) return AGT_ERR_DIST;
     cam->fx = K[0]; cam->fy = K[4]; cam->cx = K[2]; cam->cy = K[5];
     for (int i = 0; i < 12; i++) cam->k[i] = i < ndist ? dist[i] : 0.0;
     return AGT_OK;

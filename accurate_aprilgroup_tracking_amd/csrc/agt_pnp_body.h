@@ -54,7 +54,7 @@ struct PnpShared {
 template <int K, bool READBACK = true>
 __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& sh, int lane)
 {
-    static_assert(K <= 32, "one pass handles at most 32 sums");
+    static_assert(K <= NACC, "the slab holds NACC rows");
     __syncthreads();
 #pragma unroll
     for (int k = 0; k < K; k++) sh.part[k * SLAB + lane] = vals[k];
@@ -211,6 +211,54 @@ __device__ void smallest_eigvec(double* A, int n, double* v, double* tmp)
         nn = 1.0 / sqrt(nn);
         for (int i = 0; i < n; i++) v[i] *= nn;
     }
+}
+
+// Cholesky solve of the symmetric positive definite n x n system A x = b (A row-major in LDS, overwritten by its factor);
+// inv_diag != null: the diagonal of A^-1 instead / as well.  Serial: call from ONE lane.  false = not positive definite.
+__device__ bool spd_solve(double* A, int n, const double* b, double* x, double* inv_diag)
+{
+    for (int j = 0; j < n; j++) {
+        double d = A[j * n + j];
+        for (int k = 0; k < j; k++) d -= A[j * n + k] * A[j * n + k];
+        if (!(d > 0.0)) return false;
+        d = sqrt(d);
+        A[j * n + j] = d;
+        const double id = 1.0 / d;
+        for (int i = j + 1; i < n; i++) {
+            double s = A[i * n + j];
+            for (int k = 0; k < j; k++) s -= A[i * n + k] * A[j * n + k];
+            A[i * n + j] = s * id;
+        }
+    }
+    if (x) {
+        for (int i = 0; i < n; i++) {
+            double s = b[i];
+            for (int k = 0; k < i; k++) s -= A[i * n + k] * x[k];
+            x[i] = s / A[i * n + i];
+        }
+        for (int i = n - 1; i >= 0; i--) {
+            double s = x[i];
+            for (int k = i + 1; k < n; k++) s -= A[k * n + i] * x[k];
+            x[i] = s / A[i * n + i];
+        }
+    }
+    if (inv_diag) {
+        // A^-1 = L^-T L^-1: column c of L^-1 by forward substitution of e_c; diag_i = sum_c (L^-1)_{c i}^2 over c >= i
+        for (int i = 0; i < n; i++) inv_diag[i] = 0.0;
+        for (int c = 0; c < n; c++) {
+            double col[12];
+            for (int i = 0; i < n; i++) {
+                double s = i == c ? 1.0 : 0.0;
+                for (int k = c; k < i; k++) s -= A[i * n + k] * col[k];
+                col[i] = i < c ? 0.0 : s / A[i * n + i];
+            }
+            // (L^-1)_{i c} = col[i]; (A^-1)_{cc} = sum_{i >= c} (L^-1)_{i c}^2
+            double dsum = 0.0;
+            for (int i = c; i < n; i++) dsum += col[i] * col[i];
+            inv_diag[c] = dsum;
+        }
+    }
+    return true;
 }
 
 // broadcast lane `src`'s double to the whole wave through SGPRs (no LDS)
@@ -432,8 +480,9 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         agt_svd3(MM, Wm, Um, Vm);
         if (Wm[2] / Wm[1] < 1e-3) {
             // ---- planar structure: cvFindExtrinsicCameraParams2's homography branch.
-            // findHomography(method 0) = normalised DLT; OpenCV's LM polish of H is omitted, the pose LM
-            // below minimises the same error (same choice as oracle/cv_pnp.c homography_dlt).
+            // cv::findHomography(method 0): both point sets converted to float32, normalised DLT, then -- for more than
+            // four points -- the LMSolver polish (levmarq.cpp LMSolverImpl::run, <= 10 iterations); oracle/cv_pnp.c
+            // cvo_find_homography is the CPU restatement.
             flags |= AGT_PNP_PLANAR;
             double Rt[9];
 #pragma unroll
@@ -455,9 +504,10 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             for (int q = 0; q < PPL; q++) {
                 px_[q] = py_[q] = nx_[q] = ny_[q] = 0.0;
                 if (use[q]) {
-                    px_[q] = Rt[0] * X[q] + Rt[1] * Y[q] + Rt[2] * Z[q] + Tt[0];
-                    py_[q] = Rt[3] * X[q] + Rt[4] * Y[q] + Rt[5] * Z[q] + Tt[1];
+                    px_[q] = (double)(float)(Rt[0] * X[q] + Rt[1] * Y[q] + Rt[2] * Z[q] + Tt[0]);
+                    py_[q] = (double)(float)(Rt[3] * X[q] + Rt[4] * Y[q] + Rt[5] * Z[q] + Tt[1]);
                     undistort5(cam, mu_[q], mv_[q], nx_[q], ny_[q]);
+                    nx_[q] = (double)(float)nx_[q]; ny_[q] = (double)(float)ny_[q];
                     c8[0] += nx_[q]; c8[1] += ny_[q]; c8[2] += px_[q]; c8[3] += py_[q];
                 }
             }
@@ -509,10 +559,163 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 agt_mat3_mul(Tm, Hn2, h);
                 bool ok = hom_ok && h[8] != 0.0;
                 for (int i = 0; i < 9; i++) ok = ok && (h[i] - h[i] == 0.0);
+                const double s8 = ok ? 1.0 / h[8] : 0.0;
+                for (int i = 0; i < 9; i++) sh.vec[32 + i] = h[i] * s8;      // normalised: H[8] = 1
+                sh.vec[41] = ok ? 1.0 : 0.0;
+            }
+            __syncthreads();
+            double hx[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) hx[i] = sh.vec[32 + i];
+            const bool h_ok = sh.vec[41] != 0.0;
+            if (h_ok && n_used > 4) {
+                // ---- LMSolverImpl::run with HomographyRefineCallback (fundam.cpp), uniform across the wave
+                // sums of one evaluation: upper J^T J (36) | J^T r (8) | |r|^2 (1), taken in two passes of HP <= NACC sums
+                // (the reduction slab holds NACC rows)
+                constexpr int HP = 24;
+                static_assert(HP <= NACC && 2 * HP >= 45, "two passes cover the 45 sums");
+                auto hom_sums = [&](const double (&h)[8], auto LO_, double (&acc)[HP]) {
+                    constexpr int LO = decltype(LO_)::value;
+#pragma unroll
+                    for (int i = 0; i < HP; i++) acc[i] = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PPL; q++) if (use[q]) {
+                        const double Mx = px_[q], My = py_[q];
+                        double ww = h[6] * Mx + h[7] * My + 1.0;
+                        ww = fabs(ww) > DBL_EPSILON ? 1.0 / ww : 0.0;
+                        const double xi = (h[0] * Mx + h[1] * My + h[2]) * ww, yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+                        const double ex = xi - nx_[q], ey = yi - ny_[q];
+                        const double Jx[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
+                        const double Jy[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
+                        int idx = 0;
+#pragma unroll
+                        for (int a = 0; a < 8; a++)
+#pragma unroll
+                            for (int c = a; c < 8; c++) { if (idx >= LO && idx < LO + HP) acc[idx - LO] += Jx[a] * Jx[c] + Jy[a] * Jy[c]; idx++; }
+#pragma unroll
+                        for (int a = 0; a < 8; a++) { if (idx >= LO && idx < LO + HP) acc[idx - LO] += Jx[a] * ex + Jy[a] * ey; idx++; }
+                        if (idx >= LO && idx < LO + HP) acc[idx - LO] += ex * ex + ey * ey;
+                    }
+                };
+                // |r|^2 and max |r| only
+                auto hom_cost = [&](const double (&h)[8], double& rinf) -> double {
+                    double S = 0.0, ri = 0.0;
+#pragma unroll
+                    for (int q = 0; q < PPL; q++) if (use[q]) {
+                        const double Mx = px_[q], My = py_[q];
+                        double ww = h[6] * Mx + h[7] * My + 1.0;
+                        ww = fabs(ww) > DBL_EPSILON ? 1.0 / ww : 0.0;
+                        const double ex = (h[0] * Mx + h[1] * My + h[2]) * ww - nx_[q], ey = (h[3] * Mx + h[4] * My + h[5]) * ww - ny_[q];
+                        S += ex * ex + ey * ey;
+                        ri = fmax(ri, fmax(fabs(ex), fabs(ey)));
+                    }
+#pragma unroll
+                    for (int o = 32; o >= 1; o >>= 1) ri = fmax(ri, __shfl_xor(ri, o));
+                    rinf = ri;
+                    return wave_sum_f64(S);
+                };
+                double Au[36], vv[8], Dg[8], S, rinf;
+                auto hom_eval = [&](const double (&h)[8]) {
+                    double acc[HP];
+                    hom_sums(h, std::integral_constant<int, 0>{}, acc);
+                    wave_reduce_slab<HP>(acc, sh, lane);
+#pragma unroll
+                    for (int i = 0; i < HP; i++) Au[i] = acc[i];
+                    hom_sums(h, std::integral_constant<int, HP>{}, acc);
+                    wave_reduce_slab<HP>(acc, sh, lane);
+#pragma unroll
+                    for (int i = 0; i < 36 - HP; i++) Au[HP + i] = acc[i];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) vv[i] = acc[36 - HP + i];
+                    S = acc[44 - HP];
+                };
+                hom_eval(hx);
+                (void)hom_cost(hx, rinf);
+                {
+                    int idx = 0;
+#pragma unroll
+                    for (int a = 0; a < 8; a++)
+#pragma unroll
+                        for (int c = a; c < 8; c++) { if (c == a) Dg[a] = Au[idx]; idx++; }
+                }
+                double lambda_h = 1.0, lc = 0.75;
+                for (int it = 0;;) {
+                    // solve (A + lambda D) d = v  -- cv::solve(DECOMP_EIG) in OpenCV; Cholesky here (A + lambda D is SPD)
+                    __syncthreads();
+                    if (lane == 0) {
+                        double* Ap = sh.LL;
+                        int idx = 0;
+                        for (int a = 0; a < 8; a++)
+                            for (int c = a; c < 8; c++) { Ap[a * 8 + c] = Au[idx]; Ap[c * 8 + a] = Au[idx]; idx++; }
+                        for (int a = 0; a < 8; a++) { Ap[a * 9] += lambda_h * Dg[a]; sh.vec[16 + a] = vv[a]; }
+                        sh.vec[15] = spd_solve(Ap, 8, sh.vec + 16, sh.vec, nullptr) ? 1.0 : 0.0;
+                    }
+                    __syncthreads();
+                    if (sh.vec[15] == 0.0) break;
+                    double dd[8], xd[8];
+#pragma unroll
+                    for (int i = 0; i < 8; i++) { dd[i] = sh.vec[i]; xd[i] = hx[i] - dd[i]; }
+                    double rinf_d;
+                    const double Sd = hom_cost(xd, rinf_d);
+                    double dS = 0.0, tdv = 0.0;
+                    {
+                        // temp_d = -A d + 2 v;  dS = d . temp_d
+                        double Ad[8];
+#pragma unroll
+                        for (int a = 0; a < 8; a++) Ad[a] = 0.0;
+                        int idx = 0;
+#pragma unroll
+                        for (int a = 0; a < 8; a++)
+#pragma unroll
+                            for (int c = a; c < 8; c++) { Ad[a] += Au[idx] * dd[c]; if (c != a) Ad[c] += Au[idx] * dd[a]; idx++; }
+#pragma unroll
+                        for (int a = 0; a < 8; a++) { dS += dd[a] * (2.0 * vv[a] - Ad[a]); tdv += dd[a] * vv[a]; }
+                    }
+                    const double Rq = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1.0);
+                    if (Rq > 0.75) {
+                        lambda_h *= 0.5;
+                        if (lambda_h < lc) lambda_h = 0.0;
+                    } else if (Rq < 0.25) {
+                        double nu = (Sd - S) / (fabs(tdv) > DBL_EPSILON ? tdv : 1.0) + 2.0;
+                        nu = fmin(fmax(nu, 2.0), 10.0);
+                        if (lambda_h == 0.0) {
+                            __syncthreads();
+                            if (lane == 0) {
+                                double* Ap = sh.LL;
+                                int idx = 0;
+                                for (int a = 0; a < 8; a++)
+                                    for (int c = a; c < 8; c++) { Ap[a * 8 + c] = Au[idx]; Ap[c * 8 + a] = Au[idx]; idx++; }
+                                double mv = DBL_EPSILON;
+                                if (spd_solve(Ap, 8, nullptr, nullptr, sh.vec + 24))
+                                    for (int a = 0; a < 8; a++) mv = fmax(mv, fabs(sh.vec[24 + a]));
+                                sh.vec[14] = mv;
+                            }
+                            __syncthreads();
+                            lambda_h = lc = 1.0 / sh.vec[14];
+                            nu *= 0.5;
+                        }
+                        lambda_h *= nu;
+                    }
+                    if (Sd < S) {
+#pragma unroll
+                        for (int i = 0; i < 8; i++) hx[i] = xd[i];
+                        hom_eval(hx);
+                        rinf = rinf_d;
+                    }
+                    it++;
+                    double dinf = 0.0;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) dinf = fmax(dinf, fabs(dd[i]));
+                    if (!(it < 10 && dinf >= (double)FLT_EPSILON && rinf >= (double)FLT_EPSILON)) break;
+                }
+            }
+            __syncthreads();
+            if (lane == 0) {
+                double h[9];
+                for (int i = 0; i < 8; i++) h[i] = hx[i];
+                h[8] = sh.vec[40];                 // h33 * (1 / h33) as the DLT left it; not a parameter of the polish
                 double Rm[9], tv[3];
-                if (ok) {
-                    const double s8 = 1.0 / h[8];
-                    for (int i = 0; i < 9; i++) h[i] *= s8;
+                if (h_ok) {
                     const double h1n = sqrt(h[0] * h[0] + h[3] * h[3] + h[6] * h[6]);
                     const double h2n = sqrt(h[1] * h[1] + h[4] * h[4] + h[7] * h[7]);
                     const double s1 = 1. / fmax(h1n, DBL_EPSILON), s2 = 1. / fmax(h2n, DBL_EPSILON), s3 = 2. / fmax(h1n + h2n, DBL_EPSILON);

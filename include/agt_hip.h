@@ -132,7 +132,7 @@ int agt_lk_track(agt_ctx* ctx, int prev_slot, int next_slot,
 /* d_obj: n x 3 (obj_batch_stride = 0: shared by all B) or [B][n][3] (stride in elements).
  * d_img: [B][n][2].  dtype: AGT_F32 / AGT_F64 for both arrays.
  * d_mask: [B][n] u8 (0 = skip the point, e.g. LK status) or NULL.
- * K: 9 host doubles row-major.  dist: ndist host doubles (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4]]]) or NULL.
+ * K: 9 host doubles row-major.  dist: ndist host doubles (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4 [tau_x tau_y = 0]]]]) or NULL.
  * d_pose: [B][6] f64 (rvec, tvec): read when use_guess, always written on success
  * (cv2 overwrites the guess arrays in place too, detect_pose.py:487-490).
  * d_info: [B][4] i32 (AGT_INFO_*), d_err: [B] f64 mean reprojection error; either may be NULL. */

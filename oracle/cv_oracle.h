@@ -148,6 +148,9 @@ int cvo_dense_refine(const uint8_t* img, int w, int h, int stride,
 /* ---- small dense linear algebra (one-sided Jacobi SVD, as OpenCV's JacobiSVDImpl_) ---- */
 /* A: m x n row-major (m >= n). w: n, u: m x n (columns = left vectors), vt: n x n. sorted descending. */
 int cvo_svd(const double* A, int m, int n, double* w, double* u, double* vt);
+/* cv::findHomography(M -> m, method 0): points rounded to float32, normalised DLT, and (refine != 0, count > 4) the
+ * LMSolver polish of fundam.cpp / levmarq.cpp (<= 10 iterations).  M, m: count x 2 doubles; H row-major, H[8] = 1. */
+int cvo_find_homography(const double* M, const double* m, int count, int refine, double H[9]);
 /* solve A x = b (n x n) through the SVD pseudo-inverse (cv::solve DECOMP_SVD) */
 int cvo_solve_svd(const double* A, const double* b, int n, double* x);
 

@@ -321,9 +321,8 @@ int cvo_undistort_points(const double* img, int n, const double Kc[9],
 }
 
 /* ------------------------------------------------------------------------- */
-/* cv::findHomography(method = 0) initial estimate (fundam.cpp HomographyEstimatorCallback::runKernel).
- * OpenCV follows it with an LM polish of H; that polish is omitted here because the pose
- * LM below re-minimises the same pixel error afterwards (documented deviation, planar init only). */
+/* cv::findHomography(method = 0) initial estimate (fundam.cpp HomographyEstimatorCallback::runKernel);
+ * for more than four points OpenCV refines it with LMSolver (homography_refine_lm below). */
 static int homography_dlt(const double* M, const double* m, int count, double H[9])
 {
     double cMx = 0, cMy = 0, cmx = 0, cmy = 0, sMx = 0, sMy = 0, smx = 0, smy = 0;
@@ -356,6 +355,131 @@ static int homography_dlt(const double* M, const double* m, int count, double H[
     double s = 1. / H[8];
     for (int i = 0; i < 9; i++) H[i] *= s;
     return 0;
+}
+
+/* x = pinv(A) b for a symmetric PSD n x n A, as cv::solve(A, b, x, DECOMP_EIG): eigen-decomposition, components
+ * whose eigenvalue is <= 2 * DBL_EPSILON * sum(eigenvalues) dropped (matrix.cpp SVBkSb).  n <= 8. */
+static int sym_solve_eig(const double* A, int n, const double* b, double* x, double* inv_diag)
+{
+    double w[8], vt[64];
+    if (n > 8 || cvo_svd(A, n, n, w, NULL, vt)) return -1;     /* SVD of a symmetric PSD matrix = its eigen-decomposition */
+    double thr = 0;
+    for (int i = 0; i < n; i++) thr += w[i];
+    thr *= DBL_EPSILON * 2;
+    if (x) for (int i = 0; i < n; i++) x[i] = 0;
+    if (inv_diag) for (int i = 0; i < n; i++) inv_diag[i] = 0;
+    for (int k = 0; k < n; k++) {
+        if (fabs(w[k]) <= thr) continue;
+        const double* v = vt + k * n;
+        double iw = 1. / w[k];
+        if (x) {
+            double s = 0;
+            for (int i = 0; i < n; i++) s += v[i] * b[i];
+            s *= iw;
+            for (int i = 0; i < n; i++) x[i] += s * v[i];
+        }
+        if (inv_diag) for (int i = 0; i < n; i++) inv_diag[i] += v[i] * v[i] * iw;
+    }
+    return 0;
+}
+
+/* fundam.cpp HomographyRefineCallback::compute: reprojection residuals of H = [h0..h7, 1] and their 2 x 8 Jacobian rows,
+ * accumulated into A = J^T J (8 x 8), v = J^T r, S = |r|^2; returns max |r| in *rinf */
+static double hom_eval(const double* M, const double* m, int count, const double h[8], double* A, double* v, double* rinf)
+{
+    double S = 0, ri = 0;
+    if (A) { memset(A, 0, 64 * sizeof(double)); memset(v, 0, 8 * sizeof(double)); }
+    for (int i = 0; i < count; i++) {
+        double Mx = M[i * 2], My = M[i * 2 + 1];
+        double ww = h[6] * Mx + h[7] * My + 1.;
+        ww = fabs(ww) > DBL_EPSILON ? 1. / ww : 0;
+        double xi = (h[0] * Mx + h[1] * My + h[2]) * ww;
+        double yi = (h[3] * Mx + h[4] * My + h[5]) * ww;
+        double ex = xi - m[i * 2], ey = yi - m[i * 2 + 1];
+        S += ex * ex + ey * ey;
+        if (fabs(ex) > ri) ri = fabs(ex);
+        if (fabs(ey) > ri) ri = fabs(ey);
+        if (A) {
+            double Jx[8] = { Mx * ww, My * ww, ww, 0, 0, 0, -Mx * ww * xi, -My * ww * xi };
+            double Jy[8] = { 0, 0, 0, Mx * ww, My * ww, ww, -Mx * ww * yi, -My * ww * yi };
+            for (int a = 0; a < 8; a++) {
+                for (int b = 0; b < 8; b++) A[a * 8 + b] += Jx[a] * Jx[b] + Jy[a] * Jy[b];
+                v[a] += Jx[a] * ex + Jy[a] * ey;
+            }
+        }
+    }
+    if (rinf) *rinf = ri;
+    return S;
+}
+
+/* calib3d levmarq.cpp LMSolverImpl::run(param) with HomographyRefineCallback, maxIters = 10, epsx = epsf = FLT_EPSILON:
+ * what cv::findHomography(method 0) does to the DLT estimate when there are more than four points. */
+static void homography_refine_lm(const double* M, const double* m, int count, double H[9])
+{
+    double x[8], xd[8], A[64], Ap[64], v[8], d[8], D[8], tmp[8];
+    for (int i = 0; i < 8; i++) x[i] = H[i];            /* H[8] == 1 after the DLT's normalisation */
+    double rinf;
+    double S = hom_eval(M, m, count, x, A, v, &rinf);
+    for (int i = 0; i < 8; i++) D[i] = A[i * 9];
+    const double Rlo = 0.25, Rhi = 0.75;
+    double lambda = 1, lc = 0.75;
+    const int max_iters = 10;
+    const double epsx = FLT_EPSILON, epsf = FLT_EPSILON;
+    for (int iter = 0;;) {
+        memcpy(Ap, A, sizeof(Ap));
+        for (int i = 0; i < 8; i++) Ap[i * 9] += lambda * D[i];
+        if (sym_solve_eig(Ap, 8, v, d, NULL)) break;
+        for (int i = 0; i < 8; i++) xd[i] = x[i] - d[i];
+        double Sd = hom_eval(M, m, count, xd, NULL, NULL, NULL);
+        double dS = 0;
+        for (int i = 0; i < 8; i++) {
+            double t = 2 * v[i];
+            for (int j = 0; j < 8; j++) t -= A[i * 8 + j] * d[j];
+            tmp[i] = t;                                /* temp_d = -A d + 2 v */
+        }
+        for (int i = 0; i < 8; i++) dS += d[i] * tmp[i];
+        double R = (S - Sd) / (fabs(dS) > DBL_EPSILON ? dS : 1);
+        if (R > Rhi) {
+            lambda *= 0.5;
+            if (lambda < lc) lambda = 0;
+        } else if (R < Rlo) {
+            double t = 0;
+            for (int i = 0; i < 8; i++) t += d[i] * v[i];
+            double nu = (Sd - S) / (fabs(t) > DBL_EPSILON ? t : 1) + 2;
+            nu = fmin(fmax(nu, 2.), 10.);
+            if (lambda == 0) {
+                double idg[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, maxval = DBL_EPSILON;
+                sym_solve_eig(A, 8, NULL, NULL, idg);          /* invert(A, Ap, DECOMP_EIG): only its diagonal is used */
+                for (int i = 0; i < 8; i++) maxval = fmax(maxval, fabs(idg[i]));
+                lambda = lc = 1. / maxval;
+                nu *= 0.5;
+            }
+            lambda *= nu;
+        }
+        if (Sd < S) {
+            S = Sd;
+            for (int i = 0; i < 8; i++) x[i] = xd[i];
+            S = hom_eval(M, m, count, x, A, v, &rinf);      /* same value as Sd; refreshes r, J */
+        }
+        iter++;
+        double dinf = 0;
+        for (int i = 0; i < 8; i++) dinf = fmax(dinf, fabs(d[i]));
+        if (!(iter < max_iters && dinf >= epsx && rinf >= epsf)) break;
+    }
+    for (int i = 0; i < 8; i++) H[i] = x[i];
+}
+
+int cvo_find_homography(const double* M, const double* m, int count, int refine, double H[9])
+{
+    /* cv::findHomography converts both point sets to CV_32F first (fundam.cpp: p.reshape(2, npoints).convertTo(m, CV_32F)) */
+    if (!M || !m || !H || count < 4) return -1;
+    double* b = (double*)malloc((size_t)count * 4 * sizeof(double));
+    if (!b) return -2;
+    for (int i = 0; i < count * 2; i++) { b[i] = (double)(float)M[i]; b[count * 2 + i] = (double)(float)m[i]; }
+    int rc = homography_dlt(b, b + count * 2, count, H);
+    if (rc == 0 && refine && count > 4) homography_refine_lm(b, b + count * 2, count, H);
+    free(b);
+    return rc;
 }
 
 /* cvFindExtrinsicCameraParams2, the !useExtrinsicGuess branch */
@@ -391,7 +515,7 @@ int cvo_pnp_init(const double* obj, const double* img, int n,
             Mxy[i * 2] = Rt[0] * s[0] + Rt[1] * s[1] + Rt[2] * s[2] + tt[0];
             Mxy[i * 2 + 1] = Rt[3] * s[0] + Rt[4] * s[1] + Rt[5] * s[2] + tt[1];
         }
-        int ok = homography_dlt(Mxy, mn, n, h) == 0;
+        int ok = cvo_find_homography(Mxy, mn, n, 1, h) == 0;
         free(Mxy);
         for (int i = 0; ok && i < 9; i++) if (!isfinite(h[i])) ok = 0;
         if (ok) {

@@ -366,6 +366,18 @@ def solve_svd(A, b):
     return x
 
 
+def findHomography(src, dst, refine=True):
+    """cv2.findHomography(src, dst, method=0)[0]: (N,2) -> (N,2), 3x3 float64"""
+    a = _f64(np.asarray(src, np.float64).reshape(-1, 2)); b = _f64(np.asarray(dst, np.float64).reshape(-1, 2))
+    Hm = np.zeros(9)
+    L = lib()
+    L.cvo_find_homography.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    rc = L.cvo_find_homography(_p(a), _p(b), a.shape[0], 1 if refine else 0, _p(Hm))
+    if rc:
+        raise ValueError("findHomography failed (%d)" % rc)
+    return Hm.reshape(3, 3)
+
+
 def track_frame(prev_pyr, next_img, prev_pts, obj, K, dist, rvec, tvec, use_guess=True, win=21,
                 max_level=2, max_count=30, eps=0.01, acc_mode=ACC_EXACT, nthreads=1):
     """Whole CPU frame step: pyramid(next) + LK + solvePnP(guess).  Returns

@@ -198,3 +198,32 @@ def test_threaded_full_frame_passes_are_band_invariant(oracle):
                 assert np.array_equal(p.level(l), ref_p[l])
     finally:
         L.cvo_set_num_threads(1)
+
+
+def test_find_homography_lm_refinement_vs_scipy(oracle):
+    """cv::findHomography(method 0) = normalised DLT + LMSolver polish (fundam.cpp, levmarq.cpp) for > 4 points.  The
+    restatement is pinned on its defining property: the polished H is the least-squares minimiser of the reprojection
+    error (scipy least_squares 'lm' from the same DLT start), the un-polished DLT is measurably not."""
+    from scipy.optimize import least_squares
+    rng = np.random.default_rng(0)
+    Ht = np.array([[1.1, 0.05, 0.02], [-0.03, 0.95, -0.01], [0.2, -0.1, 1.0]])
+    for n, noise in ((5, 1e-3), (20, 2e-3), (60, 5e-4)):
+        M = rng.uniform(-0.05, 0.05, (n, 2)).astype(np.float32).astype(np.float64)
+        P = np.c_[M, np.ones(n)] @ Ht.T
+        m = (P[:, :2] / P[:, 2:] + rng.normal(0, noise, (n, 2))).astype(np.float32).astype(np.float64)
+        H0 = oracle.findHomography(M, m, refine=False)
+        H1 = oracle.findHomography(M, m, refine=True)
+        assert abs(H0[2, 2] - 1.0) < 1e-15 and H1[2, 2] == H0[2, 2]        # h33 = h33 * (1 / h33), not a parameter of the polish
+
+        def res(h):
+            Hm = np.r_[h, 1.0].reshape(3, 3)
+            Q = np.c_[M, np.ones(n)] @ Hm.T
+            return (Q[:, :2] / Q[:, 2:] - m).ravel()
+        sol = least_squares(res, H0.ravel()[:8], method="lm", xtol=1e-15, ftol=1e-15, gtol=1e-15)
+        c0, c1, cs = (res(H0.ravel()[:8]) ** 2).sum(), (res(H1.ravel()[:8]) ** 2).sum(), (sol.fun ** 2).sum()
+        assert c1 <= c0 and abs(c1 - cs) <= 1e-9 * cs
+        assert np.abs(H1.ravel()[:8] - sol.x).max() < 2e-5            # OpenCV stops at |step|_inf < FLT_EPSILON
+        assert np.abs(H0.ravel()[:8] - sol.x).max() > 10 * np.abs(H1.ravel()[:8] - sol.x).max()
+    # four points: exact fit, no polish (cv::findHomography refines only when npoints > 4)
+    M4 = np.array([[-1.0, -1], [-1, 1], [1, 1], [1, -1]]); P4 = np.c_[M4, np.ones(4)] @ Ht.T; m4 = P4[:, :2] / P4[:, 2:]
+    assert np.abs(oracle.findHomography(M4, m4, True) - oracle.findHomography(M4, m4, False)).max() == 0.0
