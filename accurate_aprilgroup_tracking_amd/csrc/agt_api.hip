@@ -35,6 +35,11 @@ struct agt_ctx {
     hipStream_t ms_stream[3];                // pyramid, LK, PnP
     hipEvent_t ms_ev[4][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done
     int ms_ready, ms_active;                 // streams / events exist; frames are in flight on them
+    // split mode (more corners in flight than the fused launch takes): the pipeline's groups go out as two launches,
+    // pyramid + LK on the caller's stream (X), PnP on a library stream (Y); evX / evY = ms_ev[0] / ms_ev[1]
+    long split_seq;                          // launches issued in split mode
+    int last_x_ev;                           // event slot of the most recent X launch (-1 = none)
+    int y_ev_hist[2];                        // event slots of the two most recent Y launches (-1 = none)
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
@@ -61,6 +66,7 @@ struct agt_ctx {
 };
 
 static int ms_join(agt_ctx* c);
+static int ms_init(agt_ctx* c);
 
 namespace {
 
@@ -183,6 +189,7 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
+    c->last_x_ev = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
@@ -554,8 +561,41 @@ static int launch_group(agt_ctx* c, int B)
         any = true;
     }
     if (!any) return AGT_OK;
-    hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win);
-    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+    if (agt_step_fits(c->trk_n, B)) {
+        hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_ALL);
+        return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+    }
+    // ---- split mode: the same group as two launches.  X (pyramid + LK roles, one wave per corner at four waves per
+    // SIMD) on the caller's stream, Y (PnP role, the FP64 register budget) on a library stream; they overlap because Y
+    // works on the frames X finished one launch earlier.  Events: Y waits for the PREVIOUS X launch (its LK results);
+    // X waits for the Y launch of two groups ago (ring reuse: LK rewrites corner / status entries (L + 2) groups after
+    // PnP read them; two groups of slack keep the wait off the critical path).  Five or six HIP calls per GROUP of F frames
+    // (round 1 issued thirteen per frame on three streams).
+    int rc = ms_init(c);
+    if (rc) return rc;
+    hipStream_t sY = c->ms_stream[2];
+    hipEvent_t *evX = c->ms_ev[0], *evY = c->ms_ev[1];
+    const int slot_ev = (int)(c->split_seq % AGT_RING_MAX);
+    const bool x_work = S.n_lk > 0 || S.n_pyr[0] > 0 || S.n_pyr[1] > 0 || S.n_pyr[2] > 0 || S.n_pyr[3] > 0 || S.n_pyr[4] > 0;
+    hipError_t e = hipSuccess;
+    const int x_before = c->last_x_ev;
+    if (x_work) {
+        if (c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(c->stream, evY[c->y_ev_hist[1]], 0);
+        if (e == hipSuccess) e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_X);
+        if (e == hipSuccess) e = hipEventRecord(evX[slot_ev], c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        c->last_x_ev = slot_ev;
+    }
+    if (S.n_pnp > 0) {
+        if (x_before >= 0) e = hipStreamWaitEvent(sY, evX[x_before], 0);          // the LK these frames came from (and everything before it)
+        if (e == hipSuccess) e = agt_launch_step(sY, S, T, c->cfg.win, AGT_STEP_Y);
+        if (e == hipSuccess) e = hipEventRecord(evY[slot_ev], sY);
+        if (e != hipSuccess) return hip_fail(c, e);
+        c->y_ev_hist[1] = c->y_ev_hist[0]; c->y_ev_hist[0] = slot_ev;
+        c->ms_active = 1;
+    }
+    c->split_seq++;
+    return AGT_OK;
 }
 
 // Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
@@ -578,12 +618,11 @@ int agt_tracker_join(agt_ctx* c)
 {
     if (!c) return AGT_ERR_ARG;
     if (c->trk_ready != 2) return AGT_OK;
-    if (c->ms_active) return ms_join(c);
     while (c->n_pnp < c->trk_frame) {
         int rc = launch_group(c, c->trk_B);
         if (rc) return rc;
     }
-    return AGT_OK;
+    return c->ms_active ? ms_join(c) : AGT_OK;
 }
 
 int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int B, double* d_state_out)
@@ -614,76 +653,17 @@ static int ms_init(agt_ctx* c)
     return AGT_OK;
 }
 
-#define AGT_MS_RING 8            // ring entries multi-stream mode needs at least
-#define AGT_MS_GAP 4             // buffer-reuse waits are issued every AGT_MS_GAP frames, on the events of AGT_MS_GAP frames ago
-
-static int step_multistream(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
-{
-    int rc = ms_init(c);
-    if (rc) return rc;
-    const bool first = !c->ms_active;
-    if (first && c->live_ring < AGT_MS_RING) {
-        // (the caller joined: only the newest frame is live) at least eight ring entries let the reuse waits be sparse
-        rc = ensure_ring(c, AGT_MS_RING);
-        if (rc) return rc;
-        ring_move(c, c->trk_frame, c->live_ring, AGT_MS_RING);
-        c->live_ring = AGT_MS_RING;
-    }
-    const int R = c->live_ring;
-    const long t = c->trk_frame + 1;
-    const int slot = (int)(t % R), pslot = (int)((t - 1) % R);
-    hipStream_t sA = c->ms_stream[0], sB = c->ms_stream[1], sC = c->ms_stream[2];
-    hipEvent_t *evU = c->ms_ev[0], *evA = c->ms_ev[1], *evB = c->ms_ev[2], *evC = c->ms_ev[3];
-    // HIP event calls cost ~4 us of host time each, so only the waits that carry a real dependency are issued:
-    //   every frame   caller -> pyramid (the frame data), pyramid -> LK, LK -> PnP
-    //   first frame   caller -> LK, PnP too (corners and tracker state written by agt_tracker_reset / earlier modes)
-    //   every 4th     the ring-reuse guards, on the events of 4 frames ago: pyramid(t..t+3) overwrite the entries of
-    //                 frames t-8..t-5, last read by LK(t-7..t-4); LK(t..t+3) overwrite corner entries last read by
-    //                 PnP(t-8..t-5); both are complete once LK(t-4) / PnP(t-4) are (streams run in order)
-    const bool guard = t % AGT_MS_GAP == 0 && t - AGT_MS_GAP >= 1;
-    const int gslot = (int)((t - AGT_MS_GAP) % R);
-    hipError_t e = hipEventRecord(evU[slot], c->stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(sA, evU[slot], 0);
-    if (e == hipSuccess && first) e = hipStreamWaitEvent(sB, evU[slot], 0);
-    if (e == hipSuccess && first) e = hipStreamWaitEvent(sC, evU[slot], 0);
-    if (e == hipSuccess && guard) e = hipStreamWaitEvent(sA, evB[gslot], 0);
-    // ... and the caller's stream falls in behind LK(t-4) as well: frames handed over 9 or more calls ago are then
-    // dead for every later operation on that stream, which is what a stream-ordered allocator needs to recycle them
-    if (e == hipSuccess && guard) e = hipStreamWaitEvent(c->stream, evB[gslot], 0);
-    if (e != hipSuccess) return hip_fail(c, e);
-    rc = pyramid_build_on(c, sA, slot, d_frames, pitch, batch_stride, B);
-    if (rc) return rc;
-    e = hipEventRecord(evA[slot], sA);
-    if (e == hipSuccess) e = hipStreamWaitEvent(sB, evA[slot], 0);
-    if (e == hipSuccess && guard) e = hipStreamWaitEvent(sB, evC[gslot], 0);
-    if (e != hipSuccess) return hip_fail(c, e);
-    rc = lk_track_on(c, sB, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
-                     c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
-    if (rc) return rc;
-    e = hipEventRecord(evB[slot], sB);
-    if (e == hipSuccess) e = hipStreamWaitEvent(sC, evB[slot], 0);
-    if (e != hipSuccess) return hip_fail(c, e);
-    AgtPnpParams p;
-    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, nullptr);
-    e = agt_launch_pnp(sC, p, B);
-    if (e == hipSuccess && t % AGT_MS_GAP == 0) e = hipEventRecord(evC[slot], sC);
-    if (e != hipSuccess) return hip_fail(c, e);
-    c->trk_frame = t; c->n_lk = c->n_pnp = t;
-    for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
-    c->ms_active = 1;
-    return AGT_OK;
-}
-
-// the caller's stream waits for everything in flight on the library's streams: PnP of the newest frame comes after
-// its LK, which comes after its pyramid, and each stream runs in order
+// the caller's stream waits for everything in flight on the library's stream (the PnP launches of split mode; each
+// came after the LK it depends on)
 static int ms_join(agt_ctx* c)
 {
     if (!c->ms_active) return AGT_OK;
-    hipEvent_t ev = c->ms_ev[0][AGT_RING_MAX - 1];                   // (hand-over events are waited on immediately: the last entry is free)
+    hipEvent_t ev = c->ms_ev[2][0];
     hipError_t e = hipEventRecord(ev, c->ms_stream[2]);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
     if (e != hipSuccess) return hip_fail(c, e);
     c->ms_active = 0;
+    c->last_x_ev = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;     // everything issued so far is ordered before the caller's next work
     return AGT_OK;
 }
 
@@ -744,18 +724,12 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
     // the fused launch pays off while the stages are latency-bound (few streams); the biggest batches fill
     // the chip per stage and run faster as separate launches with their own register budgets
-    if (c->pipeline && !c->reproject && agt_step_fits(c->trk_n, B)) {
+    if (c->pipeline && !c->reproject && (agt_step_fits(c->trk_n, B) || !pev)) {
         // fused launch: the three spans collapse into one (span 2 = the whole step_kernel launch)
         if (pev) { (void)hipEventRecord(pev[0], c->stream); (void)hipEventRecord(pev[1], c->stream); (void)hipEventRecord(pev[2], c->stream); }
         int rc = step_pipelined(c, d_frames, pitch, batch_stride, B, d_state_out);
         if (pev && rc == AGT_OK) { (void)hipEventRecord(pev[3], c->stream); c->prof_n++; }
         return rc;
-    }
-
-    if (c->pipeline && !c->reproject && !pev) {
-        // more corners in flight than the fused launch takes: stage kernels, overlapped across frames on three streams
-        if (!c->ms_active) { int rj = agt_tracker_join(c); if (rj) return rj; }
-        return step_multistream(c, d_frames, pitch, batch_stride, B, d_state_out);
     }
 
     return step_serial(c, d_frames, pitch, batch_stride, B, d_state_out, nullptr, pev);

@@ -123,11 +123,41 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
     }
 }
 
+// PnP role alone (split mode: more corners in flight than the fused launch takes; the LK + pyramid roles go out as
+// step_kernel<.., PNP = false> on the caller's stream, this one on a library stream).  PPL: points per lane.
+template <int PPL>
+__global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    __shared__ agt_pnp::PnpShared sh;
+    const __attribute__((address_space(4))) AgtStepTables* KT = (const __attribute__((address_space(4))) AgtStepTables*)(
+        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
+    const int blk = blockIdx.x;
+    if (S.pnp_nf > 1 && threadIdx.x < sizeof(AgtPnpTables) / 4)
+        reinterpret_cast<uint32_t*>(sh.tab)[threadIdx.x] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[threadIdx.x];
+    for (int k = 0; k < S.pnp_nf; k++) {
+        const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
+        if (k) {
+            __syncthreads();
+            img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
+        }
+        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so);
+    }
+}
+
+// roles: AGT_STEP_ALL = one fused launch; AGT_STEP_X = pyramid + LK roles only (kernel compiled without the FP64 PnP role:
+// the one-wave-per-corner LK keeps its four waves per SIMD); AGT_STEP_Y = the PnP role only
 template <int WIN, int NW>
-hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T)
+hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int roles)
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
+    if (roles == AGT_STEP_Y) {
+        if (P.n_pnp <= 0) return hipSuccess;
+        if (P.pnp.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
+        else hipLaunchKernelGGL((pnp_group_kernel<agt_pnp::MAX_PPL>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
+        return hipGetLastError();
+    }
+    if (roles == AGT_STEP_X) { P.n_pnp = 0; P.pnp_nf = 0; }
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only (make dbg): drop roles from the launch to time the others
     { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();
       if (skip & 1) P.n_pnp = 0; if (skip & 2) P.n_lk = 0; if (skip & 4) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.n_pyr[s] = 0; } }
@@ -146,6 +176,12 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (P.n_pnp > 0) { blocks += P.n_pnp; lds = lds > sizeof(agt_pnp::PnpShared) ? lds : sizeof(agt_pnp::PnpShared); }
     if (blocks == 0) return hipSuccess;
     const bool small = P.lk.max_level < 3;
+    if (roles == AGT_STEP_X) {
+        constexpr int OCCX = NW == 1 ? 4 : 1;
+        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, false, OCCX>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, false, OCCX>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+        return hipGetLastError();
+    }
     // OCC = 1: the FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU,
     // best while <= 256 corners are in flight.  OCC = 2: registers capped at 256 (336 B of scratch for the PnP
     // role), two workgroups per CU: +0.4 us on one stream, but 8 / 32 streams run at 23 / 49 us per step.
@@ -165,6 +201,7 @@ bool agt_step_supported(int win) { return win == 21; }
 // Fused launch (all roles in one kernel) up to 2048 corners in flight, measured on 48-corner streams: 1 / 4 / 8 / 16 /
 // 32 streams take 20 / 22 / 23 / 42 / 49 us per step against 41 / 42 / 46 / 53 / 67 as separate kernels; at 64 streams
 // (94 vs 85) the one-wave-per-corner LK role wants more than the two waves per SIMD the fused launch can hold.
+// (larger batches: the same pipeline in two launches per group, see AGT_STEP_X / AGT_STEP_Y)
 bool agt_step_fits(int n, int B)
 {
 #ifdef AGT_DEBUG_KNOBS
@@ -175,9 +212,9 @@ bool agt_step_fits(int n, int B)
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
 
-hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win)
+hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, int roles)
 {
     if (win != 21) return hipErrorInvalidValue;
     const bool wide = S.n_lk > 0 ? agt_lk_wide(S.lk.n, S.lk_B) : true;
-    return wide ? launch_step_t<21, 4>(stream, S, T) : launch_step_t<21, 1>(stream, S, T);
+    return wide ? launch_step_t<21, 4>(stream, S, T, roles) : launch_step_t<21, 1>(stream, S, T, roles);
 }

@@ -305,7 +305,7 @@ def main():
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
     auto_depth = 4 if K >= 100 else (2 if K >= 40 else 1)
-    depth = max(1, min(args.depth or auto_depth, 8)) if fused else 1
+    depth = max(1, min(args.depth or (auto_depth if fused else 2), 8))       # split mode (not fused): two launches per group of `depth` frames
     bench.trk.pipeline(depth)
     dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
     med, p10, p90 = percentiles(dts)
@@ -364,7 +364,8 @@ def main():
                           "frames_resident": "HBM ring %d slots (%.0f MiB)" % (bench.ring_slots, bench.ring_slots * B * bench.W * bench.H / 2**20),
                           "parallelism": "stream-per-GPU x%d, %s all_gather of poses once per block" % (world, "gloo (REHEARSAL: ranks share GPUs)" if rehearsal else "RCCL"),
                           "launch": ("fused software-pipelined step, %d frames per launch (record of frame t written ~%d steps later)"
-                                     % (depth, LEVELS * depth)) if fused else "stage kernels per step"},
+                                     % (depth, LEVELS * depth)) if fused else
+                                    "split pipeline: pyramid + LK launch (caller's stream) | PnP launch (library stream), %d frames per group" % depth},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5),
                           "value_p10": round(world * B * K / p90, 2), "value_p90": round(world * B * K / p10, 2)},
@@ -461,7 +462,7 @@ def batch_extra(torch, D, HL, args, rank, dev):
     a.steps, a.warmup, a.streams, a.render_frames = 60, 10, 64, min(args.render_frames, 8)
     wl = WORKLOADS["c3"]
     b = Bench(torch, wl, a, rank, 1, dev)
-    b.trk.pipeline(1)
+    b.trk.pipeline(args.depth or 2)
     dts, _, _, st, _ = b.timed_blocks(D, 7)
     med, p10, p90 = percentiles(dts)
     spans = b.stage_spans_us(HL, 40)

@@ -172,10 +172,9 @@ int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate
  * stages of all supplied frames (no host synchronisation) and agt_synchronize joins and waits.  Frames handed to
  * agt_track_frame must stay valid and unmodified until their pose has been produced ((L+2)*F + F frames are in
  * flight at most), and the frames of one group must share pitch and batch stride.  Changing the depth joins first.
- * With more than 2048 corners in flight (depth >= 1) the three stages run as separate kernels on three library-owned
- * streams, overlapped across frames with event dependencies; agt_tracker_join makes the context's stream wait for them.
- * In that mode a frame buffer must stay valid for 9 further agt_track_frame calls (or until a join): every 4th call
- * the context's stream is made to wait for the LK of 4 frames earlier, so stream-ordered allocators may recycle it then. */
+ * With more than 2048 corners in flight (depth >= 1) the same pipeline runs as TWO launches per group: the pyramid and LK
+ * roles on the context's stream, the PnP role (its FP64 register budget) on a library-owned stream, ordered by two events per
+ * group; agt_tracker_join makes the context's stream wait for the library's.  Frame lifetime is the same as above. */
 int agt_tracker_pipeline(agt_ctx* ctx, int depth);
 int agt_tracker_join(agt_ctx* ctx);
 /* PoseDetector._estimate_pose (detect_pose.py:467-574) for B streams with device-resident

@@ -266,7 +266,7 @@ def test_solve_pnp_planar_two_minima(torch_cuda, cvh, oracle):
             assert info[b, H.INFO_OK] == 1 and info[b, H.INFO_FLAGS] & H.PNP_PLANAR
             assert np.abs(pose[b, :3] - r_o.ravel()).max() < 1e-7 and np.abs(pose[b, 3:] - t_o.ravel()).max() < 1e-7, "problem %d" % b
             flips += int(np.abs(pose[b, :3] - truth[b][:3]).max() > 0.2)
-        assert flips < B // 2          # the ambiguity is real on this set (some land in the mirror pose), not the rule
+        assert 0 < flips < B           # the ambiguity is real on this set: both minima are reached, problem by problem as the oracle does
 
 
 def test_distortion_coefficient_counts(cvh, oracle):
