@@ -9,6 +9,7 @@
 
 #define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
 #define AGT_RING_MAX 64          // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
+#define AGT_SPLIT_SLACK 2        // split mode: groups of extra ring entries (pyramid launches run that far ahead of LK)
 
 struct agt_ctx {
     agt_config cfg;
@@ -35,11 +36,12 @@ struct agt_ctx {
     hipStream_t ms_stream[3];                // pyramid, LK, PnP
     hipEvent_t ms_ev[4][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done
     int ms_ready, ms_active;                 // streams / events exist; frames are in flight on them
-    // split mode (more corners in flight than the fused launch takes): the pipeline's groups go out as two launches,
-    // pyramid + LK on the caller's stream (X), PnP on a library stream (Y); evX / evY = ms_ev[0] / ms_ev[1]
-    long split_seq;                          // launches issued in split mode
-    int last_x_ev;                           // event slot of the most recent X launch (-1 = none)
-    int y_ev_hist[2];                        // event slots of the two most recent Y launches (-1 = none)
+    // split mode (more corners in flight than the fused launch takes): the pipeline's groups go out as three launches,
+    // pyramid on the caller's stream, LK and PnP on library streams (ms_stream[1], [2])
+    long split_seq;                          // groups issued in split mode
+    int last_p_ev;                           // event slot of the most recent pyramid launch (-1 = none)
+    int l_ev_hist[3];                        // event slots of the three most recent LK launches (-1 = none)
+    int y_ev_hist[2];                        // event slots of the two most recent PnP launches (-1 = none)
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
@@ -189,7 +191,7 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
-    c->last_x_ev = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;
+    c->last_p_ev = -1; c->l_ev_hist[0] = c->l_ev_hist[1] = c->l_ev_hist[2] = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
@@ -494,6 +496,7 @@ static int launch_group(agt_ctx* c, int B)
     done_before[0] = c->trk_frame;
     for (int s = 0; s < L; s++) done_before[s + 1] = c->n_stage[s];
     const long lk_before = c->n_lk;
+    long lk_f0 = 0;                              // LK role: the frame before its group
     bool any = false;
     for (int s = 0; s < L; s++) {
         long cnt = done_before[s] - c->n_stage[s];
@@ -528,6 +531,7 @@ static int launch_group(agt_ctx* c, int B)
         long cnt = done_before[L] - c->n_lk;
         if (cnt > F) cnt = F;
         const long f0 = c->n_lk;                 // the frame before the group
+        lk_f0 = f0;
         // level 0 geometry comes from the frame's own registration; a group needs it uniform
         for (long k = 1; k <= cnt; k++) {
             const int a = (int)(f0 % M), q = (int)((f0 + k) % M);
@@ -565,30 +569,59 @@ static int launch_group(agt_ctx* c, int B)
         hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_ALL);
         return e == hipSuccess ? AGT_OK : hip_fail(c, e);
     }
-    // ---- split mode: the same group as two launches.  X (pyramid + LK roles, one wave per corner at four waves per
-    // SIMD) on the caller's stream, Y (PnP role, the FP64 register budget) on a library stream; they overlap because Y
-    // works on the frames X finished one launch earlier.  Events: Y waits for the PREVIOUS X launch (its LK results);
-    // X waits for the Y launch of two groups ago (ring reuse: LK rewrites corner / status entries (L + 2) groups after
-    // PnP read them; two groups of slack keep the wait off the critical path).  Five or six HIP calls per GROUP of F frames
-    // (round 1 issued thirteen per frame on three streams).
+    // ---- split mode: the same group as three launches, one per role, each with its own LDS size and register budget:
+    // pyramid on the caller's stream (the frames come from there), LK and PnP on two library streams.  The roles of one
+    // group are independent (the pipeline skews them across frames), so the three launches overlap; ordering is by events:
+    //   LK(k)  waits for pyramid(k-1)   (its images)          and for PnP(k-2)  (ring reuse of corner / status entries)
+    //   PnP(k) waits for LK(k-1)        (its corners)
+    //   pyramid(k) waits for LK(k-3)    (ring reuse of level entries: split mode keeps AGT_SPLIT_SLACK = 2 groups of extra
+    //                                    ring entries, so the HBM-bound pyramid launches run AHEAD of the LK launches they share
+    //                                    the chip with and never sit on the critical path; the wait also keeps the caller's
+    //                                    stream behind the readers of frames handed over (L + 6) groups ago, so stream-ordered
+    //                                    allocators may recycle those)
+    // Ten HIP calls per GROUP of F frames (round 1 issued thirteen per frame).
     int rc = ms_init(c);
     if (rc) return rc;
-    hipStream_t sY = c->ms_stream[2];
-    hipEvent_t *evX = c->ms_ev[0], *evY = c->ms_ev[1];
+    hipStream_t sL = c->ms_stream[1], sY = c->ms_stream[2];
+    hipEvent_t *evP = c->ms_ev[0], *evL = c->ms_ev[1], *evY = c->ms_ev[3];
     const int slot_ev = (int)(c->split_seq % AGT_RING_MAX);
-    const bool x_work = S.n_lk > 0 || S.n_pyr[0] > 0 || S.n_pyr[1] > 0 || S.n_pyr[2] > 0 || S.n_pyr[3] > 0 || S.n_pyr[4] > 0;
+    bool p_work = false;
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) p_work |= S.n_pyr[s] > 0;
+    const int p_before = c->last_p_ev, l_before = c->l_ev_hist[0];
     hipError_t e = hipSuccess;
-    const int x_before = c->last_x_ev;
-    if (x_work) {
-        if (c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(c->stream, evY[c->y_ev_hist[1]], 0);
-        if (e == hipSuccess) e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_X);
-        if (e == hipSuccess) e = hipEventRecord(evX[slot_ev], c->stream);
+    if (p_work) {
+        if (c->l_ev_hist[AGT_SPLIT_SLACK] >= 0) e = hipStreamWaitEvent(c->stream, evL[c->l_ev_hist[AGT_SPLIT_SLACK]], 0);
+        if (e == hipSuccess) e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_PYR);
+        if (e == hipSuccess) e = hipEventRecord(evP[slot_ev], c->stream);
         if (e != hipSuccess) return hip_fail(c, e);
-        c->last_x_ev = slot_ev;
+        c->last_p_ev = slot_ev;
+    }
+    if (S.n_lk > 0) {
+        if (p_before >= 0) e = hipStreamWaitEvent(sL, evP[p_before], 0);
+        else {
+            // no pyramid launch since the last join (single-level pyramids, or the first LK of a run): order the LK stream
+            // behind the caller's stream explicitly (reset's corner copy, earlier modes' pyramids)
+            e = hipEventRecord(c->ms_ev[2][2], c->stream);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sL, c->ms_ev[2][2], 0);
+        }
+        if (e == hipSuccess && c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(sL, evY[c->y_ev_hist[1]], 0);
+        if (e != hipSuccess) return hip_fail(c, e);
+        // one stand-alone LK launch per frame of the group, back to back on the LK stream (as a role with an in-kernel frame
+        // loop the one-wave-per-corner kernel needs 240 B of scratch per lane at its 128-register budget and runs at half speed)
+        for (int k = 1; k <= S.lk_nf; k++) {
+            const int ps = (int)((lk_f0 + k - 1) % M), sl = (int)((lk_f0 + k) % M);
+            rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B,
+                             AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+            if (rc) return rc;
+        }
+        e = hipEventRecord(evL[slot_ev], sL);
+        if (e != hipSuccess) return hip_fail(c, e);
+        c->l_ev_hist[2] = c->l_ev_hist[1]; c->l_ev_hist[1] = c->l_ev_hist[0]; c->l_ev_hist[0] = slot_ev;
+        c->ms_active = 1;
     }
     if (S.n_pnp > 0) {
-        if (x_before >= 0) e = hipStreamWaitEvent(sY, evX[x_before], 0);          // the LK these frames came from (and everything before it)
-        if (e == hipSuccess) e = agt_launch_step(sY, S, T, c->cfg.win, AGT_STEP_Y);
+        if (l_before >= 0) e = hipStreamWaitEvent(sY, evL[l_before], 0);
+        if (e == hipSuccess) e = agt_launch_step(sY, S, T, c->cfg.win, AGT_STEP_PNP);
         if (e == hipSuccess) e = hipEventRecord(evY[slot_ev], sY);
         if (e != hipSuccess) return hip_fail(c, e);
         c->y_ev_hist[1] = c->y_ev_hist[0]; c->y_ev_hist[0] = slot_ev;
@@ -601,6 +634,21 @@ static int launch_group(agt_ctx* c, int B)
 // Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
 static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
 {
+    // ring modulus of this mode: (L + 2) groups, plus the split mode's slack when the entries are available
+    {
+        const bool split = !agt_step_fits(c->trk_n, B);
+        int groups = c->eff_max_level + 2 + (split ? AGT_SPLIT_SLACK : 0);
+        if (groups * c->group > AGT_RING_MAX) groups = c->eff_max_level + 2;
+        const int want = groups * c->group > AGT_SLOTS ? groups * c->group : AGT_SLOTS;
+        if (want != c->live_ring) {
+            int rc = agt_tracker_join(c);            // only the newest frame is live afterwards
+            if (rc) return rc;
+            rc = ensure_ring(c, want);
+            if (rc) return rc;
+            ring_move(c, c->trk_frame, c->live_ring, want);
+            c->live_ring = want;
+        }
+    }
     const long t = c->trk_frame + 1;
     const int slot = (int)(t % c->live_ring);
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
@@ -653,17 +701,18 @@ static int ms_init(agt_ctx* c)
     return AGT_OK;
 }
 
-// the caller's stream waits for everything in flight on the library's stream (the PnP launches of split mode; each
-// came after the LK it depends on)
+// the caller's stream waits for everything in flight on the library's streams (the LK and PnP launches of split mode)
 static int ms_join(agt_ctx* c)
 {
     if (!c->ms_active) return AGT_OK;
-    hipEvent_t ev = c->ms_ev[2][0];
-    hipError_t e = hipEventRecord(ev, c->ms_stream[2]);
-    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev, 0);
+    hipEvent_t ev1 = c->ms_ev[2][0], ev2 = c->ms_ev[2][1];
+    hipError_t e = hipEventRecord(ev1, c->ms_stream[1]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev1, 0);
+    if (e == hipSuccess) e = hipEventRecord(ev2, c->ms_stream[2]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev2, 0);
     if (e != hipSuccess) return hip_fail(c, e);
     c->ms_active = 0;
-    c->last_x_ev = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;     // everything issued so far is ordered before the caller's next work
+    c->last_p_ev = -1; c->l_ev_hist[0] = c->l_ev_hist[1] = c->l_ev_hist[2] = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;     // everything issued so far is ordered before the caller's next work
     return AGT_OK;
 }
 

@@ -154,7 +154,9 @@ bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
 bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used up to 2048 corners in flight
-#define AGT_STEP_ALL 0
-#define AGT_STEP_X   1            // pyramid + LK roles (caller's stream)
-#define AGT_STEP_Y   2            // PnP role (library stream)
+// role subsets of one pipeline group (split mode launches them separately, each with its own LDS size and register budget)
+#define AGT_STEP_PYR 1
+#define AGT_STEP_LK  2
+#define AGT_STEP_PNP 4
+#define AGT_STEP_ALL 7
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, int roles);

@@ -22,92 +22,78 @@ namespace {
 
 constexpr int STEP_THREADS = 256;
 
-// OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).  The one-wave-per-corner
-// LK role of big batches wants 3, as the stand-alone LK kernel has.
-template <int WIN, int NW, int NLEV, bool PNP, int OCC>
-__global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void step_kernel(const AgtStepParams S, const AgtStepTables T)
+typedef const __attribute__((address_space(4))) AgtStepParams* KParams;
+typedef const __attribute__((address_space(4))) AgtStepTables* KTables;
+
+// The per-frame tables (second kernel argument) are indexed with run-time frame numbers; they are read straight
+// from the kernel-argument segment -- indexing a by-value argument dynamically forces a copy into scratch.
+__device__ __forceinline__ KParams kernarg_params() { return (KParams)__builtin_amdgcn_kernarg_segment_ptr(); }
+__device__ __forceinline__ KTables kernarg_tables()
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    // The per-frame tables (second argument) are indexed with run-time frame numbers; they are read straight
-    // from the kernel-argument segment -- indexing a by-value argument dynamically forces a copy into scratch.
     static_assert(alignof(AgtStepTables) == 8 && alignof(AgtStepParams) == 8, "kernel-argument layout");
-    const __attribute__((address_space(4))) AgtStepParams* KS = (const __attribute__((address_space(4))) AgtStepParams*)__builtin_amdgcn_kernarg_segment_ptr();
-    const __attribute__((address_space(4))) AgtStepTables* KT = (const __attribute__((address_space(4))) AgtStepTables*)(
-        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
-    // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
-    // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
-    int blk = blockIdx.x;
-    if (PNP && blk < S.n_pnp) {
-        if (threadIdx.x >= AGT_WAVE) return;
-        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        // consecutive frames of stream `blk`: frame k+1 starts from the tracker state frame k left in
-        // global memory (written and read by this one wave; the barrier orders the two).  Frames 2.. read
-        // their pointers from an LDS copy of the tables requested up front (see the LK role).
-        static_assert(sizeof(AgtPnpTables) == 24 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
-        if (S.pnp_nf > 1 && threadIdx.x < sizeof(AgtPnpTables) / 4)
-            reinterpret_cast<uint32_t*>(sh.tab)[threadIdx.x] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[threadIdx.x];
-        for (int k = 0; k < S.pnp_nf; k++) {
-            const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
-            if (k) {
-                __syncthreads();
-                img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
-            }
-            agt_pnp::pnp_body<float, 1>(S.pnp, blk, sh, img, mask, so);     // fused path: n <= 64
+    return (KTables)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
+}
+
+// ---- LK role: workgroup `blk` of the role, THREADS threads.  NW = 4: the workgroup is one corner; NW = 1: each wave is
+// its own corner.  Consecutive frames of a corner are tracked in-kernel (position carried in registers).
+template <int WIN, int NW, int NLEV, int THREADS>
+__device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTables& T, KParams KS, KTables KT, int blk, uint8_t* lds)
+{
+    constexpr int CPB = THREADS / (AGT_WAVE * NW);
+    const int wave = threadIdx.x / AGT_WAVE;
+    const long corner = (long)blk * CPB + (NW == 1 ? wave : 0);
+    if (corner >= (long)S.lk.n * S.lk_B) return;
+    const int b = (int)(corner / S.lk.n), pt = (int)(corner - (long)b * S.lk.n);
+    constexpr size_t LKB = sizeof(AgtLkTables);
+    const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(S.lk.max_level + 1) + LKB + 15) & ~(size_t)15;
+    uint8_t* my = lds + (NW == 1 ? (size_t)wave * per : 0);
+    // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: the kernel-
+    // argument segment is host memory, a dependent scalar load from it in the middle of the chain costs a
+    // PCIe round trip.  The copy is requested here, before anything else, and lands while the first frame's
+    // corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
+    AgtLkTables* tab = reinterpret_cast<AgtLkTables*>(my + per - LKB);
+    {
+        const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
+        const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)&KT->lk;
+        if (S.lk_nf > 1) {
+            const uint32_t* gsrc = (const uint32_t*)src;              // vector loads: one per lane, all in flight at once
+            for (int i = tid; i < (int)(LKB / 4); i += AGT_WAVE * NW) reinterpret_cast<uint32_t*>(tab)[i] = gsrc[i];
         }
-        return;
     }
-    if (PNP) blk -= S.n_pnp;
-    if (blk < S.n_lk) {
-        // NW = 4: the workgroup is one corner; NW = 1: each wave is its own corner
-        constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
-        const int wave = threadIdx.x / AGT_WAVE;
-        const long corner = (long)blk * CPB + (NW == 1 ? wave : 0);
-        if (corner >= (long)S.lk.n * S.lk_B) return;
-        const int b = (int)(corner / S.lk.n), pt = (int)(corner - (long)b * S.lk.n);
-        constexpr size_t LKB = sizeof(AgtLkTables);
-        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(S.lk.max_level + 1) + LKB + 15) & ~(size_t)15;
-        uint8_t* my = lds + (NW == 1 ? (size_t)wave * per : 0);
-        // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: the kernel-
-        // argument segment is host memory, a dependent scalar load from it in the middle of the chain costs a
-        // PCIe round trip.  The copy is requested here, before anything else, and lands while the first frame's
-        // corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
-        AgtLkTables* tab = reinterpret_cast<AgtLkTables*>(my + per - LKB);
-        {
-            const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
-            const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)&KT->lk;
-            if (S.lk_nf > 1) {
-                const uint32_t* gsrc = (const uint32_t*)src;              // vector loads: one per lane, all in flight at once
-                for (int i = tid; i < (int)(LKB / 4); i += AGT_WAVE * NW) reinterpret_cast<uint32_t*>(tab)[i] = gsrc[i];
-            }
-        }
-        // consecutive frames of this corner: its position is carried in registers from frame to frame
-        float px = 0.f, py = 0.f; int pst = 1;
-        for (int k = 0; k < S.lk_nf; k++) {
-            agt_lk::LkFrameIo<NLEV> io;
-            io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py; io.pst = pst;
-            if (k == 0) {
+    float px = 0.f, py = 0.f; int pst = 1;
+    for (int k = 0; k < S.lk_nf; k++) {
+        agt_lk::LkFrameIo<NLEV> io;
+        io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py; io.pst = pst;
+        if (k == 0) {
 #pragma unroll
-                for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
-                io.next_pts = T.lk.next[0]; io.status = T.lk.status[0];
-            } else {
-                agt_lk::block_sync<NW>();          // the previous frame's LDS tiles are free again; the table copy is visible
+            for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
+            io.next_pts = T.lk.next[0]; io.status = T.lk.status[0];
+        } else {
+            agt_lk::block_sync<NW>();          // the previous frame's LDS tiles are free again; the table copy is visible
 #pragma unroll
-                for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
-                io.next_pts = tab->next[k]; io.status = tab->status[k];
-            }
-            agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
+            for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
+            io.next_pts = tab->next[k]; io.status = tab->status[k];
         }
-        return;
+        agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
     }
-    blk -= S.n_lk;
-    int base = (PNP ? S.n_pnp : 0) + S.n_lk;  // workgroup index of the stage's first tile
+}
+
+// ---- pyramid role: workgroup `blk` of the role (all stages concatenated); `base` = launch-wide index of the role's first
+// workgroup (decides which XCD a workgroup sits on).  Everything is read from the kernel-argument segment (scalar loads):
+// a reference to the by-value argument would make the compiler copy the whole structure to scratch.
+__device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int base, uint8_t* lds)
+{
 #pragma unroll
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) {
-        if (blk < S.n_pyr[s]) {
-            const AgtPyrArgs& A = S.pyr[s];
+        const int n = KS->n_pyr[s];
+        if (blk < n) {
+            AgtPyrArgs A;
+            A.src = nullptr; A.dst = nullptr; A.pad = 0;
+            A.spitch = KS->pyr[s].spitch; A.sbatch = KS->pyr[s].sbatch; A.dpitch = KS->pyr[s].dpitch; A.dbatch = KS->pyr[s].dbatch;
+            A.sw = KS->pyr[s].sw; A.sh = KS->pyr[s].sh; A.dw = KS->pyr[s].dw; A.dh = KS->pyr[s].dh;
+            A.gx = KS->pyr[s].gx; A.gy = KS->pyr[s].gy; A.B = KS->pyr[s].B;
             // XCD-aware tile order (see agt_pyramid.hip): workgroup index % 8 is the XCD; the stage's
             // workgroups on XCD j take a contiguous run of tiles, runs laid out in XCD order.
-            const int n = S.n_pyr[s];
             const int j = (blk + base) & 7;
             int tile = (blk - ((j - base) & 7)) >> 3;
             for (int q = 0; q < j; q++) tile += (n - ((q - base) & 7) + 7) >> 3;
@@ -118,20 +104,18 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
             agt_pyr::pyr_down_body(A, bx, by, KT->pyr_src[s][fr] + (long)st * A.sbatch, KT->pyr_dst[s][fr] + (long)st * A.dbatch, lds);
             return;
         }
-        blk -= S.n_pyr[s];
-        base += S.n_pyr[s];
+        blk -= n;
+        base += n;
     }
 }
 
-// PnP role alone (split mode: more corners in flight than the fused launch takes; the LK + pyramid roles go out as
-// step_kernel<.., PNP = false> on the caller's stream, this one on a library stream).  PPL: points per lane.
+// ---- PnP role: one wave per stream, consecutive frames: frame k+1 starts from the tracker state frame k left in
+// global memory (written and read by this one wave; the barrier orders the two).  Frames 2.. read their pointers
+// from an LDS copy of the tables requested up front (see the LK role).
 template <int PPL>
-__global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams S, const AgtStepTables T)
+__device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
 {
-    __shared__ agt_pnp::PnpShared sh;
-    const __attribute__((address_space(4))) AgtStepTables* KT = (const __attribute__((address_space(4))) AgtStepTables*)(
-        (const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
-    const int blk = blockIdx.x;
+    static_assert(sizeof(AgtPnpTables) == 24 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
     if (S.pnp_nf > 1 && threadIdx.x < sizeof(AgtPnpTables) / 4)
         reinterpret_cast<uint32_t*>(sh.tab)[threadIdx.x] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[threadIdx.x];
     for (int k = 0; k < S.pnp_nf; k++) {
@@ -144,20 +128,73 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams
     }
 }
 
-// roles: AGT_STEP_ALL = one fused launch; AGT_STEP_X = pyramid + LK roles only (kernel compiled without the FP64 PnP role:
-// the one-wave-per-corner LK keeps its four waves per SIMD); AGT_STEP_Y = the PnP role only
+// One heterogeneous launch: block ranges [PnP | LK | pyr stage 0 | stage 1 | ..].
+// OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).
+template <int WIN, int NW, int NLEV, bool PNP, int OCC>
+__global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void step_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    KParams KS = kernarg_params();
+    KTables KT = kernarg_tables();
+    // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
+    // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
+    int blk = blockIdx.x;
+    if (PNP && blk < S.n_pnp) {
+        if (threadIdx.x >= AGT_WAVE) return;
+        pnp_role<1>(S, T, KT, blk, *reinterpret_cast<agt_pnp::PnpShared*>(lds));     // fused path: n <= 64
+        return;
+    }
+    if (PNP) blk -= S.n_pnp;
+    if (blk < S.n_lk) {
+        lk_role<WIN, NW, NLEV, STEP_THREADS>(S, T, KS, KT, blk, lds);
+        return;
+    }
+    blk -= S.n_lk;
+    pyr_role(KS, KT, blk, (PNP ? S.n_pnp : 0) + S.n_lk, lds);
+}
+
+// ---- split mode (more corners in flight than the fused launch takes): one kernel per role, so that each has its own
+// register allocation, block shape and LDS size.  Same role code, same tables.
+// LK: one corner per workgroup of 64 * NW threads (the shape of the stand-alone lk_kernel; as a role of the 256-thread
+// step_kernel the one-wave-per-corner variant needed 240 B of scratch and ran at half the speed)
+template <int WIN, int NW, int NLEV, int OCC>
+__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_group_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    lk_role<WIN, NW, NLEV, AGT_WAVE * NW>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
+}
+
+__global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    pyr_role(kernarg_params(), kernarg_tables(), blockIdx.x, 0, lds);
+}
+
+// PPL: points per lane (n <= 64 * PPL)
+template <int PPL>
+__global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    __shared__ agt_pnp::PnpShared sh;
+    pnp_role<PPL>(S, T, kernarg_tables(), blockIdx.x, sh);
+}
+
+// roles: AGT_STEP_ALL = one fused launch; AGT_STEP_PYR / AGT_STEP_LK = that role alone, from the kernel compiled without
+// the FP64 PnP role (the one-wave-per-corner LK keeps its four waves per SIMD; each launch sizes its own LDS);
+// AGT_STEP_PNP = the PnP role alone
 template <int WIN, int NW>
 hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int roles)
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
-    if (roles == AGT_STEP_Y) {
+    if (roles == AGT_STEP_PNP) {
         if (P.n_pnp <= 0) return hipSuccess;
         if (P.pnp.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
         else hipLaunchKernelGGL((pnp_group_kernel<agt_pnp::MAX_PPL>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
         return hipGetLastError();
     }
-    if (roles == AGT_STEP_X) { P.n_pnp = 0; P.pnp_nf = 0; }
+    if (!(roles & AGT_STEP_PNP)) { P.n_pnp = 0; P.pnp_nf = 0; }
+    if (!(roles & AGT_STEP_LK)) { P.n_lk = 0; P.lk_nf = 0; }
+    if (!(roles & AGT_STEP_PYR)) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; } }
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only (make dbg): drop roles from the launch to time the others
     { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();
       if (skip & 1) P.n_pnp = 0; if (skip & 2) P.n_lk = 0; if (skip & 4) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.n_pyr[s] = 0; } }
@@ -176,12 +213,19 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (P.n_pnp > 0) { blocks += P.n_pnp; lds = lds > sizeof(agt_pnp::PnpShared) ? lds : sizeof(agt_pnp::PnpShared); }
     if (blocks == 0) return hipSuccess;
     const bool small = P.lk.max_level < 3;
-    if (roles == AGT_STEP_X) {
-        constexpr int OCCX = NW == 1 ? 4 : 1;
-        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, false, OCCX>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, false, OCCX>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    if (roles == AGT_STEP_PYR) {
+        hipLaunchKernelGGL(pyr_group_kernel, dim3(blocks), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, P, T);
         return hipGetLastError();
     }
+    if (roles == AGT_STEP_LK) {
+        constexpr int OCCL = (WIN == 21 && NW == 1) ? 4 : 1;          // as the stand-alone lk_kernel
+        const long corners = (long)P.lk.n * P.lk_B;
+        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(P.lk.max_level + 1) + sizeof(AgtLkTables) + 15) & ~(size_t)15;
+        if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
+        else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
+        return hipGetLastError();
+    }
+    if (roles != AGT_STEP_ALL) return hipErrorInvalidValue;
     // OCC = 1: the FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU,
     // best while <= 256 corners are in flight.  OCC = 2: registers capped at 256 (336 B of scratch for the PnP
     // role), two workgroups per CU: +0.4 us on one stream, but 8 / 32 streams run at 23 / 49 us per step.
@@ -201,7 +245,7 @@ bool agt_step_supported(int win) { return win == 21; }
 // Fused launch (all roles in one kernel) up to 2048 corners in flight, measured on 48-corner streams: 1 / 4 / 8 / 16 /
 // 32 streams take 20 / 22 / 23 / 42 / 49 us per step against 41 / 42 / 46 / 53 / 67 as separate kernels; at 64 streams
 // (94 vs 85) the one-wave-per-corner LK role wants more than the two waves per SIMD the fused launch can hold.
-// (larger batches: the same pipeline in two launches per group, see AGT_STEP_X / AGT_STEP_Y)
+// (larger batches: the same pipeline as one launch per role, see AGT_STEP_PYR / _LK / _PNP)
 bool agt_step_fits(int n, int B)
 {
 #ifdef AGT_DEBUG_KNOBS

@@ -39,7 +39,7 @@ class StreamTracker:
         H.check(self.ctx.L.agt_tracker_options(self.ctx.h, int(reproject), int(min_points), float(gate_px)),
                 "agt_tracker_options")
         self._alive = []            # frames aliased by pyramid level 0 of the ring entries in flight
-        self._keep_frames = max((max_level + 3) + 2, 10)
+        self._keep_frames = max((max_level + 6) + 2, 12)
 
     def _dist_ptr(self):
         return self.dist.ctypes.data_as(C.c_void_p) if self.ndist else None
@@ -64,7 +64,7 @@ class StreamTracker:
         depth = int(depth)
         H.check(self.ctx.L.agt_tracker_pipeline(self.ctx.h, depth), "agt_tracker_pipeline")
         # (big batches run their stage kernels on library-owned streams: a frame is dead 9 calls after it was handed over)
-        self._keep_frames = max((self.ctx.max_level + 3) * max(depth, 1) + 2, 10)
+        self._keep_frames = max((self.ctx.max_level + 6) * max(depth, 1) + 2, 12)
 
     def step(self, frames, state_out=None):
         """frames: cuda u8 [B,H,W] (a reference is kept while the frame is in flight: level 0 of the
