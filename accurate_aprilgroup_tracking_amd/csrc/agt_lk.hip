@@ -1,6 +1,6 @@
 // agt_lk.hip -- stand-alone cv::calcOpticalFlowPyrLK launch (body and design notes: agt_lk_body.h).
 #include <cstdlib>
-#include "agt_lk_body.h"
+#include "agt_lk_rs_body.h"
 
 namespace {
 
@@ -14,6 +14,17 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
     io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
     float ox, oy; int ost;
+    if constexpr (WIN == 21 && NW == 1) {
+        // one wave per corner: the row-segment body (agt_lk_rs_body.h) while the window's derivative footprint stays inside
+        // the image at every level and the corner is alive; the general body otherwise (wave-uniform choice)
+        const long pidx = (long)blockIdx.y * P.n + blockIdx.x;
+        const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
+        const int pst = P.prev_status ? P.prev_status[pidx] : 1;
+        if (agt_uniform((int)(pst != 0 && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)))) {
+            agt_lk::lk_body_rs<NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ppx, ppy, ox, oy, ost);
+            return;
+        }
+    }
     agt_lk::lk_body<WIN, NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ox, oy, ost);
 }
 

@@ -1,0 +1,347 @@
+// agt_lk_rs_body.h -- cv::calcOpticalFlowPyrLK per-point tracker, ONE WAVE PER CORNER, 21x21 window:
+// the throughput kernel of big batches (BASELINE configs[2]: 64 x 1280x720, 3072 corners per step).
+// Same semantics and the same bits as agt_lk_body.h (oracle: oracle/cv_lk.c, CVO_ACC_EXACT); different mapping.
+//
+// Round 1's one-wave kernel gave lane l the window pixels l, l + 64, ... (7 per lane): 28 single-byte LDS reads
+// and ~20 VALU per pixel per iteration, a Scharr tile written to and re-read from LDS per level -- 4,184 VALU and
+// 633 LDS instructions per corner, VALU-issue bound at three to four waves per SIMD.  Here:
+//   * lane l = (row r, segment s) = (l / 3, l % 3) owns the 7 CONSECUTIVE window pixels [7s, 7s + 7) of window row r
+//     (63 lanes; lane 63 idles).  Its two source rows come as three aligned dwords each (6 LDS dword reads per
+//     iteration instead of 28 byte reads), aligned with v_alignbyte_b32;
+//   * the fixed-point bilinear tap  v00*iw00 + v01*iw01 + v10*iw10 + v11*iw11  is two v_dot4_u32_u8: the four bytes
+//     are packed into one register with v_perm_b32 and the 15-bit weights are split into high and low bytes
+//     (sum = 256 * dot4(P, WH) + dot4(P, WL), exact); the rounding constant rides in the accumulator input;
+//   * the I side of a level lives in registers only.  By linearity  sum_ij w_ij * Scharr(I)(x+j, y+i)  =
+//     Scharr(B)(x, y)  with  B = sum_ij w_ij * I(.+j, .+i)  taken WITHOUT rounding (B < 2^22, Scharr(B) < 2^27):
+//     each lane interpolates its 3 x 9 patch of B (27 dot4 pairs) and applies the Scharr taps to it -- no derivative
+//     tile in LDS, no barrier.  Valid while every derivative position of the window lies inside the image (the
+//     derivative image has a ZERO border); corners whose window touches the image border at some level take the
+//     general kernel body (agt_lk_body.h) instead, chosen per corner at entry;
+//   * the exact sums: per-lane partials (< 2^28) are split into 16-bit halves, each half is reduced over the wave in
+//     int32 without overflow (two sums share one DPP chain through v_permlane32_swap), and  hi * 65536 + lo  is formed
+//     in FP64 (exact) and rounded to float once -- the same value as (float)(double)(int64 sum).
+#pragma once
+#include "agt_lk_body.h"
+
+namespace agt_lk {
+
+// byte selectors of v_perm_b32(S0 = next row, S1 = this row): { this[k], this[k+1], next[k], next[k+1] }
+constexpr uint32_t RS_SEL0 = 0x05040100u, RS_SEL1 = 0x06050201u, RS_SEL2 = 0x07060302u;
+
+// 14-bit bilinear weights -> the two byte-packed operands of the dot4 pair.  iw11 = 2^14 - (the three rounded products)
+// can come out as -1 when a * b * 2^14 < 1.5: the packed operands then carry 0 for it and `neg11` (wave-uniform, > 0)
+// tells the caller to subtract neg11 * v11 from every tap (rs_fix_taps; a rare scalar branch).
+__device__ __forceinline__ void rs_pack_weights(int iw00, int iw01, int iw10, int iw11, uint32_t& WL, uint32_t& WH, int& neg11)
+{
+    neg11 = agt_uniform(iw11 < 0 ? -iw11 : 0);
+    iw11 = iw11 < 0 ? 0 : iw11;
+    WL = (uint32_t)(iw00 & 255) | ((uint32_t)(iw01 & 255) << 8) | ((uint32_t)(iw10 & 255) << 16) | ((uint32_t)(iw11 & 255) << 24);
+    WH = (uint32_t)(iw00 >> 8) | ((uint32_t)(iw01 >> 8) << 8) | ((uint32_t)(iw10 >> 8) << 16) | ((uint32_t)(iw11 >> 8) << 24);
+}
+
+// sum of the four taps packed in P, plus `round`
+__device__ __forceinline__ int rs_tap(uint32_t P, uint32_t WL, uint32_t WH, uint32_t round)
+{
+    const uint32_t lo = __builtin_amdgcn_udot4(P, WL, round, false);
+    const uint32_t hi = __builtin_amdgcn_udot4(P, WH, 0u, false);
+    return (int)((hi << 8) + lo);
+}
+
+template <int N>
+__device__ __forceinline__ void rs_fix_taps(int (&raw)[N], const uint32_t (&P)[N], int neg11)
+{
+#pragma unroll
+    for (int k = 0; k < N; k++) raw[k] -= neg11 * (int)(P[k] >> 24);
+}
+
+// N consecutive taps of two rows given as aligned bytes: a0|a1|a2 = bytes 0..11 of the upper row, b0|b1|b2 of the lower
+// one; tap k uses bytes k, k + 1 of both.  N <= 9.
+template <int N>
+__device__ __forceinline__ void rs_pack_taps(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t (&P)[N])
+{
+    P[0] = __builtin_amdgcn_perm(b0, a0, RS_SEL0);
+    if (N > 1) P[1] = __builtin_amdgcn_perm(b0, a0, RS_SEL1);
+    if (N > 2) P[2] = __builtin_amdgcn_perm(b0, a0, RS_SEL2);
+    if (N > 3) {
+        const uint32_t m = __builtin_amdgcn_alignbyte(a1, a0, 3), mu = __builtin_amdgcn_alignbyte(b1, b0, 3);   // bytes 3..6
+        P[3] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
+        if (N > 4) P[4] = __builtin_amdgcn_perm(mu, m, RS_SEL1);
+        if (N > 5) P[5] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
+    }
+    if (N > 6) P[6] = __builtin_amdgcn_perm(b1, a1, RS_SEL2);                                                  // bytes 6, 7
+    if (N > 7) {
+        const uint32_t m = __builtin_amdgcn_alignbyte(a2, a1, 3), mu = __builtin_amdgcn_alignbyte(b2, b1, 3);   // bytes 7..10
+        P[7] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
+        if (N > 8) P[8] = __builtin_amdgcn_perm(mu, m, RS_SEL1);
+    }
+}
+
+// three aligned dwords of an LDS row from byte address `a` on; `sh` = a & 3 is applied by the caller
+__device__ __forceinline__ void rs_row3(const uint8_t* s, int a, uint32_t& d0, uint32_t& d1, uint32_t& d2)
+{
+    const uint32_t* p = reinterpret_cast<const uint32_t*>(s + (a & ~3));
+    d0 = p[0]; d1 = p[1]; d2 = p[2];
+}
+
+// Exact wave sums of two int32 per lane (|v| < 2^28), identical in every lane, as FP64.
+// 16-bit halves; each half: v_permlane32_swap folds { v0 | v1 } into one register (lanes 0-31: pair sums of v0, lanes
+// 32-63: of v1), four DPP row steps, one readlane per 16-lane row.
+__device__ __forceinline__ void rs_wave_sum2(int v0, int v1, double& s0, double& s1)
+{
+    auto chain = [](int a, int b, int& ta, int& tb) {
+        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
+        int x = (int)sw[0] + (int)sw[1];
+        x += agt_dpp_i32<0xB1>(x);
+        x += agt_dpp_i32<0x4E>(x);
+        x += agt_dpp_i32<0x141>(x);
+        x += agt_dpp_i32<0x140>(x);
+        ta = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16);
+        tb = __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
+    };
+    int lo0, lo1, hi0, hi1;
+    chain(v0 & 0xffff, v1 & 0xffff, lo0, lo1);
+    chain(v0 >> 16, v1 >> 16, hi0, hi1);
+    s0 = (double)hi0 * 65536.0 + (double)lo0;
+    s1 = (double)hi1 * 65536.0 + (double)lo1;
+}
+
+// LDS bytes of one corner: the level tiles only (no derivative tile, no reduction slots)
+__host__ __device__ constexpr size_t lk_rs_lds_bytes(int levels) { return (size_t)levels * LkCfg<21, 1>::LEVEL_LDS; }
+
+// true when every derivative position the 21x21 window of `pt` touches lies inside the image at every level
+__device__ __forceinline__ bool rs_interior(float ppx, float ppy, int max_level, int w0, int h0)
+{
+    bool ok = true;
+    int w = w0, h = h0;
+    for (int l = 0; l <= max_level; l++) {
+        const float scale = 1.f / (float)(1 << l);
+        const int ipx = (int)floorf(ppx * scale - 10.f), ipy = (int)floorf(ppy * scale - 10.f);
+        ok = ok && ipx >= 0 && ipx + 21 < w && ipy >= 0 && ipy + 21 < h;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    return ok;
+}
+
+// Track one corner through one frame with ONE wave (all 64 lanes call).  Preconditions checked by the caller:
+// rs_interior(...) holds and the corner's previous status is 1.  lds: lk_rs_lds_bytes, 16-B aligned.
+template <int NLEV, typename PP>
+__device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float ppx, float ppy,
+                                           float& ox, float& oy, int& ost)
+{
+    constexpr int WIN = 21;
+    using C = LkCfg<WIN, 1>;
+    constexpr int T = AGT_WAVE;
+    const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
+    const bool act = lane < 63;
+    const int rr = act ? lane / 3 : 20, ss = act ? lane - rr * 3 : 2;     // window row, segment
+    const long pidx = (long)b * P->n + pt;
+    const float halfw = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+
+    float outx = 0.f, outy = 0.f;
+    if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
+    const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;
+    const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
+
+    // ---- prologue: request every level's tiles before touching any of them
+    {
+        uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            if (l <= P->max_level) {
+                const float scale = 1.f / (float)(1 << l);
+                const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
+                const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+                AgtLevel LI = get_level(P->prev[l]);
+                AgtLevel LJ = get_level(P->next[l]);
+                if (io.grouped) { LI.ptr = io.imgI[l]; LJ.ptr = io.imgJ[l]; }
+                tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, lane, ti[l]);
+                tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, tj[l]);
+            }
+        }
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            if (l <= P->max_level) {
+                tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, lane, ti[l]);
+                tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, lane, tj[l]);
+            }
+        }
+    }
+    block_sync<1>();
+
+    int st = 1;
+    float errv = 0.f;
+
+    for (int level = P->max_level; level >= 0; level--) {
+        AgtLevel LJ = get_level(P->next[level]);
+        if (io.grouped) {
+            const uint8_t* q = io.imgJ[0];
+#pragma unroll
+            for (int l = 1; l < NLEV; l++) q = level == l ? io.imgJ[l] : q;
+            LJ.ptr = q;
+        }
+        const uint8_t* imgJ = LJ.ptr + (long)b * LJ.bstride;
+        const uint8_t* sI = lds + level * C::LEVEL_LDS;
+        uint8_t* sJ = lds + level * C::LEVEL_LDS + C::IW * C::IP;
+        const float scale = 1.f / (float)(1 << level);
+        float prevx = ppx * scale, prevy = ppy * scale;
+        float nextx, nexty;
+        if (level == P->max_level) {
+            if (P->flags & AGT_LK_USE_INITIAL_FLOW) { nextx = outx * scale; nexty = outy * scale; }
+            else { nextx = prevx; nexty = prevy; }
+        } else { nextx = outx * 2.f; nexty = outy * 2.f; }
+        outx = nextx; outy = nexty;
+
+        prevx -= halfw; prevy -= halfw;
+        const int ipx = agt_uniform((int)floorf(prevx)), ipy = agt_uniform((int)floorf(prevy));
+        // (interior by precondition: no bounds test of the I window)
+        int iw00, iw01, iw10, iw11;
+        bilinear_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
+        uint32_t WL, WH;
+        int neg11;
+        rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+
+        // ---- I side in registers: B = un-rounded bilinear interpolation on the lane's 3 x 9 grid (rows rr .. rr+2 of the
+        // B grid = tile rows rr .. rr+3, columns 7 ss .. 7 ss + 9 of the tile shifted by the alignment offset)
+        int Iv[7], Ix[7], Iy[7];
+        {
+            const int offI = (ipx - 1) - ((ipx - 1) & ~3);
+            const int c0 = offI + 7 * ss, sh = c0 & 3;
+            uint32_t e[4][3];                                   // four tile rows, bytes 0..11 from column c0 on
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(sI + (rr + i) * C::IP + (c0 & ~3));
+                const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
+                e[i][0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
+                e[i][1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
+                e[i][2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+            }
+            int Bv[3][9];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                uint32_t Pk[9];
+                rs_pack_taps<9>(e[i][0], e[i][1], e[i][2], e[i + 1][0], e[i + 1][1], e[i + 1][2], Pk);
+#pragma unroll
+                for (int k = 0; k < 9; k++) Bv[i][k] = rs_tap(Pk[k], WL, WH, 0u);
+                if (neg11) rs_fix_taps<9>(Bv[i], Pk, neg11);
+            }
+            int Cs[9], Es[9];                                   // vertical Scharr halves per column
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                Cs[k] = 3 * (Bv[0][k] + Bv[2][k]) + 10 * Bv[1][k];
+                Es[k] = Bv[2][k] - Bv[0][k];
+            }
+#pragma unroll
+            for (int k = 0; k < 7; k++) {
+                const int iv = descale(Bv[1][k + 1], W_BITS - 5);
+                const int ix = descale(Cs[k + 2] - Cs[k], W_BITS);
+                const int iy = descale(3 * (Es[k] + Es[k + 2]) + 10 * Es[k + 1], W_BITS);
+                Iv[k] = iv; Ix[k] = act ? ix : 0; Iy[k] = act ? iy : 0;
+            }
+        }
+        int a11 = 0, a12 = 0, a22 = 0;
+#pragma unroll
+        for (int k = 0; k < 7; k++) { a11 += __mul24(Ix[k], Ix[k]); a12 += __mul24(Ix[k], Iy[k]); a22 += __mul24(Iy[k], Iy[k]); }
+        double sA11, sA12, sA22, sdummy;
+        rs_wave_sum2(a11, a12, sA11, sA12);
+        rs_wave_sum2(a22, 0, sA22, sdummy);
+        const float A11 = (float)sA11 * FLT_SCALE;
+        const float A12 = (float)sA12 * FLT_SCALE;
+        const float A22 = (float)sA22 * FLT_SCALE;
+
+        float D = A11 * A22 - A12 * A12;
+        const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
+        if (P->flags & AGT_LK_GET_MIN_EIGENVALS) errv = minEig;
+        if (agt_uniform((int)((double)minEig < P->min_eig_threshold || D < FLT_EPSILON))) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+
+        nextx -= halfw; nexty -= halfw;
+        float pdx = 0.f, pdy = 0.f;
+        int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+        auto restage_j = [&](int inx, int iny) {
+            jx0 = inx - C::MARGIN; jy0 = iny - C::MARGIN;
+            uint32_t t[C::JLD];
+            block_sync<1>();
+            tile_load<C::JT, C::JNDW, T>(imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, t);
+            tile_store<C::JT, C::JNDW, T>(sJ, lane, t);
+            block_sync<1>();
+        };
+        // the lane's 7 interpolated J pixels (value * 32) at window position (inx, iny), weights in WL / WH
+        auto window_taps = [&](int inx, int iny, int (&Jv)[7]) {
+            const int a = (iny - jy0 + rr) * C::JP + (inx - (jx0 & ~3)) + 7 * ss;
+            const int shj = a & 3;
+            uint32_t d0, d1, d2, f0, f1, f2;
+            rs_row3(sJ, a, d0, d1, d2);
+            rs_row3(sJ, a + C::JP, f0, f1, f2);
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, shj), a1 = __builtin_amdgcn_alignbyte(d2, d1, shj);
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(f1, f0, shj), b1 = __builtin_amdgcn_alignbyte(f2, f1, shj);
+            uint32_t Pk[7];
+            rs_pack_taps<7>(a0, a1, 0u, b0, b1, 0u, Pk);
+#pragma unroll
+            for (int k = 0; k < 7; k++) Jv[k] = rs_tap(Pk[k], WL, WH, 1u << (W_BITS - 5 - 1));
+            if (neg11) rs_fix_taps<7>(Jv, Pk, neg11);
+#pragma unroll
+            for (int k = 0; k < 7; k++) Jv[k] >>= (W_BITS - 5);
+        };
+        for (int j = 0; j < P->max_count; j++) {
+            const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
+            if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
+            bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
+            rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+            int Jv[7];
+            window_taps(inx, iny, Jv);
+            int b1 = 0, b2 = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const int diff = Jv[k] - Iv[k]; b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]); }
+            double sb1, sb2;
+            rs_wave_sum2(b1, b2, sb1, sb2);
+            const float fb1 = (float)sb1 * FLT_SCALE;
+            const float fb2 = (float)sb2 * FLT_SCALE;
+            const float dx = (A12 * fb2 - A22 * fb1) * D;
+            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            nextx += dx; nexty += dy;
+            outx = nextx + halfw; outy = nexty + halfw;
+            if (agt_uniform((int)((double)dx * dx + (double)dy * dy <= P->eps2))) break;
+            if (j > 0 && agt_uniform((int)(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01))) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+
+        if (st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
+            const float npx = outx - halfw, npy = outy - halfw;
+            const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
+            if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) { st = 0; continue; }
+            if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
+            bilinear_weights(npx - (float)inx, npy - (float)iny, iw00, iw01, iw10, iw11);
+            rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+            int Jv[7];
+            window_taps(inx, iny, Jv);
+            int e = 0;
+#pragma unroll
+            for (int k = 0; k < 7; k++) { const int diff = Jv[k] - Iv[k]; e += diff < 0 ? -diff : diff; }
+            e = act ? e : 0;
+            double se, sdum;
+            rs_wave_sum2(e, 0, se, sdum);
+            errv = (float)se * 1.f / (float)(32 * WIN * WIN);
+        }
+    }
+
+    if (lane == 0) {
+        io.next_pts[pidx * 2] = outx;
+        io.next_pts[pidx * 2 + 1] = outy;
+        io.status[pidx] = (uint8_t)st;
+        if (io.err) io.err[pidx] = errv;
+    }
+    ox = outx; oy = outy; ost = st;
+}
+
+}  // namespace agt_lk

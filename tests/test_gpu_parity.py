@@ -136,6 +136,45 @@ def test_lk_large_batch_single_wave_path(torch_cuda, cvh, oracle, seq640):
         _assert_lk_equal(o, (nx[b].reshape(-1, 1, 2), st[b].reshape(-1, 1), er[b].reshape(-1, 1)))
 
 
+def test_lk_edge_cases_single_wave_path(torch_cuda, cvh, oracle, seq640):
+    """the one-wave-per-corner kernel (row-segment body inside the image, general body at the border) on the edge-case
+    set of test_lk_edge_cases: border / outside points, flat regions, every pyramid depth, flags and criteria variants,
+    sub-pixel positions that make the fourth bilinear weight 0 or negative -- bit-exact against the oracle"""
+    torch = torch_cuda
+    a, b = seq640.frame(0), seq640.frame(2)
+    h, w = a.shape
+    rng = np.random.default_rng(5)
+    tiny = np.float32(2.0 ** -11)          # a * b * 2^14 < 1.5: iw11 may round to -1
+    pts = np.concatenate([
+        seq640.corners(0)[:16],
+        np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [-5.5, 10.25], [w + 3.0, 7.0], [3.2, h + 8.9], [-40.0, -40.0],
+                  [w + 30.0, h + 30.0], [10.5, 10.5], [w - 11.0, h - 11.0], [1.0, h / 2.0]], np.float32),
+        seq640.corners(0)[16:32].round() + np.array([[tiny * (1 + i % 5), tiny * (1 + i % 3)] for i in range(16)], np.float32),
+        np.floor(seq640.corners(0)[32:40]) + np.float32(0.5),
+        rng.uniform([-15, -15], [w + 15, h + 15], size=(38, 2)).astype(np.float32)]).astype(np.float32)
+    n = pts.shape[0]
+    B = 1024 // n + 1
+    assert n * B > 1024
+    fa = torch.from_numpy(np.stack([a] * B)).cuda().contiguous(); fb = torch.from_numpy(np.stack([b] * B)).cuda().contiguous()
+    pg = torch.from_numpy(np.stack([pts] * B)).cuda().contiguous()
+    init = pts + rng.normal(0, 1.5, pts.shape).astype(np.float32)
+    for ml in (0, 1, 2, 3, 4):
+        ctx = cvh.Context(w, h, max_level=ml, max_points=n, max_streams=B)
+        ctx.pyramid_build(0, fa); ctx.pyramid_build(1, fb)
+        variants = [dict()] if ml != 2 else [dict(), dict(flags=4, nextPts=init), dict(flags=8), dict(criteria=(1, 5, 0.0)),
+                                             dict(criteria=(2, 0, 0.03)), dict(minEigThreshold=1e-2)]
+        for kw in variants:
+            nxt = None
+            if "nextPts" in kw:
+                nxt = torch.from_numpy(np.stack([kw["nextPts"]] * B)).cuda().contiguous()
+            nx, st, er = ctx.lk_track(0, 1, pg, nxt, criteria=kw.get("criteria", (3, 30, 0.01)), flags=kw.get("flags", 0),
+                                      min_eig_threshold=kw.get("minEigThreshold", 1e-4))
+            nx, st, er = nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+            o = oracle.calcOpticalFlowPyrLK(a, b, pts, maxLevel=ml, **kw)
+            for bb in (0, B - 1):
+                _assert_lk_equal(o, (nx[bb].reshape(-1, 1, 2), st[bb].reshape(-1, 1), er[bb].reshape(-1, 1)))
+
+
 def test_project_points(cvh, oracle, seq640_dist):
     s = seq640_dist
     for dt in (np.float64, np.float32):
