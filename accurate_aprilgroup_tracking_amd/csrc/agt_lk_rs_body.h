@@ -33,7 +33,9 @@ constexpr uint32_t RS_SEL0 = 0x05040100u, RS_SEL1 = 0x06050201u, RS_SEL2 = 0x070
 // tells the caller to subtract neg11 * v11 from every tap (rs_fix_taps; a rare scalar branch).
 __device__ __forceinline__ void rs_pack_weights(int iw00, int iw01, int iw10, int iw11, uint32_t& WL, uint32_t& WH, int& neg11)
 {
-    neg11 = agt_uniform(iw11 < 0 ? -iw11 : 0);
+    // the weights are wave-uniform: packing them is scalar work (and the dot4s take them as SGPR operands)
+    iw00 = agt_uniform(iw00); iw01 = agt_uniform(iw01); iw10 = agt_uniform(iw10); iw11 = agt_uniform(iw11);
+    neg11 = iw11 < 0 ? -iw11 : 0;
     iw11 = iw11 < 0 ? 0 : iw11;
     WL = (uint32_t)(iw00 & 255) | ((uint32_t)(iw01 & 255) << 8) | ((uint32_t)(iw10 & 255) << 16) | ((uint32_t)(iw11 & 255) << 24);
     WH = (uint32_t)(iw00 >> 8) | ((uint32_t)(iw01 >> 8) << 8) | ((uint32_t)(iw10 >> 8) << 16) | ((uint32_t)(iw11 >> 8) << 24);
@@ -83,10 +85,11 @@ __device__ __forceinline__ void rs_row3(const uint8_t* s, int a, uint32_t& d0, u
     d0 = p[0]; d1 = p[1]; d2 = p[2];
 }
 
-// Exact wave sums of two int32 per lane (|v| < 2^28), identical in every lane, as FP64.
+// Exact wave sums of two int32 per lane (|v| < 2^28), identical in every lane, ROUNDED ONCE to float.
 // 16-bit halves; each half: v_permlane32_swap folds { v0 | v1 } into one register (lanes 0-31: pair sums of v0, lanes
-// 32-63: of v1), four DPP row steps, one readlane per 16-lane row.
-__device__ __forceinline__ void rs_wave_sum2(int v0, int v1, double& s0, double& s1)
+// 32-63: of v1), four DPP row steps, one readlane per 16-lane row.  Both half sums are below 2^24 in magnitude, so they are
+// exact as floats and fma(hi, 65536, lo) rounds the exact integer sum once: the value of (float)(double)(int64 sum).
+__device__ __forceinline__ void rs_wave_sum2(int v0, int v1, float& s0, float& s1)
 {
     auto chain = [](int a, int b, int& ta, int& tb) {
         const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
@@ -101,8 +104,8 @@ __device__ __forceinline__ void rs_wave_sum2(int v0, int v1, double& s0, double&
     int lo0, lo1, hi0, hi1;
     chain(v0 & 0xffff, v1 & 0xffff, lo0, lo1);
     chain(v0 >> 16, v1 >> 16, hi0, hi1);
-    s0 = (double)hi0 * 65536.0 + (double)lo0;
-    s1 = (double)hi1 * 65536.0 + (double)lo1;
+    s0 = __builtin_fmaf((float)hi0, 65536.f, (float)lo0);
+    s1 = __builtin_fmaf((float)hi1, 65536.f, (float)lo1);
 }
 
 // LDS bytes of one corner: the level tiles only (no derivative tile, no reduction slots)
@@ -134,20 +137,34 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
     const bool act = lane < 63;
     const int rr = act ? lane / 3 : 20, ss = act ? lane - rr * 3 : 2;     // window row, segment
+    const int lane7s = 7 * ss;
     const long pidx = (long)b * P->n + pt;
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps2_lo = (float)(P->eps2 * (1.0 - 1e-6)), eps2_hi = (float)(P->eps2 * (1.0 + 1e-6));
 
     float outx = 0.f, outy = 0.f;
     if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
     const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;
     const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 
-    // ---- prologue: request every level's tiles before touching any of them
+    // ---- prologue: request every level's tiles before touching any of them.
+    // Fast path (the tile's dword-aligned footprint lies inside the image): buffer loads -- lane (row, dword) offsets
+    // computed once per level, the tile origin rides in the scalar offset, no per-dword address or border arithmetic
+    // (the general loader spends ~25 VALU per dword on indices, reflection and 64-bit addresses: 23 % of this kernel).
     {
+        // lane maps: I tile 24 rows x 7 dwords = 3 loads of 9 rows; J tile 40 rows x 11 dwords = 8 loads of 5 rows
+        const int irow = lane / C::INDW, idw = lane - irow * C::INDW;
+        const int jrow = lane / C::JNDW, jdw = lane - jrow * C::JNDW;
+        constexpr int IR = AGT_WAVE / C::INDW, JR = AGT_WAVE / C::JNDW;          // 9, 5 rows per load
+        constexpr int IK = (C::IW + IR - 1) / IR, JK = (C::JT + JR - 1) / JR;    // 3, 8 loads
+        const bool ion = irow < IR, jon = jrow < JR;
+        uint32_t fi[NLEV][IK], fj[NLEV][JK];
         uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
+        bool fastI[NLEV], fastJ[NLEV];
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
+            fastI[l] = fastJ[l] = false;
             if (l <= P->max_level) {
                 const float scale = 1.f / (float)(1 << l);
                 const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
@@ -155,15 +172,57 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 AgtLevel LI = get_level(P->prev[l]);
                 AgtLevel LJ = get_level(P->next[l]);
                 if (io.grouped) { LI.ptr = io.imgI[l]; LJ.ptr = io.imgJ[l]; }
-                tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, lane, ti[l]);
-                tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, tj[l]);
+                {
+                    const int ax0 = agt_uniform((ipx - 1) & ~3), ty0 = agt_uniform(ipy - 1);
+                    fastI[l] = ax0 >= 0 && ax0 + 4 * C::INDW <= LI.w && ty0 >= 0 && ty0 + C::IW <= LI.h;
+                    if (fastI[l]) {
+                        const int pitch = (int)LI.pitch;
+                        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(LI.ptr + (long)b * LI.bstride), 0, LI.h * pitch, 0x00020000);
+                        const int vo = __mul24(irow, pitch) + 4 * idw;
+#pragma unroll
+                        for (int k = 0; k < IK; k++) {
+                            fi[l][k] = 0;
+                            if (ion && (k * IR + irow) < C::IW)
+                                fi[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * IR) * pitch + ax0, 0);
+                        }
+                    } else {
+                        tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, lane, ti[l]);
+                    }
+                }
+                {
+                    const int ax0 = agt_uniform(jx0 & ~3), ty0 = agt_uniform(jy0);
+                    fastJ[l] = ax0 >= 0 && ax0 + 4 * C::JNDW <= LJ.w && ty0 >= 0 && ty0 + C::JT <= LJ.h;
+                    if (fastJ[l]) {
+                        const int pitch = (int)LJ.pitch;
+                        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(LJ.ptr + (long)b * LJ.bstride), 0, LJ.h * pitch, 0x00020000);
+                        const int vo = __mul24(jrow, pitch) + 4 * jdw;
+#pragma unroll
+                        for (int k = 0; k < JK; k++) {
+                            fj[l][k] = 0;
+                            if (jon && (k * JR + jrow) < C::JT)
+                                fj[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * JR) * pitch + ax0, 0);
+                        }
+                    } else {
+                        tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, tj[l]);
+                    }
+                }
             }
         }
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             if (l <= P->max_level) {
-                tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, lane, ti[l]);
-                tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, lane, tj[l]);
+                uint8_t* sIl = lds + l * C::LEVEL_LDS;
+                uint8_t* sJl = sIl + C::IW * C::IP;
+                if (fastI[l]) {
+#pragma unroll
+                    for (int k = 0; k < IK; k++)
+                        if (ion && (k * IR + irow) < C::IW) *reinterpret_cast<uint32_t*>(sIl + (k * IR + irow) * C::IP + 4 * idw) = fi[l][k];
+                } else tile_store<C::IW, C::INDW, T>(sIl, lane, ti[l]);
+                if (fastJ[l]) {
+#pragma unroll
+                    for (int k = 0; k < JK; k++)
+                        if (jon && (k * JR + jrow) < C::JT) *reinterpret_cast<uint32_t*>(sJl + (k * JR + jrow) * C::JP + 4 * jdw) = fj[l][k];
+                } else tile_store<C::JT, C::JNDW, T>(sJl, lane, tj[l]);
             }
         }
     }
@@ -206,11 +265,11 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         int Iv[7], Ix[7], Iy[7];
         {
             const int offI = (ipx - 1) - ((ipx - 1) & ~3);
-            const int c0 = offI + 7 * ss, sh = c0 & 3;
+            const int c0 = offI + lane7s, sh = c0 & 3;
             uint32_t e[4][3];                                   // four tile rows, bytes 0..11 from column c0 on
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                const uint32_t* p = reinterpret_cast<const uint32_t*>(sI + (rr + i) * C::IP + (c0 & ~3));
+                const uint32_t* p = reinterpret_cast<const uint32_t*>(sI + __mul24(rr + i, C::IP) + (c0 & ~3));
                 const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
                 e[i][0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
                 e[i][1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
@@ -226,28 +285,32 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 if (neg11) rs_fix_taps<9>(Bv[i], Pk, neg11);
             }
             int Cs[9], Es[9];                                   // vertical Scharr halves per column
+            // (3 x as shift-add, 10 x as a 24-bit multiply: B < 2^22, so every operand fits; v_mul_lo_u32 is quarter rate)
 #pragma unroll
             for (int k = 0; k < 9; k++) {
-                Cs[k] = 3 * (Bv[0][k] + Bv[2][k]) + 10 * Bv[1][k];
+                const int t = Bv[0][k] + Bv[2][k];
+                Cs[k] = ((t << 1) + t) + __mul24(10, Bv[1][k]);
                 Es[k] = Bv[2][k] - Bv[0][k];
             }
 #pragma unroll
             for (int k = 0; k < 7; k++) {
-                const int iv = descale(Bv[1][k + 1], W_BITS - 5);
-                const int ix = descale(Cs[k + 2] - Cs[k], W_BITS);
-                const int iy = descale(3 * (Es[k] + Es[k + 2]) + 10 * Es[k + 1], W_BITS);
-                Iv[k] = iv; Ix[k] = act ? ix : 0; Iy[k] = act ? iy : 0;
+                const int t = Es[k] + Es[k + 2];
+                Iv[k] = descale(Bv[1][k + 1], W_BITS - 5);
+                Ix[k] = descale(Cs[k + 2] - Cs[k], W_BITS);
+                Iy[k] = descale(((t << 1) + t) + __mul24(10, Es[k + 1]), W_BITS);
             }
         }
+        // (the idle lane 63 duplicates lane 62: its partial sums are dropped, its patch values are never masked)
         int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
         for (int k = 0; k < 7; k++) { a11 += __mul24(Ix[k], Ix[k]); a12 += __mul24(Ix[k], Iy[k]); a22 += __mul24(Iy[k], Iy[k]); }
-        double sA11, sA12, sA22, sdummy;
+        a11 = act ? a11 : 0; a12 = act ? a12 : 0; a22 = act ? a22 : 0;
+        float sA11, sA12, sA22, sdummy;
         rs_wave_sum2(a11, a12, sA11, sA12);
         rs_wave_sum2(a22, 0, sA22, sdummy);
-        const float A11 = (float)sA11 * FLT_SCALE;
-        const float A12 = (float)sA12 * FLT_SCALE;
-        const float A22 = (float)sA22 * FLT_SCALE;
+        const float A11 = sA11 * FLT_SCALE;
+        const float A12 = sA12 * FLT_SCALE;
+        const float A22 = sA22 * FLT_SCALE;
 
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -269,9 +332,14 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             tile_store<C::JT, C::JNDW, T>(sJ, lane, t);
             block_sync<1>();
         };
-        // the lane's 7 interpolated J pixels (value * 32) at window position (inx, iny), weights in WL / WH
+        // IvS[k] = Iv[k] << 9: floor((raw + 256 - 512 Iv) / 512) = floor((raw + 256) / 512) - Iv, so the subtraction of the patch
+        // value rides in the accumulator input of the low dot4 (mod 2^32) and the arithmetic shift yields the difference directly
+        int IvR[7];
+#pragma unroll
+        for (int k = 0; k < 7; k++) IvR[k] = (1 << (W_BITS - 5 - 1)) - (Iv[k] << (W_BITS - 5));
+        // the lane's 7 temporal differences J - I (values * 32) at window position (inx, iny), weights in WL / WH
         auto window_taps = [&](int inx, int iny, int (&Jv)[7]) {
-            const int a = (iny - jy0 + rr) * C::JP + (inx - (jx0 & ~3)) + 7 * ss;
+            const int a = __mul24(iny - jy0 + rr, C::JP) + (inx - (jx0 & ~3)) + lane7s;
             const int shj = a & 3;
             uint32_t d0, d1, d2, f0, f1, f2;
             rs_row3(sJ, a, d0, d1, d2);
@@ -281,7 +349,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             uint32_t Pk[7];
             rs_pack_taps<7>(a0, a1, 0u, b0, b1, 0u, Pk);
 #pragma unroll
-            for (int k = 0; k < 7; k++) Jv[k] = rs_tap(Pk[k], WL, WH, 1u << (W_BITS - 5 - 1));
+            for (int k = 0; k < 7; k++) Jv[k] = rs_tap(Pk[k], WL, WH, (uint32_t)IvR[k]);
             if (neg11) rs_fix_taps<7>(Jv, Pk, neg11);
 #pragma unroll
             for (int k = 0; k < 7; k++) Jv[k] >>= (W_BITS - 5);
@@ -299,17 +367,24 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             window_taps(inx, iny, Jv);
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { const int diff = Jv[k] - Iv[k]; b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]); }
-            double sb1, sb2;
+            for (int k = 0; k < 7; k++) { const int diff = Jv[k]; b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]); }
+            b1 = act ? b1 : 0; b2 = act ? b2 : 0;
+            float sb1, sb2;
             rs_wave_sum2(b1, b2, sb1, sb2);
-            const float fb1 = (float)sb1 * FLT_SCALE;
-            const float fb2 = (float)sb2 * FLT_SCALE;
+            const float fb1 = sb1 * FLT_SCALE;
+            const float fb2 = sb2 * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nextx += dx; nexty += dy;
             outx = nextx + halfw; outy = nexty + halfw;
-            if (agt_uniform((int)((double)dx * dx + (double)dy * dy <= P->eps2))) break;
-            if (j > 0 && agt_uniform((int)(fabs((double)(dx + pdx)) < 0.01 && fabs((double)(dy + pdy)) < 0.01))) {
+            // OpenCV tests  (double)dx*dx + (double)dy*dy <= eps^2  in FP64; the float sum is within 2e-7 of it, so the
+            // FP64 evaluation is only needed inside a 1e-6 band around the threshold (wave-uniform, rare)
+            const float d2 = dx * dx + dy * dy;
+            bool conv = d2 < eps2_lo;
+            if (!conv && !(d2 > eps2_hi)) conv = (double)dx * dx + (double)dy * dy <= P->eps2;
+            if (agt_uniform((int)conv)) break;
+            // fabs((double)f) < 0.01  <=>  fabsf(f) <= 0.01f  (0.01f is the largest float below 0.01)
+            if (j > 0 && agt_uniform((int)(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f))) {
                 outx -= dx * 0.5f; outy -= dy * 0.5f;
                 break;
             }
@@ -327,11 +402,11 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             window_taps(inx, iny, Jv);
             int e = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { const int diff = Jv[k] - Iv[k]; e += diff < 0 ? -diff : diff; }
+            for (int k = 0; k < 7; k++) { const int diff = Jv[k]; e += diff < 0 ? -diff : diff; }
             e = act ? e : 0;
-            double se, sdum;
+            float se, sdum;
             rs_wave_sum2(e, 0, se, sdum);
-            errv = (float)se * 1.f / (float)(32 * WIN * WIN);
+            errv = se * 1.f / (float)(32 * WIN * WIN);
         }
     }
 
