@@ -108,6 +108,13 @@ __device__ __forceinline__ void rs_wave_sum2(int v0, int v1, float& s0, float& s
     s1 = __builtin_fmaf((float)hi1, 65536.f, (float)lo1);
 }
 
+__device__ __forceinline__ const uint8_t* rs_uniform_ptr(const uint8_t* p)
+{
+    const unsigned long long v = (unsigned long long)p;
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return (const uint8_t*)(((unsigned long long)hi << 32) | lo);
+}
+
 // LDS bytes of one corner: the level tiles only (no derivative tile, no reduction slots)
 __host__ __device__ constexpr size_t lk_rs_lds_bytes(int levels) { return (size_t)levels * LkCfg<21, 1>::LEVEL_LDS; }
 
@@ -171,7 +178,8 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
                 AgtLevel LI = get_level(P->prev[l]);
                 AgtLevel LJ = get_level(P->next[l]);
-                if (io.grouped) { LI.ptr = io.imgI[l]; LJ.ptr = io.imgJ[l]; }
+                // (frames 2.. of a group read their image pointers from an LDS table: uniform, but only provably so after this)
+                if (io.grouped) { LI.ptr = rs_uniform_ptr(io.imgI[l]); LJ.ptr = rs_uniform_ptr(io.imgJ[l]); }
                 {
                     const int ax0 = agt_uniform((ipx - 1) & ~3), ty0 = agt_uniform(ipy - 1);
                     fastI[l] = ax0 >= 0 && ax0 + 4 * C::INDW <= LI.w && ty0 >= 0 && ty0 + C::IW <= LI.h;

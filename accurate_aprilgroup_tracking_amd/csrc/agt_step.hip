@@ -15,7 +15,7 @@
 #include <cstdlib>
 #include <cstddef>
 #include "agt_pyramid_body.h"
-#include "agt_lk_body.h"
+#include "agt_lk_rs_body.h"
 #include "agt_pnp_body.h"
 
 namespace {
@@ -73,6 +73,16 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
 #pragma unroll
             for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
             io.next_pts = tab->next[k]; io.status = tab->status[k];
+        }
+        if constexpr (WIN == 21 && NW == 1) {
+            // one wave per corner: the row-segment body while the window stays inside the image and the corner is alive
+            const long pidx = (long)b * S.lk.n + pt;
+            const float ppx = k ? px : S.lk.prev_pts[pidx * 2], ppy = k ? py : S.lk.prev_pts[pidx * 2 + 1];
+            const int alive = k ? pst : (S.lk.prev_status ? S.lk.prev_status[pidx] : 1);
+            if (agt_uniform((int)(alive != 0 && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h)))) {
+                agt_lk::lk_body_rs<NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
+                continue;
+            }
         }
         agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
     }
