@@ -14,14 +14,14 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
     io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
     float ox, oy; int ost;
-    if constexpr (WIN == 21 && NW == 1) {
+    if constexpr (WIN == 21 && (NW == 1 || NW == 4)) {
         // one wave per corner: the row-segment body (agt_lk_rs_body.h) while the window's derivative footprint stays inside
         // the image at every level and the corner is alive; the general body otherwise (wave-uniform choice)
         const long pidx = (long)blockIdx.y * P.n + blockIdx.x;
         const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
         const int pst = P.prev_status ? P.prev_status[pidx] : 1;
-        if (agt_uniform((int)(pst != 0 && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)))) {
-            agt_lk::lk_body_rs<NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ppx, ppy, ox, oy, ost);
+        if (agt_uniform((int)(pst != 0 && !(P.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)))) {
+            agt_lk::lk_body_rs<NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ppx, ppy, ox, oy, ost);
             return;
         }
     }
@@ -55,8 +55,12 @@ bool agt_lk_wide(int n, int B)
     return (long)n * B <= cap;
 }
 
-hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B)
+hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, int B)
 {
+    AgtLkParams p = p_in;
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_LK_RS=0 keeps every corner on the general body (flag bit 16, internal)
+    { static const int rs = [] { const char* e = getenv("AGT_LK_RS"); return e ? atoi(e) : 1; }(); if (!rs) p.flags |= 0x10000; }
+#endif
     switch (win) {
     // (2 and 8 waves per corner were measured too: 2 loses to 1 on big batches -- 60 vs 42 us at 64 streams --, 8 loses
     // to 4 on small ones -- 19.5 vs 17.8 us)

@@ -132,39 +132,68 @@ __device__ __forceinline__ bool rs_interior(float ppx, float ppy, int max_level,
     return ok;
 }
 
-// Track one corner through one frame with ONE wave (all 64 lanes call).  Preconditions checked by the caller:
-// rs_interior(...) holds and the corner's previous status is 1.  lds: lk_rs_lds_bytes, 16-B aligned.
-template <int NLEV, typename PP>
+// lane -> (window row, segment) maps of the two shapes: one wave per corner (throughput: 7 consecutive pixels per lane,
+// 63 lanes) and four waves per corner (latency: 2 pixels per lane, 231 lanes; the last segment's second pixel is column 21,
+// outside the window, and is masked)
+template <int NW>
+struct RsCfg {
+    static constexpr int PX = NW == 1 ? 7 : 2;              // window pixels per lane
+    static constexpr int SEG = NW == 1 ? 3 : 11;            // segments per window row
+    static constexpr int NLANE = 21 * SEG;                  // active lanes
+    static constexpr int NB = PX + 2;                       // columns of the lane's B grid
+    static constexpr int IDW = (3 + NB + 1 + 3) / 4;        // aligned dwords per I-tile row that cover NB + 1 bytes at any shift
+    static constexpr int JDW = (3 + PX + 1 + 3) / 4;        // ... per J-tile row (PX + 1 bytes)
+    static_assert(NW == 1 || NW == 4, "shapes built: 1 and 4 waves per corner");
+};
+
+// Track one corner through one frame with NW waves (all 64 * NW threads call).  Preconditions checked by the caller:
+// rs_interior(...) holds and the corner's previous status is 1.  lds: lk_lds_bytes<21, NW>, 16-B aligned.
+template <int NW, int NLEV, typename PP>
 __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float ppx, float ppy,
                                            float& ox, float& oy, int& ost)
 {
     constexpr int WIN = 21;
-    using C = LkCfg<WIN, 1>;
-    constexpr int T = AGT_WAVE;
-    const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
-    const bool act = lane < 63;
-    const int rr = act ? lane / 3 : 20, ss = act ? lane - rr * 3 : 2;     // window row, segment
-    const int lane7s = 7 * ss;
+    using C = LkCfg<WIN, NW>;
+    using R = RsCfg<NW>;
+    constexpr int T = AGT_WAVE * NW;
+    constexpr int PX = R::PX, NB = R::NB;
+    const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
+    const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
+    const bool act = tid < R::NLANE;
+    const int rr = act ? tid / R::SEG : 20, ss = act ? tid - rr * R::SEG : R::SEG - 1;     // window row, segment
+    const int x0s = PX * ss;                                                               // first window column of the lane
     const long pidx = (long)b * P->n + pt;
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps2_lo = (float)(P->eps2 * (1.0 - 1e-6)), eps2_hi = (float)(P->eps2 * (1.0 + 1e-6));
+    long long* slots = reinterpret_cast<long long*>(lds + (P->max_level + 1) * C::LEVEL_LDS + ((C::DW * C::DW + 3) & ~3) * sizeof(int));
+    int phase = 0;
 
     float outx = 0.f, outy = 0.f;
     if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
     const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;
     const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 
+    // exact sums over the corner's lanes of two / three partials, rounded once to float
+    auto sum2 = [&](int v0, int v1, float& s0, float& s1) {
+        if constexpr (NW == 1) rs_wave_sum2(v0, v1, s0, s1);
+        else {
+            const int v[2] = { v0, v1 };
+            long long t[2];
+            block_sum_exact<NW, C::SUM_STEPS, 2, C::PAIR_OK>(v, t, slots, phase, wave, lane);
+            s0 = (float)(double)t[0]; s1 = (float)(double)t[1];
+        }
+    };
+
     // ---- prologue: request every level's tiles before touching any of them.
     // Fast path (the tile's dword-aligned footprint lies inside the image): buffer loads -- lane (row, dword) offsets
     // computed once per level, the tile origin rides in the scalar offset, no per-dword address or border arithmetic
-    // (the general loader spends ~25 VALU per dword on indices, reflection and 64-bit addresses: 23 % of this kernel).
+    // (the general loader spends ~25 VALU per dword on indices, reflection and 64-bit addresses).
     {
-        // lane maps: I tile 24 rows x 7 dwords = 3 loads of 9 rows; J tile 40 rows x 11 dwords = 8 loads of 5 rows
-        const int irow = lane / C::INDW, idw = lane - irow * C::INDW;
-        const int jrow = lane / C::JNDW, jdw = lane - jrow * C::JNDW;
-        constexpr int IR = AGT_WAVE / C::INDW, JR = AGT_WAVE / C::JNDW;          // 9, 5 rows per load
-        constexpr int IK = (C::IW + IR - 1) / IR, JK = (C::JT + JR - 1) / JR;    // 3, 8 loads
+        const int irow = tid / C::INDW, idw = tid - irow * C::INDW;
+        const int jrow = tid / C::JNDW, jdw = tid - jrow * C::JNDW;
+        constexpr int IR = T / C::INDW, JR = T / C::JNDW;                        // rows per load (9 / 5 with one wave)
+        constexpr int IK = (C::IW + IR - 1) / IR, JK = (C::JT + JR - 1) / JR;    // loads per tile (3 / 8 with one wave, 1 / 2 with four)
         const bool ion = irow < IR, jon = jrow < JR;
         uint32_t fi[NLEV][IK], fj[NLEV][JK];
         uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
@@ -194,7 +223,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                                 fi[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * IR) * pitch + ax0, 0);
                         }
                     } else {
-                        tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, lane, ti[l]);
+                        tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti[l]);
                     }
                 }
                 {
@@ -211,7 +240,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                                 fj[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * JR) * pitch + ax0, 0);
                         }
                     } else {
-                        tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, tj[l]);
+                        tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj[l]);
                     }
                 }
             }
@@ -225,16 +254,16 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
 #pragma unroll
                     for (int k = 0; k < IK; k++)
                         if (ion && (k * IR + irow) < C::IW) *reinterpret_cast<uint32_t*>(sIl + (k * IR + irow) * C::IP + 4 * idw) = fi[l][k];
-                } else tile_store<C::IW, C::INDW, T>(sIl, lane, ti[l]);
+                } else tile_store<C::IW, C::INDW, T>(sIl, tid, ti[l]);
                 if (fastJ[l]) {
 #pragma unroll
                     for (int k = 0; k < JK; k++)
                         if (jon && (k * JR + jrow) < C::JT) *reinterpret_cast<uint32_t*>(sJl + (k * JR + jrow) * C::JP + 4 * jdw) = fj[l][k];
-                } else tile_store<C::JT, C::JNDW, T>(sJl, lane, tj[l]);
+                } else tile_store<C::JT, C::JNDW, T>(sJl, tid, tj[l]);
             }
         }
     }
-    block_sync<1>();
+    block_sync<NW>();
 
     int st = 1;
     float errv = 0.f;
@@ -268,57 +297,69 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         int neg11;
         rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
 
-        // ---- I side in registers: B = un-rounded bilinear interpolation on the lane's 3 x 9 grid (rows rr .. rr+2 of the
-        // B grid = tile rows rr .. rr+3, columns 7 ss .. 7 ss + 9 of the tile shifted by the alignment offset)
-        int Iv[7], Ix[7], Iy[7];
+        // ---- I side in registers: B = un-rounded bilinear interpolation on the lane's 3 x NB grid (rows rr .. rr+2 of the
+        // B grid = tile rows rr .. rr+3, columns x0s .. x0s + NB of the tile shifted by the alignment offset)
+        int Iv[PX], Ix[PX], Iy[PX];
         {
             const int offI = (ipx - 1) - ((ipx - 1) & ~3);
-            const int c0 = offI + lane7s, sh = c0 & 3;
+            const int c0 = offI + x0s, sh = c0 & 3;
             uint32_t e[4][3];                                   // four tile rows, bytes 0..11 from column c0 on
 #pragma unroll
             for (int i = 0; i < 4; i++) {
                 const uint32_t* p = reinterpret_cast<const uint32_t*>(sI + __mul24(rr + i, C::IP) + (c0 & ~3));
-                const uint32_t q0 = p[0], q1 = p[1], q2 = p[2], q3 = p[3];
-                e[i][0] = __builtin_amdgcn_alignbyte(q1, q0, sh);
-                e[i][1] = __builtin_amdgcn_alignbyte(q2, q1, sh);
-                e[i][2] = __builtin_amdgcn_alignbyte(q3, q2, sh);
+                uint32_t q[4] = { 0, 0, 0, 0 };
+#pragma unroll
+                for (int d = 0; d < R::IDW; d++) q[d] = p[d];
+                e[i][0] = __builtin_amdgcn_alignbyte(q[1], q[0], sh);
+                e[i][1] = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
+                e[i][2] = __builtin_amdgcn_alignbyte(q[3], q[2], sh);
             }
-            int Bv[3][9];
+            int Bv[3][NB];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                uint32_t Pk[9];
-                rs_pack_taps<9>(e[i][0], e[i][1], e[i][2], e[i + 1][0], e[i + 1][1], e[i + 1][2], Pk);
+                uint32_t Pk[NB];
+                rs_pack_taps<NB>(e[i][0], e[i][1], e[i][2], e[i + 1][0], e[i + 1][1], e[i + 1][2], Pk);
 #pragma unroll
-                for (int k = 0; k < 9; k++) Bv[i][k] = rs_tap(Pk[k], WL, WH, 0u);
-                if (neg11) rs_fix_taps<9>(Bv[i], Pk, neg11);
+                for (int k = 0; k < NB; k++) Bv[i][k] = rs_tap(Pk[k], WL, WH, 0u);
+                if (neg11) rs_fix_taps<NB>(Bv[i], Pk, neg11);
             }
-            int Cs[9], Es[9];                                   // vertical Scharr halves per column
+            int Cs[NB], Es[NB];                                 // vertical Scharr halves per column
             // (3 x as shift-add, 10 x as a 24-bit multiply: B < 2^22, so every operand fits; v_mul_lo_u32 is quarter rate)
 #pragma unroll
-            for (int k = 0; k < 9; k++) {
+            for (int k = 0; k < NB; k++) {
                 const int t = Bv[0][k] + Bv[2][k];
                 Cs[k] = ((t << 1) + t) + __mul24(10, Bv[1][k]);
                 Es[k] = Bv[2][k] - Bv[0][k];
             }
 #pragma unroll
-            for (int k = 0; k < 7; k++) {
+            for (int k = 0; k < PX; k++) {
                 const int t = Es[k] + Es[k + 2];
                 Iv[k] = descale(Bv[1][k + 1], W_BITS - 5);
                 Ix[k] = descale(Cs[k + 2] - Cs[k], W_BITS);
                 Iy[k] = descale(((t << 1) + t) + __mul24(10, Es[k + 1]), W_BITS);
             }
+            if constexpr (NW != 1) {                            // the pixel of column 21 (last segment) is not in the window
+                const bool in1 = x0s + 1 < WIN;
+                Ix[PX - 1] = in1 ? Ix[PX - 1] : 0; Iy[PX - 1] = in1 ? Iy[PX - 1] : 0;
+            }
         }
-        // (the idle lane 63 duplicates lane 62: its partial sums are dropped, its patch values are never masked)
+        // (idle lanes duplicate the last active one: their partial sums are dropped, their patch values are never masked)
         int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
-        for (int k = 0; k < 7; k++) { a11 += __mul24(Ix[k], Ix[k]); a12 += __mul24(Ix[k], Iy[k]); a22 += __mul24(Iy[k], Iy[k]); }
+        for (int k = 0; k < PX; k++) { a11 += __mul24(Ix[k], Ix[k]); a12 += __mul24(Ix[k], Iy[k]); a22 += __mul24(Iy[k], Iy[k]); }
         a11 = act ? a11 : 0; a12 = act ? a12 : 0; a22 = act ? a22 : 0;
-        float sA11, sA12, sA22, sdummy;
-        rs_wave_sum2(a11, a12, sA11, sA12);
-        rs_wave_sum2(a22, 0, sA22, sdummy);
-        const float A11 = sA11 * FLT_SCALE;
-        const float A12 = sA12 * FLT_SCALE;
-        const float A22 = sA22 * FLT_SCALE;
+        float A11, A12, A22;
+        if constexpr (NW == 1) {
+            float sdummy;
+            rs_wave_sum2(a11, a12, A11, A12);
+            rs_wave_sum2(a22, 0, A22, sdummy);
+        } else {
+            const int v[3] = { a11, a12, a22 };
+            long long t[3];
+            block_sum_exact<NW, C::SUM_STEPS, 3, C::PAIR_OK>(v, t, slots, phase, wave, lane);
+            A11 = (float)(double)t[0]; A12 = (float)(double)t[1]; A22 = (float)(double)t[2];
+        }
+        A11 *= FLT_SCALE; A12 *= FLT_SCALE; A22 *= FLT_SCALE;
 
         float D = A11 * A22 - A12 * A12;
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
@@ -335,32 +376,34 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         auto restage_j = [&](int inx, int iny) {
             jx0 = inx - C::MARGIN; jy0 = iny - C::MARGIN;
             uint32_t t[C::JLD];
-            block_sync<1>();
-            tile_load<C::JT, C::JNDW, T>(imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, lane, t);
-            tile_store<C::JT, C::JNDW, T>(sJ, lane, t);
-            block_sync<1>();
+            block_sync<NW>();
+            tile_load<C::JT, C::JNDW, T>(imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, t);
+            tile_store<C::JT, C::JNDW, T>(sJ, tid, t);
+            block_sync<NW>();
         };
-        // IvS[k] = Iv[k] << 9: floor((raw + 256 - 512 Iv) / 512) = floor((raw + 256) / 512) - Iv, so the subtraction of the patch
-        // value rides in the accumulator input of the low dot4 (mod 2^32) and the arithmetic shift yields the difference directly
-        int IvR[7];
+        // IvR[k] = 256 - (Iv[k] << 9): floor((raw + 256 - 512 Iv) / 512) = floor((raw + 256) / 512) - Iv, so the subtraction of
+        // the patch value rides in the accumulator input of the low dot4 (mod 2^32) and the arithmetic shift yields the difference
+        int IvR[PX];
 #pragma unroll
-        for (int k = 0; k < 7; k++) IvR[k] = (1 << (W_BITS - 5 - 1)) - (Iv[k] << (W_BITS - 5));
-        // the lane's 7 temporal differences J - I (values * 32) at window position (inx, iny), weights in WL / WH
-        auto window_taps = [&](int inx, int iny, int (&Jv)[7]) {
-            const int a = __mul24(iny - jy0 + rr, C::JP) + (inx - (jx0 & ~3)) + lane7s;
+        for (int k = 0; k < PX; k++) IvR[k] = (1 << (W_BITS - 5 - 1)) - (Iv[k] << (W_BITS - 5));
+        // the lane's temporal differences J - I (values * 32) at window position (inx, iny), weights in WL / WH
+        auto window_taps = [&](int inx, int iny, int (&Jv)[PX]) {
+            const int a = __mul24(iny - jy0 + rr, C::JP) + (inx - (jx0 & ~3)) + x0s;
             const int shj = a & 3;
-            uint32_t d0, d1, d2, f0, f1, f2;
-            rs_row3(sJ, a, d0, d1, d2);
-            rs_row3(sJ, a + C::JP, f0, f1, f2);
-            const uint32_t a0 = __builtin_amdgcn_alignbyte(d1, d0, shj), a1 = __builtin_amdgcn_alignbyte(d2, d1, shj);
-            const uint32_t b0 = __builtin_amdgcn_alignbyte(f1, f0, shj), b1 = __builtin_amdgcn_alignbyte(f2, f1, shj);
-            uint32_t Pk[7];
-            rs_pack_taps<7>(a0, a1, 0u, b0, b1, 0u, Pk);
+            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3));
+            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3) + C::JP);
+            uint32_t d[3] = { 0, 0, 0 }, f[3] = { 0, 0, 0 };
 #pragma unroll
-            for (int k = 0; k < 7; k++) Jv[k] = rs_tap(Pk[k], WL, WH, (uint32_t)IvR[k]);
-            if (neg11) rs_fix_taps<7>(Jv, Pk, neg11);
+            for (int i = 0; i < R::JDW; i++) { d[i] = p0[i]; f[i] = p1[i]; }
+            const uint32_t a0 = __builtin_amdgcn_alignbyte(d[1], d[0], shj), a1 = __builtin_amdgcn_alignbyte(d[2], d[1], shj);
+            const uint32_t b0 = __builtin_amdgcn_alignbyte(f[1], f[0], shj), b1 = __builtin_amdgcn_alignbyte(f[2], f[1], shj);
+            uint32_t Pk[PX];
+            rs_pack_taps<PX>(a0, a1, 0u, b0, b1, 0u, Pk);
 #pragma unroll
-            for (int k = 0; k < 7; k++) Jv[k] >>= (W_BITS - 5);
+            for (int k = 0; k < PX; k++) Jv[k] = rs_tap(Pk[k], WL, WH, (uint32_t)IvR[k]);
+            if (neg11) rs_fix_taps<PX>(Jv, Pk, neg11);
+#pragma unroll
+            for (int k = 0; k < PX; k++) Jv[k] >>= (W_BITS - 5);
         };
         for (int j = 0; j < P->max_count; j++) {
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
@@ -371,14 +414,14 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
             bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
             rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
-            int Jv[7];
+            int Jv[PX];
             window_taps(inx, iny, Jv);
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { const int diff = Jv[k]; b1 += __mul24(diff, Ix[k]); b2 += __mul24(diff, Iy[k]); }
+            for (int k = 0; k < PX; k++) { b1 += __mul24(Jv[k], Ix[k]); b2 += __mul24(Jv[k], Iy[k]); }
             b1 = act ? b1 : 0; b2 = act ? b2 : 0;
             float sb1, sb2;
-            rs_wave_sum2(b1, b2, sb1, sb2);
+            sum2(b1, b2, sb1, sb2);
             const float fb1 = sb1 * FLT_SCALE;
             const float fb2 = sb2 * FLT_SCALE;
             const float dx = (A12 * fb2 - A22 * fb1) * D;
@@ -406,19 +449,22 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
             bilinear_weights(npx - (float)inx, npy - (float)iny, iw00, iw01, iw10, iw11);
             rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
-            int Jv[7];
+            int Jv[PX];
             window_taps(inx, iny, Jv);
             int e = 0;
 #pragma unroll
-            for (int k = 0; k < 7; k++) { const int diff = Jv[k]; e += diff < 0 ? -diff : diff; }
+            for (int k = 0; k < PX; k++) {
+                const int diff = Jv[k], ad = diff < 0 ? -diff : diff;
+                e += (NW == 1 || x0s + k < WIN) ? ad : 0;
+            }
             e = act ? e : 0;
             float se, sdum;
-            rs_wave_sum2(e, 0, se, sdum);
+            sum2(e, 0, se, sdum);
             errv = se * 1.f / (float)(32 * WIN * WIN);
         }
     }
 
-    if (lane == 0) {
+    if (tid == 0) {
         io.next_pts[pidx * 2] = outx;
         io.next_pts[pidx * 2 + 1] = outy;
         io.status[pidx] = (uint8_t)st;

@@ -18,6 +18,29 @@
 #include "agt_lk_rs_body.h"
 #include "agt_pnp_body.h"
 
+// Role timeline of the fused step (diagnostic build only, -DAGT_STEP_STAMPS; tools/stepstamps.py): s_memtime at entry and
+// exit of the PnP block, of the first LK block and the latest exit of any LK / pyramid block.
+#ifdef AGT_STEP_STAMPS
+__device__ unsigned long long agt_step_stamps[16];
+#define SSTAMP_SET(i) do { if (threadIdx.x == 0) agt_step_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+#define SSTAMP_MAX(i) do { if (threadIdx.x == 0) atomicMax(&agt_step_stamps[i], (unsigned long long)__builtin_amdgcn_s_memtime()); } while (0)
+#define SSTAMP_MIN(i) do { if (threadIdx.x == 0) atomicMin(&agt_step_stamps[i], (unsigned long long)__builtin_amdgcn_s_memtime()); } while (0)
+extern "C" int agt_debug_step_stamps(unsigned long long* host16, int reset)
+{
+    int rc = (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(agt_step_stamps), sizeof(agt_step_stamps));
+    if (reset) {
+        unsigned long long z[16];
+        for (int i = 0; i < 16; i++) z[i] = (i == 6) ? ~0ull : 0ull;
+        rc |= (int)hipMemcpyToSymbol(HIP_SYMBOL(agt_step_stamps), z, sizeof(z));
+    }
+    return rc;
+}
+#else
+#define SSTAMP_SET(i)
+#define SSTAMP_MAX(i)
+#define SSTAMP_MIN(i)
+#endif
+
 namespace {
 
 constexpr int STEP_THREADS = 256;
@@ -76,11 +99,13 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         }
         if constexpr (WIN == 21 && NW == 1) {
             // one wave per corner: the row-segment body while the window stays inside the image and the corner is alive
+            // (with four waves per corner the general body is kept here: inside this kernel the row-segment form measured
+            // 16.7 us per frame against 15.9, although it wins by 2.5 us as the stand-alone lk_kernel)
             const long pidx = (long)b * S.lk.n + pt;
             const float ppx = k ? px : S.lk.prev_pts[pidx * 2], ppy = k ? py : S.lk.prev_pts[pidx * 2 + 1];
             const int alive = k ? pst : (S.lk.prev_status ? S.lk.prev_status[pidx] : 1);
-            if (agt_uniform((int)(alive != 0 && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h)))) {
-                agt_lk::lk_body_rs<NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
+            if (agt_uniform((int)(alive != 0 && !(S.lk.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h)))) {
+                agt_lk::lk_body_rs<NW, NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
                 continue;
             }
         }
@@ -149,18 +174,25 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
     // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
     // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
     int blk = blockIdx.x;
+    SSTAMP_MIN(6);                                   // earliest entry of any block
     if (PNP && blk < S.n_pnp) {
         if (threadIdx.x >= AGT_WAVE) return;
+        if (blk == 0) SSTAMP_SET(0);
         pnp_role<1>(S, T, KT, blk, *reinterpret_cast<agt_pnp::PnpShared*>(lds));     // fused path: n <= 64
+        if (blk == 0) SSTAMP_SET(1);
         return;
     }
     if (PNP) blk -= S.n_pnp;
     if (blk < S.n_lk) {
+        if (blk == 0) SSTAMP_SET(2);
         lk_role<WIN, NW, NLEV, STEP_THREADS>(S, T, KS, KT, blk, lds);
+        if (blk == 0) SSTAMP_SET(3);
+        SSTAMP_MAX(4);
         return;
     }
     blk -= S.n_lk;
     pyr_role(KS, KT, blk, (PNP ? S.n_pnp : 0) + S.n_lk, lds);
+    SSTAMP_MAX(5);
 }
 
 // ---- split mode (more corners in flight than the fused launch takes): one kernel per role, so that each has its own
@@ -205,6 +237,9 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (!(roles & AGT_STEP_PNP)) { P.n_pnp = 0; P.pnp_nf = 0; }
     if (!(roles & AGT_STEP_LK)) { P.n_lk = 0; P.lk_nf = 0; }
     if (!(roles & AGT_STEP_PYR)) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; } }
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_LK_RS=0 keeps every corner on the general LK body
+    { static const int rs = [] { const char* e = getenv("AGT_LK_RS"); return e ? atoi(e) : 1; }(); if (!rs) P.lk.flags |= 0x10000; }
+#endif
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only (make dbg): drop roles from the launch to time the others
     { static const int skip = [] { const char* e = getenv("AGT_STEP_SKIP"); return e ? atoi(e) : 0; }();
       if (skip & 1) P.n_pnp = 0; if (skip & 2) P.n_lk = 0; if (skip & 4) { for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.n_pyr[s] = 0; } }
