@@ -264,7 +264,17 @@ static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint
     if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
-    for (int l = 1; l <= c->eff_max_level; l++) {
+    int l0 = 1;
+    if (c->eff_max_level >= 2) {
+        // levels 1 and 2 in one pass: level 0 is read once, level 1 is never re-read from HBM
+        const long db1 = (long)c->lh[1] * c->lpitch[1], db2 = (long)c->lh[2] * c->lpitch[2];
+        hipError_t e = agt_launch_pyr_down2(stream, src, c->lw[0], c->lh[0], sp, sb, c->lmem[slot][1], c->lpitch[1], db1,
+                                            c->lmem[slot][2], c->lpitch[2], db2, B);
+        if (e != hipSuccess) return hip_fail(c, e);
+        src = c->lmem[slot][2]; sp = c->lpitch[2]; sb = db2;
+        l0 = 3;
+    }
+    for (int l = l0; l <= c->eff_max_level; l++) {
         const long db = (long)c->lh[l] * c->lpitch[l];
         hipError_t e = agt_launch_pyr_down(stream, src, c->lw[l - 1], c->lh[l - 1], sp, sb, c->lmem[slot][l], c->lpitch[l], db, B);
         if (e != hipSuccess) return hip_fail(c, e);
@@ -498,7 +508,10 @@ static int launch_group(agt_ctx* c, int B)
     const long lk_before = c->n_lk;
     long lk_f0 = 0;                              // LK role: the frame before its group
     bool any = false;
+    const bool fused = L >= 2;                    // stage 0 builds levels 1 and 2 in one pass; stage 1 only keeps the books
+    S.pyr_fused = fused ? 1 : 0;
     for (int s = 0; s < L; s++) {
+        if (fused && s == 1) continue;
         long cnt = done_before[s] - c->n_stage[s];
         if (cnt <= 0) continue;
         if (cnt > F) cnt = F;
@@ -522,6 +535,17 @@ static int launch_group(agt_ctx* c, int B)
             T.pyr_dst[s][k] = c->lmem[slot][s + 1];
         }
         A.src = T.pyr_src[s][0]; A.dst = T.pyr_dst[s][0];
+        if (fused && s == 0) {
+            // the level 1 -> 2 geometry and buffers ride in stage 1's slots; the pass's tile grid (64 x 16 tiles of level 2) in A
+            AgtPyrArgs& A1 = S.pyr[1];
+            A1.sw = c->lw[1]; A1.sh = c->lh[1]; A1.dw = c->lw[2]; A1.dh = c->lh[2];
+            A1.spitch = c->lpitch[1]; A1.sbatch = (long)c->lh[1] * c->lpitch[1];
+            A1.dpitch = c->lpitch[2]; A1.dbatch = (long)c->lh[2] * c->lpitch[2];
+            agt_pyr2_grid(A1.dw, A1.dh, &A.gx, &A.gy);
+            A1.gx = A.gx; A1.gy = A.gy; A1.B = B;
+            for (long k = 0; k < cnt; k++) T.pyr_dst[1][k] = c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
+            c->n_stage[1] += cnt;                // (same frames: level 2 is complete when level 1 is)
+        }
         S.pyr_nf[s] = (int)cnt;
         S.n_pyr[s] = A.gx * A.gy * B * (int)cnt;
         c->n_stage[s] += cnt;

@@ -92,6 +92,8 @@ struct AgtTrackState {
 // chains are serial across frames; the pyramid stages treat the frames as a batch)
 struct AgtStepParams {
     AgtPyrArgs pyr[AGT_MAX_LEVELS - 1];                        // geometry; src / dst per frame in AgtStepTables
+    int pyr_fused;                    // != 0: stage 0 builds levels 1 AND 2 in one pass (pyr[0].gx / gy = its tile grid, pyr[1] =
+    int pyr_pad;                      // the level 1 -> 2 geometry, pyr_dst[1] = the level-2 buffers); stage 1 then has no blocks
     int pyr_nf[AGT_MAX_LEVELS - 1];
     int n_pyr[AGT_MAX_LEVELS - 1];    // blocks of each pyramid stage = tiles x streams x frames (0 = stage idle)
     AgtLkParams lk;                   // geometry of prev[] / next[], criteria; images per frame in AgtStepTables
@@ -131,6 +133,10 @@ struct AgtProjParams {
 };
 
 void agt_pyr_grid(int dw, int dh, int* gx, int* gy);
+void agt_pyr2_grid(int w2, int h2, int* gx, int* gy);           // tile grid of the two-level pass (64 x 16 tiles of L2)
+int agt_pyr2_lds_bytes(void);
+hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
+                                uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B);
 hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
                                uint8_t* dst, long dpitch, long dbatch, int B);
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B);

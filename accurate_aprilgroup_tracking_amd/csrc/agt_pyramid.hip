@@ -1,7 +1,7 @@
 // agt_pyramid.hip -- stand-alone cv::pyrDown launch (body: agt_pyramid_body.h).
 // Replaces the pyramid build inside cv.calcOpticalFlowPyrLK (north-star step).
 // Algorithmic bytes per launch: sw*sh read + dw*dh written (per image).
-#include "agt_pyramid_body.h"
+#include "agt_pyramid2_body.h"
 
 namespace {
 
@@ -21,7 +21,45 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs 
     agt_pyr::pyr_down_body(A, r - by * A.gx, by, A.src + (long)bz * A.sbatch, A.dst + (long)bz * A.dbatch, lds);
 }
 
+// two levels per pass (agt_pyramid2_body.h): same XCD-aware tile order, tiles of 64 x 16 L2 pixels
+__global__ __launch_bounds__(agt_pyr::NT) void pyr_down2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int per_img = A0.gx * A0.gy;
+    if (t >= per_img * A0.B) return;
+    const int bz = t / per_img, r = t - bz * per_img;
+    const int by = r / A0.gx;
+    agt_pyr2::pyr_down2_body(A0, A1, r - by * A0.gx, by, A0.src + (long)bz * A0.sbatch, A0.dst + (long)bz * A0.dbatch,
+                             A1.dst + (long)bz * A1.dbatch, lds);
+}
+
 }  // namespace
+
+void agt_pyr2_grid(int w2, int h2, int* gx, int* gy)
+{
+    *gx = (w2 + agt_pyr2::TW2 - 1) / agt_pyr2::TW2;
+    *gy = (h2 + agt_pyr2::TH2 - 1) / agt_pyr2::TH2;
+}
+int agt_pyr2_lds_bytes(void) { return agt_pyr2::PYR2_LDS_BYTES; }
+
+// src (sw x sh) -> dst1 ((sw+1)/2 x (sh+1)/2) -> dst2, both written, one launch
+hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
+                                uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B)
+{
+    AgtPyrArgs A0, A1;
+    A0.src = src; A0.sw = sw; A0.sh = sh; A0.spitch = spitch; A0.sbatch = sbatch;
+    A0.dst = dst1; A0.dw = (sw + 1) / 2; A0.dh = (sh + 1) / 2; A0.dpitch = dpitch1; A0.dbatch = dbatch1;
+    A1.src = dst1; A1.sw = A0.dw; A1.sh = A0.dh; A1.spitch = dpitch1; A1.sbatch = dbatch1;
+    A1.dst = dst2; A1.dw = (A0.dw + 1) / 2; A1.dh = (A0.dh + 1) / 2; A1.dpitch = dpitch2; A1.dbatch = dbatch2;
+    agt_pyr2_grid(A1.dw, A1.dh, &A0.gx, &A0.gy);              // the tile grid of the pass rides in A0
+    A1.gx = A0.gx; A1.gy = A0.gy;
+    A0.B = A1.B = B; A0.pad = A1.pad = 0;
+    const long tiles = (long)A0.gx * A0.gy * B;
+    hipLaunchKernelGGL(pyr_down2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr2::PYR2_LDS_BYTES, stream, A0, A1);
+    return hipGetLastError();
+}
 
 void agt_pyr_grid(int dw, int dh, int* gx, int* gy)
 {

@@ -54,6 +54,40 @@ __device__ __noinline__ uint4 load_chunk_reflect(const uint8_t* __restrict__ row
     return make_uint4(v[0], v[1], v[2], v[3]);
 }
 
+// eight horizontal [1 4 6 4 1] sums (u16) from 16 source bytes d (output o centred at byte 2 o), the 4 bytes before (pm)
+// and the 4 bytes after (nx): one v_dot4_u32_u8 per output
+__device__ __forceinline__ uint4 hgroup8(uint4 d, uint32_t pm, uint32_t nx)
+{
+    const uint32_t W4 = 0x04060401u;                                      // taps c-2, c-1, c, c+1
+    // even outputs start two bytes before an aligned dword, odd outputs on one
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(d.x, pm, 2), e2 = __builtin_amdgcn_alignbyte(d.y, d.x, 2);
+    const uint32_t e4 = __builtin_amdgcn_alignbyte(d.z, d.y, 2), e6 = __builtin_amdgcn_alignbyte(d.w, d.z, 2);
+    const uint32_t h0 = __builtin_amdgcn_udot4(e0, W4, (d.x >> 16) & 0xff, false);     // fifth tap: byte 2
+    const uint32_t h1 = __builtin_amdgcn_udot4(d.x, W4, d.y & 0xff, false);            // byte 4
+    const uint32_t h2 = __builtin_amdgcn_udot4(e2, W4, (d.y >> 16) & 0xff, false);     // byte 6
+    const uint32_t h3 = __builtin_amdgcn_udot4(d.y, W4, d.z & 0xff, false);            // byte 8
+    const uint32_t h4 = __builtin_amdgcn_udot4(e4, W4, (d.z >> 16) & 0xff, false);     // byte 10
+    const uint32_t h5 = __builtin_amdgcn_udot4(d.z, W4, d.w & 0xff, false);            // byte 12
+    const uint32_t h6 = __builtin_amdgcn_udot4(e6, W4, (d.w >> 16) & 0xff, false);     // byte 14
+    const uint32_t h7 = __builtin_amdgcn_udot4(d.w, W4, nx & 0xff, false);             // byte 16
+    return make_uint4(h0 | (h1 << 16), h2 | (h3 << 16), h4 | (h5 << 16), h6 | (h7 << 16));
+}
+
+// eight vertical [1 4 6 4 1] sums + (v + 128) >> 8 from five rows of eight u16 each -> eight bytes (packed 16-bit math)
+__device__ __forceinline__ uint2 vgroup8(uint4 r0, uint4 r1, uint4 r2, uint4 r3, uint4 r4)
+{
+    const uint32_t K4 = 0x00040004u, K6 = 0x00060006u, K128 = 0x00800080u;
+    auto col = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4) -> uint32_t {
+        uint32_t v = pk_mad(pk_add(a1, a3), K4, pk_add(a0, a4));
+        v = pk_mad(a2, K6, v);
+        return pk_shr8(pk_add(v, K128));                                 // two results, one per 16-bit half
+    };
+    const uint32_t p0 = col(r0.x, r1.x, r2.x, r3.x, r4.x), p1 = col(r0.y, r1.y, r2.y, r3.y, r4.y);
+    const uint32_t p2 = col(r0.z, r1.z, r2.z, r3.z, r4.z), p3 = col(r0.w, r1.w, r2.w, r3.w, r4.w);
+    // gather the low byte of each half: (p.lo, p.hi, q.lo, q.hi) -> one dword
+    return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x06040200u), __builtin_amdgcn_perm(p3, p2, 0x06040200u));
+}
+
 // one 128x16 output tile (bx, by) of the image at `img` -> `out`.  lds: PYR_LDS_BYTES, 16-B aligned
 __device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int by, const uint8_t* __restrict__ img,
                                               uint8_t* __restrict__ out, uint8_t* lds)

@@ -14,7 +14,7 @@
 #undef AGT_PNP_STAMPS
 #include <cstdlib>
 #include <cstddef>
-#include "agt_pyramid_body.h"
+#include "agt_pyramid2_body.h"
 #include "agt_lk_rs_body.h"
 #include "agt_pnp_body.h"
 
@@ -136,6 +136,17 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
             const int bz = tile / per_img, r = tile - bz * per_img;      // bz = frame * B + stream
             const int by = r / A.gx, bx = r - by * A.gx;
             const int fr = bz / A.B, st = bz - fr * A.B;
+            if (s == 0 && KS->pyr_fused) {
+                // levels 1 and 2 in one pass (agt_pyramid2_body.h); the level 1 -> 2 geometry sits in pyr[1]
+                AgtPyrArgs A1;
+                A1.src = nullptr; A1.dst = nullptr; A1.pad = 0;
+                A1.spitch = KS->pyr[1].spitch; A1.sbatch = KS->pyr[1].sbatch; A1.dpitch = KS->pyr[1].dpitch; A1.dbatch = KS->pyr[1].dbatch;
+                A1.sw = KS->pyr[1].sw; A1.sh = KS->pyr[1].sh; A1.dw = KS->pyr[1].dw; A1.dh = KS->pyr[1].dh;
+                A1.gx = A.gx; A1.gy = A.gy; A1.B = A.B;
+                agt_pyr2::pyr_down2_body(A, A1, bx, by, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
+                                         KT->pyr_dst[1][fr] + (long)st * A1.dbatch, lds);
+                return;
+            }
             agt_pyr::pyr_down_body(A, bx, by, KT->pyr_src[s][fr] + (long)st * A.sbatch, KT->pyr_dst[s][fr] + (long)st * A.dbatch, lds);
             return;
         }
@@ -246,7 +257,8 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 #endif
     size_t lds = 0;
     int blocks = 0;
-    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) if (P.n_pyr[s] > 0) { blocks += P.n_pyr[s]; lds = lds > (size_t)agt_pyr::PYR_LDS_BYTES ? lds : (size_t)agt_pyr::PYR_LDS_BYTES; }
+    const size_t pyr_lds = P.pyr_fused ? (size_t)agt_pyr2::PYR2_LDS_BYTES : (size_t)agt_pyr::PYR_LDS_BYTES;
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) if (P.n_pyr[s] > 0) { blocks += P.n_pyr[s]; lds = lds > pyr_lds ? lds : pyr_lds; }
     if (P.n_lk > 0) {
         const long corners = (long)P.lk.n * P.lk_B;
         P.n_lk = (int)((corners + CPB - 1) / CPB);
@@ -259,7 +271,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (blocks == 0) return hipSuccess;
     const bool small = P.lk.max_level < 3;
     if (roles == AGT_STEP_PYR) {
-        hipLaunchKernelGGL(pyr_group_kernel, dim3(blocks), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, P, T);
+        hipLaunchKernelGGL(pyr_group_kernel, dim3(blocks), dim3(agt_pyr::NT), pyr_lds, stream, P, T);
         return hipGetLastError();
     }
     if (roles == AGT_STEP_LK) {

@@ -103,6 +103,19 @@ class Context:
                 "agt_pyramid_build")
         self._keep[slot] = frames
 
+    def pyramid_level(self, slot, level):
+        """copy of one level of a built slot: numpy uint8 [B, h_l, w_l] (tests)"""
+        p, w, h, pitch, bs = C.c_void_p(), C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
+        H.check(self.L.agt_pyramid_level(self.h, slot, level, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch), C.byref(bs)),
+                "agt_pyramid_level")
+        B = self._keep[slot].shape[0]
+        self.synchronize()
+        raw = torch.empty(((B - 1) * bs.value + h.value * pitch.value,), dtype=torch.uint8, device="cuda")
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(C.c_void_p(raw.data_ptr()), p, C.c_size_t(raw.numel()), 3) == 0
+        raw = raw.cpu().numpy()
+        return np.stack([np.lib.stride_tricks.as_strided(raw[b * bs.value:], (h.value, w.value), (pitch.value, 1)).copy() for b in range(B)])
+
     # ---- frame pre-processing (detect_pose.py:147-183, :602)
     def undistort_init(self, K, dist, newK, width, height):
         """Build the CV_16SC2 undistortion maps for this camera on the device (once per camera)."""

@@ -61,6 +61,33 @@ def _assert_lk_equal(o, g):
     assert np.array_equal(o[2].view(np.uint32), g[2].view(np.uint32)), "err not bit-identical"
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (1080, 1920), (97, 131), (200, 260), (150, 516), (257, 95), (131, 1030)])
+def test_pyramid_build_all_levels_bit_exact(torch_cuda, cvh, oracle, shape):
+    """agt_pyramid_build: levels 1 and 2 come from the two-level pass (L0 read once, L1 never re-read), deeper levels from
+    single passes; every level of every stream must equal pyrDown applied level by level -- tile seams, image edges at
+    sizes that are not multiples of the tile, odd sizes (where pyrDown's reflection of L1 differs from filtering reflected
+    L0), unaligned pitches"""
+    torch = torch_cuda
+    h, w = shape
+    rng = np.random.default_rng(h * 7 + w)
+    B = 2
+    img = rng.integers(0, 256, size=(B, h, w), dtype=np.uint8)
+    for pad in (0, 4):                                  # pitch = w rounded to 4 (+4): multiples of 16 and not
+        wp = ((w + 3) & ~3) + pad
+        d = torch.zeros((B, h, wp), dtype=torch.uint8, device="cuda")
+        d[:, :, :w] = torch.from_numpy(img).cuda()
+        ctx = cvh.Context(w, h, max_level=4, max_points=8, max_streams=B)
+        ctx.pyramid_build(1, d[:, :, :w])
+        L = ctx.eff_max_level
+        assert L >= 2
+        for b in range(B):
+            ref = img[b]
+            for l in range(1, L + 1):
+                ref = oracle.pyrDown(ref)
+                got = ctx.pyramid_level(1, l)[b]
+                assert got.shape == ref.shape and np.array_equal(got, ref), "level %d, stream %d, pad %d" % (l, b, pad)
+
+
 def test_lk_bit_exact_640(cvh, oracle, seq640):
     for k in range(3):
         o, g = _lk_both(cvh, oracle, seq640.frame(k), seq640.frame(k + 1), seq640.corners(k), maxLevel=2)
