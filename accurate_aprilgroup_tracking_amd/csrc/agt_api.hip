@@ -9,6 +9,10 @@
 
 #define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
 #define AGT_RING_MAX 64          // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
+// The two-level pyramid pass saves a launch / pipeline stage and 16 % of the pyramid's HBM bytes, but its 41 KB workgroups
+// (3 per CU, eight barriers per tile) stream at 2.5 TB/s against 3.9 + 3.4 TB/s for two single-level passes (8 per CU): it is
+// used where the stage count matters (few streams), the two passes where throughput does (measured at 64 x 720p: 30.5 vs 25 us).
+#define AGT_PYR2_MAX_B 8
 #define AGT_SPLIT_SLACK 2        // split mode: groups of extra ring entries (pyramid launches run that far ahead of LK)
 
 struct agt_ctx {
@@ -265,7 +269,7 @@ static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
     int l0 = 1;
-    if (c->eff_max_level >= 2) {
+    if (c->eff_max_level >= 2 && B <= AGT_PYR2_MAX_B) {
         // levels 1 and 2 in one pass: level 0 is read once, level 1 is never re-read from HBM
         const long db1 = (long)c->lh[1] * c->lpitch[1], db2 = (long)c->lh[2] * c->lpitch[2];
         hipError_t e = agt_launch_pyr_down2(stream, src, c->lw[0], c->lh[0], sp, sb, c->lmem[slot][1], c->lpitch[1], db1,
@@ -508,7 +512,8 @@ static int launch_group(agt_ctx* c, int B)
     const long lk_before = c->n_lk;
     long lk_f0 = 0;                              // LK role: the frame before its group
     bool any = false;
-    const bool fused = L >= 2;                    // stage 0 builds levels 1 and 2 in one pass; stage 1 only keeps the books
+    // stage 0 builds levels 1 and 2 in one pass (stage 1 then only keeps the books) while the batch is small
+    const bool fused = L >= 2 && B <= AGT_PYR2_MAX_B;
     S.pyr_fused = fused ? 1 : 0;
     for (int s = 0; s < L; s++) {
         if (fused && s == 1) continue;

@@ -21,7 +21,10 @@ namespace agt_pyr2 {
 
 using namespace agt_pyr;
 
-constexpr int TW2 = 64, TH2 = 16;            // L2 tile
+#ifndef AGT_PYR2_TH2
+#define AGT_PYR2_TH2 16
+#endif
+constexpr int TW2 = 64, TH2 = AGT_PYR2_TH2;  // L2 tile
 constexpr int R1 = 2 * TH2 + 3;              // 35 extended L1 rows
 constexpr int SHF = 2 * R1 + 3;              // 73 staged L0 rows
 constexpr int HP1 = 272;                     // plane 1 pitch: 128 u16 (groups) + 3 u16 (halo columns) + pad
@@ -54,9 +57,10 @@ __device__ __forceinline__ void pyr_down2_body(const AgtPyrArgs& A0, const AgtPy
         const bool lane_on = tid < 14 * NCH;
         const bool inside = aligned16 && gx >= 0 && gx + 15 < sw;
         const bool outside = gx + 15 < 0 || gx >= sw;      // not fetched: the <= 2 halo bytes the filter reads there are patched below
-        uint4 v[6];
+        constexpr int NR = (SHF + 13) / 14;
+        uint4 v[NR];
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < NR; k++) {
             const int r = r0 + 14 * k;
             v[k] = make_uint4(0, 0, 0, 0);
             if (lane_on && r < SHF && !outside) {
@@ -65,7 +69,7 @@ __device__ __forceinline__ void pyr_down2_body(const AgtPyrArgs& A0, const AgtPy
             }
         }
 #pragma unroll
-        for (int k = 0; k < 6; k++) {
+        for (int k = 0; k < NR; k++) {
             const int r = r0 + 14 * k;
             if (lane_on && r < SHF) *reinterpret_cast<uint4*>(s_src + r * SW + 16 * c) = v[k];
         }

@@ -21,3 +21,14 @@ e1.record(); torch.cuda.synchronize()
 us = e0.elapsed_time(e1) * 1e3 / n
 byt = B * (W * H + (W // 2) * (H // 2))
 print("pyr_down L0->L1 x%d images: %.2f us/launch, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (B, us, byt / us / 1e3, byt / us / 1e3 / 80))
+# the two-level pass (L0 -> L1 -> L2 in one launch: agt_pyramid_build with max_level 2), same rotation
+for i in range(10):
+    ctx.pyramid_build(1, src[i % SLOTS])
+torch.cuda.synchronize()
+e0.record()
+for i in range(n):
+    ctx.pyramid_build(1, src[i % SLOTS])
+e1.record(); torch.cuda.synchronize()
+us2 = e0.elapsed_time(e1) * 1e3 / n
+byt2 = B * (W * H + (W // 2) * (H // 2) + (W // 4) * (H // 4))
+print("pyramid L0->L1->L2 x%d images, one pass: %.2f us/launch, %.1f GB/s algorithmic (%.1f%% of 8 TB/s)" % (B, us2, byt2 / us2 / 1e3, byt2 / us2 / 1e3 / 80))
