@@ -252,6 +252,21 @@ int agt_synchronize(agt_ctx* c)
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
+int agt_upload(agt_ctx* c, void* d_dst, const void* h_src, size_t bytes)
+{
+    if (!c || !d_dst || !h_src) return AGT_ERR_ARG;
+    hipError_t e = hipMemcpyAsync(d_dst, h_src, bytes, hipMemcpyHostToDevice, c->stream);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+int agt_download(agt_ctx* c, void* h_dst, const void* d_src, size_t bytes)
+{
+    if (!c || !h_dst || !d_src) return AGT_ERR_ARG;
+    hipError_t e = hipMemcpyAsync(h_dst, d_src, bytes, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
 int agt_pyr_down_u8(agt_ctx* c, const uint8_t* d_src, int sw, int sh, size_t spitch, size_t sbatch,
                     uint8_t* d_dst, size_t dpitch, size_t dbatch, int B)
 {

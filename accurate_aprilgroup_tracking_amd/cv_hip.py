@@ -260,6 +260,48 @@ def _geom_context(n):
     return _context(64, 64, 0, 21, n)
 
 
+class _Staging:
+    """Pinned host buffer + device buffer of one geometry context: a cv2-shaped call packs all of its inputs into ONE
+    host-to-device copy and reads all of its outputs back with ONE device-to-host copy (round 1 issued a pageable copy per
+    array and a synchronising .cpu() per result: 129 us for solvePnP at N = 48; this path: bench.py per_call_latency_us)."""
+    OBJ, IMG = 0, 256 * 3 * 8
+    POSE = IMG + 256 * 2 * 8                 # pose (48 B) sits right in front of the outputs: one download covers both
+    OUT = POSE + 48                          # info (16 B) | projected points (n x 2) | Jacobian (2n x 6 f64)
+    PTS = OUT + 16
+    JAC = PTS + 256 * 2 * 8
+    SIZE = JAC + 2 * 256 * 6 * 8
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self.host = torch.empty(self.SIZE, dtype=torch.uint8).pin_memory()
+        self.np = self.host.numpy()
+        self.hbase = self.host.data_ptr()
+        self.dev = torch.empty(self.SIZE, dtype=torch.uint8, device=torch.device("cuda", ctx.device))
+        self.base = self.dev.data_ptr()
+
+    def f64(self, off, n):
+        return self.np[off:off + 8 * n].view(np.float64)
+
+    def view(self, off, n, dt):
+        return self.np[off:off + np.dtype(dt).itemsize * n].view(dt)
+
+    def upload(self, off, nbytes):
+        H.check(self.ctx.L.agt_upload(self.ctx.h, C.c_void_p(self.base + off), C.c_void_p(self.hbase + off), nbytes), "agt_upload")
+
+    def download(self, off, nbytes):
+        H.check(self.ctx.L.agt_download(self.ctx.h, C.c_void_p(self.hbase + off), C.c_void_p(self.base + off), nbytes), "agt_download")
+
+
+_staging = {}
+
+
+def _stage(ctx):
+    st = _staging.get(id(ctx))
+    if st is None:
+        st = _staging[id(ctx)] = _Staging(ctx)
+    return st
+
+
 def getOptimalNewCameraMatrix(cameraMatrix, distCoeffs, imageSize, alpha, newImgSize=(0, 0)):
     """cv2.getOptimalNewCameraMatrix -> (newCameraMatrix (3,3) f64, roi (x, y, w, h)).  Host arithmetic
     (81 grid points), done by the C-ABI library like every other cv2 replacement."""
@@ -368,21 +410,28 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
         raise error("solvePnP: need 4 <= N <= 256 matching object/image points")
     dt = np.float32 if (obj.dtype == np.float32 and img.dtype == np.float32) else np.float64
     ctx = _geom_context(n)
-    dev = torch.device("cuda", ctx.device)
-    o = torch.from_numpy(np.ascontiguousarray(obj, dtype=dt)).to(dev)
-    m = torch.from_numpy(np.ascontiguousarray(img, dtype=dt)).to(dev).reshape(1, n, 2)
-    pose = torch.zeros((1, 6), dtype=torch.float64, device=dev)
+    if useExtrinsicGuess and (rvec is None or tvec is None or np.size(rvec) != 3 or np.size(tvec) != 3):
+        raise error("solvePnP: useExtrinsicGuess needs 3-element rvec and tvec")
+    # one pinned staging buffer: [obj | img | pose] up in one copy, [pose | info] down in one copy
+    st = _stage(ctx)
+    st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
+    st.view(st.IMG, n * 2, dt)[:] = img.reshape(-1)
+    g = st.f64(st.POSE, 6)
     if useExtrinsicGuess:
-        if rvec is None or tvec is None or np.size(rvec) != 3 or np.size(tvec) != 3:
-            raise error("solvePnP: useExtrinsicGuess needs 3-element rvec and tvec")
-        g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
-        pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
-    try:
-        pose, info, _ = ctx.solve_pnp(o, m, cameraMatrix, distCoeffs, pose, useExtrinsicGuess)
-    except H.AgtError as e:
-        raise error(str(e))
-    p = pose.cpu().numpy().reshape(6)
-    inf = info.cpu().numpy().reshape(4)
+        g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
+    else:
+        g[:] = 0.0
+    st.upload(0, st.OUT)
+    Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
+    base = st.base
+    rc = ctx.L.agt_solve_pnp(ctx.h, C.c_void_p(base + st.OBJ), 0, C.c_void_p(base + st.IMG), H.F32 if dt == np.float32 else H.F64,
+                             None, n, 1, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                             C.c_void_p(base + st.POSE), 1 if useExtrinsicGuess else 0, C.c_void_p(base + st.OUT), None)
+    if rc:
+        raise error(str(H.AgtError(rc, "agt_solve_pnp")))
+    st.download(st.POSE, 64)                                   # pose | info
+    inf = st.view(st.OUT, 4, np.int32)
+    p = st.f64(st.POSE, 6).copy()
     if not inf[H.INFO_OK]:
         raise error("solvePnP: not enough usable points (non-planar sets need 6 without a guess)")
     if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
@@ -401,6 +450,23 @@ def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, jacobian=F
     obj = np.ascontiguousarray(obj.reshape(-1, 3), dtype=dt)
     n = obj.shape[0]
     ctx = _geom_context(min(n, 256))
+    if n <= 256:
+        # staged path: [obj | pose] up in one copy, [points (| Jacobian)] down in one copy
+        st = _stage(ctx)
+        st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
+        g = st.f64(st.POSE, 6)
+        g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
+        st.upload(0, st.OUT)
+        Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
+        rc = ctx.L.agt_project_points(ctx.h, C.c_void_p(st.base + st.OBJ), 0, H.F32 if dt == np.float32 else H.F64, n, 1,
+                                      C.c_void_p(st.base + st.POSE), Kh.ctypes.data_as(C.c_void_p),
+                                      dh.ctypes.data_as(C.c_void_p) if nd else None, nd, C.c_void_p(st.base + st.PTS),
+                                      C.c_void_p(st.base + st.JAC) if jacobian else None)
+        if rc:
+            raise error(str(H.AgtError(rc, "agt_project_points")))
+        st.download(st.PTS, (st.JAC - st.PTS) + (2 * n * 6 * 8 if jacobian else 0) if jacobian else n * 2 * np.dtype(dt).itemsize)
+        pts = st.view(st.PTS, n * 2, dt).reshape(n, 1, 2).copy()
+        return pts, (st.f64(st.JAC, 2 * n * 6).reshape(2 * n, 6).copy() if jacobian else None)
     dev = torch.device("cuda", ctx.device)
     g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
     pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()

@@ -102,6 +102,12 @@ int  agt_set_stream(agt_ctx* ctx, void* hip_stream);
 int  agt_last_hip_error(const agt_ctx* ctx);   /* hipError_t of the last failing HIP call */
 int  agt_synchronize(agt_ctx* ctx);            /* hipStreamSynchronize(ctx stream) */
 
+/* ---- staging copies for host-array callers (the cv2-shaped Python functions): both on the context's stream;
+ * agt_upload enqueues host -> device (pin the host buffer for it to be asynchronous), agt_download enqueues device -> host
+ * and then WAITS for the stream, so the bytes are valid on return. ---- */
+int agt_upload(agt_ctx* ctx, void* d_dst, const void* h_src, size_t bytes);
+int agt_download(agt_ctx* ctx, void* h_dst, const void* d_src, size_t bytes);
+
 /* ---- image pyramid (cv::pyrDown / buildOpticalFlowPyramid) ---- */
 /* One pyrDown: dst is ((sw+1)/2) x ((sh+1)/2).  Pitches and batch strides in bytes;
  * base pointers and pitches must be multiples of 4. */

@@ -95,22 +95,24 @@ def test_pose_detector_mirror_on_hip_backend(tmp_path, name):
             assert np.abs(g - fx["guess"][k]).max() < POSE_TOL
 
 
+@pytest.mark.parametrize("scene", ["640", "720", "640_dist"])
 @pytest.mark.parametrize("reproject,pipeline", [(False, True), (True, True), (False, False)])
-def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, reproject, pipeline):
+def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, seq720, seq640_dist, scene, reproject, pipeline):
     """GPU: StreamTracker.step over rendered frames.  CPU: oracle LK + the (reference-validated)
-    PoseDetector mirror on the oracle backend, fed per-corner."""
+    PoseDetector mirror on the oracle backend, fed per-corner.  Scenes: 640x480, the headline 1280x720 (BASELINE
+    configs[1]) and a camera with lens distortion (synthetic.MILD_DIST: frames rendered through it, solvePnP with it)."""
     torch = torch_cuda
     from oracle import cv2_shim
     from accurate_aprilgroup_tracking_amd import hiplib as H
     from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
-    s = seq640
+    s = {"640": seq640, "720": seq720, "640_dist": seq640_dist}[scene]
     F = len(s)
     # reproject=True rounds the re-projected corners to float32: a 1e-10 pose difference can flip
     # a corner by one float32 ulp (6e-5 px), which LK+PnP turn into ~1e-7 on the next pose.
     tol = 1e-6 if reproject else POSE_TOL
     frames = torch.from_numpy(s.frames()).cuda()                      # [F,H,W]
-    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2, reproject=reproject)
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, s.dist, n_streams=2, reproject=reproject)
     trk.pipeline(pipeline)
     c0 = torch.from_numpy(np.stack([s.corners(0), s.corners(0)])).cuda().contiguous()
     two = lambda k: torch.stack([frames[k], frames[k]]).contiguous()
@@ -124,7 +126,7 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
 
     class Det(PoseDetector):
         DIRPATH = tmp
-    det = Det(LOG, s.K, None, True, cv=cv2_shim.make_cv2())
+    det = Det(LOG, s.K, s.dist, True, cv=cv2_shim.make_cv2())
     obj32 = s.obj.astype(np.float32)
     pts = s.corners(0)
     pyr = oracle.Pyramid(s.frame(0))
@@ -148,7 +150,7 @@ def test_fused_track_frame_matches_oracle_chain(torch_cuda, oracle, seq640, repr
             assert abs(st[b, H.ST_ERR] - det.last_error) < 1e-4          # reference sums float32 norms
             assert np.abs(st[b, :3] - s.rvecs[k]).max() < 3e-3 and np.abs(st[b, 3:6] - s.tvecs[k]).max() < 3e-3
         if reproject and det.last_error is not None and det.last_error < 2:
-            pp, _ = oracle.projectPoints(s.obj, det.last_pose[0], det.last_pose[1], s.K, None)
+            pp, _ = oracle.projectPoints(s.obj, det.last_pose[0], det.last_pose[1], s.K, s.dist)
             pts = pp.reshape(-1, 2).astype(np.float32)
         else:
             pts = nx.astype(np.float32)
