@@ -79,6 +79,28 @@ __device__ __forceinline__ float agt_uniform(float v)
 // so that d(R X)/dr_j = G_j x (R X) (G_j = column j).  This is the same derivative OpenCV forms through its
 // 3x9 dR/dr table (27 entries, ~170 FP64 operations, and 27 multiply-adds per point): analytically equal,
 // a third of the work on the serial chain.  The oracle keeps OpenCV's table; parity is checked to 1e-9.
+// sin and cos of x >= 0 together, for the rotation angles of this path (|x| < 2^20; anything else goes to the library).
+// Cody-Waite reduction by pi/2 in two terms, then the fdlibm kernel polynomials on |r| <= pi/4 (< 1 ulp): two short
+// interleaved Horner chains instead of the library's general-argument sincos (which sat at 0.3 us of every LM evaluation).
+__device__ __forceinline__ void agt_sincos(double x, double& s, double& c)
+{
+    if (!(x < 1048576.0)) { sincos(x, &s, &c); return; }
+    const double k = rint(x * 6.36619772367581382433e-01);               // 2 / pi
+    double r = fma(-k, 1.57079632673412561417e+00, x);                    // pi/2, first 33 bits
+    r = fma(-k, 6.07710050650619224932e-11, r);                           // pi/2 - the above
+    const double z = r * r;
+    const double sp = fma(z, fma(z, fma(z, fma(z, fma(z, 1.58969099521155010221e-10, -2.50507602534068634195e-08), 2.75573137070700676789e-06),
+                                       -1.98412698298579493134e-04), 8.33333333332248946124e-03), -1.66666666666666324348e-01);
+    const double cp = fma(z, fma(z, fma(z, fma(z, fma(z, -1.13596475577881948265e-11, 2.08757232129817482790e-09), -2.75573143513906633035e-07),
+                                       2.48015872894767294178e-05), -1.38888888888741095749e-03), 4.16666666666666019037e-02);
+    const double sr = fma(r * z, sp, r);
+    const double cr = fma(z * z, cp, fma(z, -0.5, 1.0));
+    const int q = (int)k & 3;
+    const double ss = (q & 1) ? cr : sr, cc = (q & 1) ? sr : cr;
+    s = (q & 2) ? -ss : ss;
+    c = ((q + 1) & 2) ? -cc : cc;
+}
+
 template <bool JAC>
 __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9], double G[9])
 {
@@ -95,7 +117,7 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
         return;
     }
     double s, c;
-    sincos(theta, &s, &c);
+    agt_sincos(theta, s, c);
     double c1 = 1.0 - c, itheta = 1.0 / theta;
     if (JAC) {
         // a = (1 - cos t)/t^2, b = (t - sin t)/t^3; series below t = 1e-2 (cancellation), relative error < 1e-16 there

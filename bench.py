@@ -404,56 +404,83 @@ def h2d_inclusive(torch, bench, K):
     on the host, detect_pose.py:669-681).  A copy stream uploads chunk c+1 (G frames, one hipMemcpyAsync) while the tracker
     works on chunk c; events order upload -> step and step -> buffer reuse.  Never `value`."""
     W, H, B = bench.W, bench.H, bench.B
-    G, NB = 8, 4                                    # frames per upload, chunk buffers on the device
+    G, NB, depth = 8, 8, 4                          # frames per upload, chunk buffers on the device, frames per fused launch
+    lag = -(-((LEVELS + 2) * depth) // G) + 1       # chunks after which a chunk's frames are dead (pipeline depth, rounded up)
     P = int(np.lcm(bench.period, G))                # whole ping-pong periods AND whole chunks: the sequence stays continuous across the wrap
     assert P + 1 <= bench.ring_slots
     host = torch.empty((P, B, H, W), dtype=torch.uint8).pin_memory()
     host.copy_(bench.ring[1:P + 1].cpu())           # stream order: frame k of the run is ring[(k + 1) % slots]
     devb = torch.empty((NB, G, B, H, W), dtype=torch.uint8, device=bench.dev)
     copy_s = torch.cuda.Stream()
+    main_s = torch.cuda.Stream()                    # the tracker runs on a stream of its own here (not the legacy default stream)
     up = [torch.cuda.Event() for _ in range(NB)]
     done = [torch.cuda.Event() for _ in range(NB)]
-    main_s = torch.cuda.current_stream()
-    n = (max(K, 200) // P) * P or P
-    bench.trk.pipeline(1)
-    bench.restart()
+    n = max(4, 1000 // P) * P
     state = torch.zeros((n, B, 16), dtype=torch.float64, device=bench.dev)
+    torch.cuda.synchronize()
+    ctx_stream = torch.cuda.stream(main_s)
+    ctx_stream.__enter__()
+    bench.trk.pipeline(depth)
+    bench.restart()
+
+    # uploads go through the library's own staging call (agt_upload = hipMemcpyAsync on the stream of a second, tiny context
+    # bound to the copy stream): the torch route (stream context manager + tensor slicing + copy_) costs ~250 us of host time
+    # per chunk and made this loop host-bound at 18 k frames/s
+    from accurate_aprilgroup_tracking_amd import cv_hip, hiplib as HL
+    with torch.cuda.stream(copy_s):
+        up_ctx = cv_hip.Context(64, 64, max_level=0)
+    chunk_bytes = G * B * H * W
+    hbase, dbase = host.data_ptr(), devb.data_ptr()
+
+    tsteps = [0.0]
 
     def go(chunks, out, c0):
         for c in range(c0, c0 + chunks):
             cb = c % NB
-            with torch.cuda.stream(copy_s):
-                # a frame is dead three launches after its own (LK of the next frame reads it last): chunk c - NB is dead once
-                # chunk c - NB + 2 has run, whose `done` event was recorded NB - 2 chunks ago
-                if c - c0 >= NB:
-                    copy_s.wait_event(done[(c - NB + 2) % NB])
-                h0 = (c * G) % P
-                devb[cb].copy_(host[h0:h0 + G], non_blocking=True)
-                up[cb].record(copy_s)
+            # a frame is dead (LEVELS + 2) * depth steps after its own (the LK of the next frame reads it last): chunk
+            # c - NB is dead once chunk c - NB + lag has run; its `done` event was recorded NB - lag chunks ago
+            # (waited for on the HOST: a cross-stream wait in front of hipMemcpyAsync makes the runtime block the calling thread
+            # until the event has fired, 300 us per chunk here; with NB - lag chunks of slack the event is long complete)
+            if c - c0 >= NB:
+                done[(c - NB + lag) % NB].synchronize()
+            h0 = (c * G) % P
+            HL.check(up_ctx.L.agt_upload(up_ctx.h, C.c_void_p(dbase + cb * chunk_bytes), C.c_void_p(hbase + h0 * B * H * W), chunk_bytes), "agt_upload")
+            up[cb].record(copy_s)
             main_s.wait_event(up[cb])
+            tq = time.perf_counter()
             for g in range(G):
                 k = (c - c0) * G + g
                 bench.trk.step(devb[cb, g], out[k] if out is not None else None)
                 bench.since += 1
+            tsteps[0] += time.perf_counter() - tq
             done[cb].record(main_s)
     go(20, None, 0)
     bench.trk.join(); torch.cuda.synchronize()
     bench.restart()                                  # frame 0 again: host[0] is frame 1 of the stream
+    tsteps[0] = 0.0
     t0 = time.perf_counter()
     go(n // G, state, 0)
-    bench.trk.join(); torch.cuda.synchronize()
+    bench.trk.join()
+    t_enq = time.perf_counter() - t0
+    torch.cuda.synchronize()
     dt = time.perf_counter() - t0
     ok = float(state.cpu().numpy()[:, :, 6].mean())
     t1 = time.perf_counter()
     for k in range(32):
-        devb[k % NB].copy_(host[(k * G) % P:(k * G) % P + G], non_blocking=True)
+        HL.check(up_ctx.L.agt_upload(up_ctx.h, C.c_void_p(dbase + (k % NB) * chunk_bytes), C.c_void_p(hbase + ((k * G) % P) * B * H * W), chunk_bytes), "agt_upload")
     torch.cuda.synchronize()
     up_dt = (time.perf_counter() - t1) / (32 * G)
+    bench.trk.join(); torch.cuda.synchronize()
+    ctx_stream.__exit__(None, None, None)
+    bench.restart()                                  # back on the default stream
+    torch.cuda.synchronize()
     del host, devb
     return {"frames_per_s": round(B * n / dt, 1), "ms_per_step": round(dt / n * 1e3, 5), "accepted_frac": round(ok, 4),
             "upload_only_us_per_frame": round(up_dt * 1e6, 2), "upload_GBs": round(B * W * H / up_dt / 1e9, 2),
-            "note": "pinned host frames uploaded %d per copy on a copy stream (%d device buffers), depth-1 fused step; PCIe Gen5 x16 = 63 GB/s spec"
-                    % (G, NB * G)}
+            "frames": n, "host_enqueue_us_per_frame": round(t_enq / n * 1e6, 2), "host_tracker_calls_us_per_frame": round(tsteps[0] / n * 1e6, 2),
+            "note": "pinned host frames uploaded %d per copy on a copy stream (%d device buffers) while the tracker works on the previous chunk, "
+                    "fused step at %d frames per launch; PCIe Gen5 x16 = 63 GB/s spec; wall time of %d frames including pipeline fill and drain"
+                    % (G, NB * G, depth, n)}
 
 
 def batch_extra(torch, D, HL, args, rank, dev):
