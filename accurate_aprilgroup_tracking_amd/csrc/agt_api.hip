@@ -736,8 +736,13 @@ int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int
 static int ms_init(agt_ctx* c)
 {
     if (c->ms_ready) return AGT_OK;
+    // the LK launches are the long pole of a split-mode step (VALU-issue bound, ~38 us at 64 x 720p) and share the chip with
+    // the pyramid launches of the caller's stream, whose short workgroups otherwise take every wave slot first: the LK (and
+    // PnP) streams get the highest priority so that their workgroups are placed ahead of the pyramid's
+    int pr_lo = 0, pr_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
     for (int i = 0; i < 3; i++)
-        if (hipStreamCreateWithFlags(&c->ms_stream[i], hipStreamNonBlocking) != hipSuccess) return hip_fail(c, hipGetLastError());
+        if (hipStreamCreateWithPriority(&c->ms_stream[i], hipStreamNonBlocking, pr_hi) != hipSuccess) return hip_fail(c, hipGetLastError());
     for (int k = 0; k < 4; k++)
         for (int i = 0; i < AGT_RING_MAX; i++)
             if (hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) return hip_fail(c, hipGetLastError());
