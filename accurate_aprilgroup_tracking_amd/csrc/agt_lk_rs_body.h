@@ -185,6 +185,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         }
     };
 
+    STAMP(0);
     // ---- prologue: request every level's tiles before touching any of them.
     // Fast path (the tile's dword-aligned footprint lies inside the image): buffer loads -- lane (row, dword) offsets
     // computed once per level, the tile origin rides in the scalar offset, no per-dword address or border arithmetic
@@ -245,6 +246,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 }
             }
         }
+        STAMP(1);
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             if (l <= P->max_level) {
@@ -264,11 +266,13 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         }
     }
     block_sync<NW>();
+    STAMP(2);
 
     int st = 1;
     float errv = 0.f;
 
     for (int level = P->max_level; level >= 0; level--) {
+        STAMP(8 + level * 8 + 0);
         AgtLevel LJ = get_level(P->next[level]);
         if (io.grouped) {
             const uint8_t* q = io.imgJ[0];
@@ -343,6 +347,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 Ix[PX - 1] = in1 ? Ix[PX - 1] : 0; Iy[PX - 1] = in1 ? Iy[PX - 1] : 0;
             }
         }
+        STAMP(8 + level * 8 + 1);
         // (idle lanes duplicate the last active one: their partial sums are dropped, their patch values are never masked)
         int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
@@ -369,6 +374,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             continue;
         }
         D = 1.f / D;
+        STAMP(8 + level * 8 + 2);
 
         nextx -= halfw; nexty -= halfw;
         float pdx = 0.f, pdy = 0.f;
@@ -428,6 +434,10 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             const float dy = (A12 * fb1 - A11 * fb2) * D;
             nextx += dx; nexty += dy;
             outx = nextx + halfw; outy = nexty + halfw;
+            if (j == 0) STAMP(8 + level * 8 + 3);
+#ifdef AGT_LK_STAMPS
+            if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
+#endif
             // OpenCV tests  (double)dx*dx + (double)dy*dy <= eps^2  in FP64; the float sum is within 2e-7 of it, so the
             // FP64 evaluation is only needed inside a 1e-6 band around the threshold (wave-uniform, rare)
             const float d2 = dx * dx + dy * dy;
@@ -442,6 +452,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             pdx = dx; pdy = dy;
         }
 
+        STAMP(8 + level * 8 + 4);
         if (st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
             const float npx = outx - halfw, npy = outy - halfw;
             const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
@@ -464,6 +475,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         }
     }
 
+    STAMP(3);
     if (tid == 0) {
         io.next_pts[pidx * 2] = outx;
         io.next_pts[pidx * 2 + 1] = outy;

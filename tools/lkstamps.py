@@ -17,13 +17,13 @@ for rep in range(3):
     ctx.lk_track(0, 1, pts); torch.cuda.synchronize()
     st = (C.c_ulonglong * 64)(); L.agt_debug_lk_stamps(st)
     t0 = st[0]
-    mhz = 100.0   # s_memtime ticks at 100 MHz on gfx9 (constant), 10 ns per tick
-    f = lambda i: (st[i] - t0) * 0.01
+    f = lambda i: (st[i] - t0) / 2100.0          # s_memtime counts shader cycles (~2.1 GHz under this load): us
     print("rep %d: loads issued %.2f us, tiles in LDS %.2f us, end %.2f us" % (rep, f(1), f(2), f(3)))
     for lv in (2, 1, 0):
         b = 8 + lv * 8
         print("   level %d: start %.2f  scharr+%.2f  patch+sums+%.2f  iter0+%.2f  iters(n=%d)+%.2f" % (
             lv, f(b), f(b + 1) - f(b), f(b + 2) - f(b + 1), f(b + 3) - f(b + 2), st[b + 6], f(b + 4) - f(b + 2)))
-    g = lambda i: st[i] - st[39]
-    print("   iteration j=1 of the last level run (cycles): floor/bounds %d | weights %d | window pass %d | block sum %d | delta %d | conds %d" % (
-        g(40), g(41) - g(40), g(42) - g(41), g(43) - g(42), g(44) - g(43), g(45) - g(44)))
+    if st[45] > st[39] > 0:       # per-iteration stamps exist only in the general body (AGT_LK_RS=0)
+        g = lambda i: st[i] - st[39]
+        print("   iteration j=1 of the last level run (cycles): floor/bounds %d | weights %d | window pass %d | block sum %d | delta %d | conds %d" % (
+            g(40), g(41) - g(40), g(42) - g(41), g(43) - g(42), g(44) - g(43), g(45) - g(44)))
