@@ -269,6 +269,74 @@ __device__ __forceinline__ double lane_bcast(double v, int src)
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// Smallest eigenvector of the symmetric PSD N x N matrix A (row-major, LDS), by the WHOLE wave: the same shifted inverse
+// iteration on a Cholesky factor as smallest_eigvec, with lane i owning row i -- column j of the factor needs one broadcast
+// of row j, a triangular solve is N broadcast steps.  ~2,700 instructions against ~170 us of serial LDS round trips on one
+// lane (cv2-shaped solvePnP without a guess: 211 -> 60 us per call).  A is used as scratch; v_out: N doubles in LDS.
+// Ends with the result visible to every lane (barrier inside).
+template <int N>
+__device__ __forceinline__ void smallest_eigvec_wave(double* A, double* v_out, int lane)
+{
+    const int i = lane < N ? lane : N - 1;               // (lanes >= N mirror the last row; their results are dropped)
+    double a[N], l[N], lt[N];
+    double dmax = 0.0;
+#pragma unroll
+    for (int k = 0; k < N; k++) { a[k] = A[i * N + k]; dmax = fmax(dmax, A[k * N + k]); }
+    const double mu = dmax * 1e-11 + DBL_MIN;
+    // ---- Cholesky, A + mu I = L L^T; l[k] = L[i][k] (k <= i meaningful)
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        double d = a[j] + mu, s = a[j];
+#pragma unroll
+        for (int k = 0; k < j; k++) {
+            const double ljk = lane_bcast(l[k], j);      // L[j][k]
+            d -= l[k] * l[k];                            // (lane j's own row)
+            s -= l[k] * ljk;
+        }
+        d = d > mu * 1e-3 ? d : mu * 1e-3;
+        d = sqrt(d);
+        const double djj = lane_bcast(d, j);
+        const double id = 1.0 / djj;
+        l[j] = (i == j) ? djj : s * id;
+    }
+    // column i of L for the backward solves: transpose through LDS
+    __syncthreads();
+    if (lane < N) {
+#pragma unroll
+        for (int k = 0; k < N; k++) A[i * N + k] = l[k];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < N; k++) lt[k] = A[k * N + i];    // L[k][i], meaningful for k >= i
+    double dii = 0.0;                                    // L[i][i]
+#pragma unroll
+    for (int k = 0; k < N; k++) dii = (i == k) ? l[k] : dii;
+    const double idii = 1.0 / dii;                       // (the serial form divides; one reciprocal + multiplies here)
+    double x = 1.0 / sqrt((double)N) * ((i & 1) ? 0.9 : 1.1);
+    for (int it = 0; it < 12; it++) {
+        // forward: L y = x
+        double acc = x, y = 0.0;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            const double yk = lane_bcast(acc * idii, k);
+            y = (i == k) ? yk : y;
+            acc -= l[k] * yk;                            // (only lanes i > k use it later)
+        }
+        // backward: L^T x = y
+        acc = y;
+#pragma unroll
+        for (int k = N - 1; k >= 0; k--) {
+            const double xk = lane_bcast(acc * idii, k);
+            x = (i == k) ? xk : x;
+            acc -= lt[k] * xk;                           // (only lanes i < k use it later)
+        }
+        const double nn = wave_sum_f64(lane < N ? x * x : 0.0);
+        x *= 1.0 / sqrt(nn);
+    }
+    if (lane < N) v_out[lane] = x;
+    __syncthreads();
+}
+
 // ---- motion model of PoseDetector (wave-cooperative: independent trig runs on separate lanes) ------------------------------------
 // A^T B
 __device__ inline void mat3_tmul(const double A[9], const double B[9], double C[9])
@@ -549,8 +617,11 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                         LtL[(3 + a) * 9 + c] = 0.0;      LtL[(3 + a) * 9 + 3 + c] = t0[u];    LtL[(3 + a) * 9 + 6 + c] = -ty[u];
                         LtL[(6 + a) * 9 + c] = -tx[u];   LtL[(6 + a) * 9 + 3 + c] = -ty[u];   LtL[(6 + a) * 9 + 6 + c] = tq[u];
                     }
+            }
+            __syncthreads();
+            smallest_eigvec_wave<9>(sh.LL, sh.vec, lane);
+            if (lane == 0) {
                 double* hv = sh.vec;
-                smallest_eigvec(LtL, 9, hv, sh.vec + 16);
                 const double invHn[9] = { 1. / smx, 0, cmx, 0, 1. / smy, cmy, 0, 0, 1 };
                 const double Hn2[9] = { sMx, 0, -cMx * sMx, 0, sMy, -cMy * sMy, 0, 0, 1 };
                 double H0[9], Tm[9], h[9];
@@ -790,8 +861,11 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                     sh.LL[(4 + a) * 12 + c] = 0.0;       sh.LL[(4 + a) * 12 + 4 + c] = s0[u];  sh.LL[(4 + a) * 12 + 8 + c] = sy[u];
                     sh.LL[(8 + a) * 12 + c] = sx[u];     sh.LL[(8 + a) * 12 + 4 + c] = sy[u];  sh.LL[(8 + a) * 12 + 8 + c] = sq[u];
                 }
+        }
+        __syncthreads();
+        smallest_eigvec_wave<12>(sh.LL, sh.vec, lane);
+        if (lane == 0) {
             double* v = sh.vec;
-            smallest_eigvec(sh.LL, 12, v, sh.vec + 16);
             double RR[9] = { v[0], v[1], v[2], v[4], v[5], v[6], v[8], v[9], v[10] };
             double tt[3] = { v[3], v[7], v[11] };
             if (agt_det3(RR) < 0) {
