@@ -8,7 +8,7 @@
 #include <float.h>
 
 #define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
-#define AGT_RING_MAX 64          // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
+#define AGT_RING_MAX 224         // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
 // The two-level pyramid pass saves a launch / pipeline stage and 16 % of the pyramid's HBM bytes, but its 41 KB workgroups
 // (3 per CU, eight barriers per tile) stream at 2.5 TB/s against 3.9 + 3.4 TB/s for two single-level passes (8 per CU): it is
 // used where the stage count matters (few streams), the two passes where throughput does (measured at 64 x 720p: 30.5 vs 25 us).
@@ -49,6 +49,11 @@ struct agt_ctx {
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
+    // chained launches (fused step): per ring entry, [max_streams] arrival counters the LK role counts corners into and
+    // the PnP role of the same launch waits on; lk_target = the value the entry's counters reach once every corner
+    // of its current frame is written (counters only ever grow: no reset, no reuse hazard)
+    unsigned* lk_done;
+    unsigned lk_target[AGT_RING_MAX];
     float* lkerr;                            // [B][n]
     float* obj;                              // [n][3]
     double* pose;                            // [B][6]
@@ -194,6 +199,8 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     ok = ok && hipMalloc((void**)&c->obj, N * 3 * sizeof(float)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->pose, B * 6 * sizeof(double)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
+    ok = ok && hipMalloc((void**)&c->lk_done, (size_t)AGT_RING_MAX * B * sizeof(unsigned)) == hipSuccess;
+    ok = ok && hipMemset(c->lk_done, 0, (size_t)AGT_RING_MAX * B * sizeof(unsigned)) == hipSuccess;
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
     c->last_p_ev = -1; c->l_ev_hist[0] = c->l_ev_hist[1] = c->l_ev_hist[2] = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
@@ -221,6 +228,7 @@ int agt_destroy(agt_ctx* c)
     if (c->obj) (void)hipFree(c->obj);
     if (c->pose) (void)hipFree(c->pose);
     if (c->tstate) (void)hipFree(c->tstate);
+    if (c->lk_done) (void)hipFree(c->lk_done);
     if (c->dense_partials) (void)hipFree(c->dense_partials);
     if (c->dense_done) (void)hipFree(c->dense_done);
     if (c->map1) (void)hipFree(c->map1);
@@ -432,6 +440,9 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
     for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
+    // arrival counters of the chained launches: a run counts n corners per stream-frame, the next run may have other n / B
+    if (e == hipSuccess) e = hipMemsetAsync(c->lk_done, 0, (size_t)AGT_RING_MAX * c->cfg.max_streams * sizeof(unsigned), c->stream);
+    memset(c->lk_target, 0, sizeof(c->lk_target));
     if (e != hipSuccess) return hip_fail(c, e);
     c->trk_n = n; c->trk_B = B; c->trk_frame = 0; c->n_lk = c->n_pnp = 0; c->enhance_ape = enhance_ape ? 1 : 0;
     for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = 0;
@@ -527,6 +538,12 @@ static int launch_group(agt_ctx* c, int B)
     const long lk_before = c->n_lk;
     long lk_f0 = 0;                              // LK role: the frame before its group
     bool any = false;
+    // Chained launch (fused step only): the PnP role follows the LK role of the SAME launch frame by frame through arrival
+    // counters (agt_step.hip pnp_role), instead of one launch behind it.
+    bool chain = agt_step_fits(c->trk_n, B);
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_CHAIN=0 keeps the PnP role one launch behind the LK role
+    { static const int on = [] { const char* e = getenv("AGT_CHAIN"); return e ? atoi(e) : 1; }(); if (!on) chain = false; }
+#endif
     // stage 0 builds levels 1 and 2 in one pass (stage 1 then only keeps the books) while the batch is small
     const bool fused = L >= 2 && B <= AGT_PYR2_MAX_B;
     S.pyr_fused = fused ? 1 : 0;
@@ -588,20 +605,30 @@ static int launch_group(agt_ctx* c, int B)
         for (long k = 0; k <= cnt; k++) {
             const int q = (int)((f0 + k) % M);
             for (int l = 0; l <= L; l++) T.lk.img[k][l] = l == 0 ? c->l0_ptr[q] : c->lmem[q][l];
-            if (k) { T.lk.next[k - 1] = c->corners[q]; T.lk.status[k - 1] = c->status[q]; }
+            if (k) {
+                T.lk.next[k - 1] = c->corners[q]; T.lk.status[k - 1] = c->status[q];
+                if (chain) { T.lk.done[k - 1] = c->lk_done + (size_t)q * c->cfg.max_streams; c->lk_target[q] += (unsigned)c->trk_n; }
+            }
         }
         S.n_lk = 1; S.lk_B = B;
         c->n_lk += cnt;
         any = true;
     }
-    if (c->n_pnp < lk_before) {
-        long cnt = lk_before - c->n_pnp;
+    // frames the PnP role may take: everything tracked before this launch; chained, also the frames tracked BY it, waiting
+    // for each one's counter -- all of them when nothing more is registered (a drain: the last frames' latency counts), all
+    // but the newest while frames keep coming (the role then never stalls: the LK role works one frame ahead of it)
+    long pnp_avail = lk_before;
+    if (chain) pnp_avail = c->n_lk - (c->n_lk < c->trk_frame && c->n_lk > lk_before ? 1 : 0);
+    if (c->n_pnp < pnp_avail) {
+        long cnt = pnp_avail - c->n_pnp;
         if (cnt > F) cnt = F;
         const int slot = (int)((c->n_pnp + 1) % M);
         fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
         for (long k = 0; k < cnt; k++) {
-            const int q = (int)((c->n_pnp + 1 + k) % M);
+            const long f = c->n_pnp + 1 + k;
+            const int q = (int)(f % M);
             T.pnp.img[k] = c->corners[q]; T.pnp.mask[k] = c->status[q]; T.pnp.so[k] = c->so_ring[q];
+            if (f > lk_before) { T.pnp.wait[k] = c->lk_done + (size_t)q * c->cfg.max_streams; T.pnp.target[k] = c->lk_target[q]; }
         }
         S.pnp_nf = (int)cnt;
         S.n_pnp = B;
@@ -831,6 +858,18 @@ int agt_track_frame(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t ba
     }
 
     return step_serial(c, d_frames, pitch, batch_stride, B, d_state_out, nullptr, pev);
+}
+
+int agt_track_frames(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
+                     double* d_state_out)
+{
+    if (count < 0 || (frame_stride & 3)) return AGT_ERR_ARG;
+    for (int k = 0; k < count; k++) {
+        int rc = agt_track_frame(c, d_frames + (size_t)k * frame_stride, pitch, batch_stride, B,
+                                 d_state_out ? d_state_out + (size_t)k * B * AGT_STATE_STRIDE : nullptr);
+        if (rc) return rc;
+    }
+    return AGT_OK;
 }
 
 int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }

@@ -19,7 +19,7 @@ struct AgtPyrArgs {
     int pad;
 };
 
-#define AGT_MAX_GROUP 8          // frames one fused launch may advance each pipeline stage by
+#define AGT_MAX_GROUP 32         // frames one fused launch may advance each pipeline stage by (the per-frame tables are kernel arguments: 7.4 KB with the parameters)
 
 struct AgtLkParams {
     AgtLevel prev[AGT_MAX_LEVELS];
@@ -87,7 +87,7 @@ struct AgtTrackState {
     int pad[2];
 };
 
-// one fused launch (agt_step.hip): block ranges [PnP | LK | pyr stage 0 | stage 1 | ..]; every role advances
+// one fused launch (agt_step.hip): block ranges [LK | PnP | pyr stage 0 | stage 1 | ..]; every role advances
 // by up to AGT_MAX_GROUP consecutive frames (the LK and PnP roles loop over them inside the launch: their
 // chains are serial across frames; the pyramid stages treat the frames as a batch)
 struct AgtStepParams {
@@ -111,11 +111,14 @@ struct AgtLkTables {
     const uint8_t* img[AGT_MAX_GROUP + 1][AGT_MAX_LEVELS];     // image k of the group per level (k = 0: the frame before it)
     float* next[AGT_MAX_GROUP];                                // frame k+1's corners / status
     uint8_t* status[AGT_MAX_GROUP];
+    unsigned* done[AGT_MAX_GROUP];                             // chained launch: arrival counters of frame k+1 ([B], one count per corner) or null
 };
 struct AgtPnpTables {
     const float* img[AGT_MAX_GROUP];                           // per frame: corners, LK status, caller's state record
     const uint8_t* mask[AGT_MAX_GROUP];
     double* so[AGT_MAX_GROUP];
+    const unsigned* wait[AGT_MAX_GROUP];                       // chained launch: the frame's LK arrival counters ([B]) or null = complete before the launch
+    unsigned long long target[AGT_MAX_GROUP];                  // counter value that means "all corners of the frame are written"
 };
 struct AgtStepTables {
     const uint8_t* pyr_src[AGT_MAX_LEVELS - 1][AGT_MAX_GROUP];

@@ -208,7 +208,29 @@ struct LkFrameIo {
     bool grouped;
     const float* prev_pts; float* next_pts; uint8_t* status; float* err;
     bool have_pos; float px, py; int pst;       // pst: the corner's status after the previous frame (with have_pos)
+    unsigned* done = nullptr;                   // chained launch (agt_step.hip): arrival counters of this frame, [B]; see lk_publish
 };
+
+// The frame's result for one corner (called by one lane).  In a chained launch the PnP role of the SAME launch picks the
+// corners up as soon as the frame's counter reaches the corner count, from a workgroup on another XCD (another L2): the
+// result is written with device-scope stores (write-through past the L2) and the arrival is counted only after every one of
+// them has been acknowledged.
+template <int NLEV>
+__device__ __forceinline__ void lk_publish(const LkFrameIo<NLEV>& io, long pidx, int b, float x, float y, int st, float errv)
+{
+    if (io.done) {
+        __hip_atomic_store(io.next_pts + pidx * 2, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(io.next_pts + pidx * 2 + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(io.status + pidx, (uint8_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (io.err) io.err[pidx] = errv;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __hip_atomic_fetch_add(io.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        return;
+    }
+    io.next_pts[pidx * 2] = x; io.next_pts[pidx * 2 + 1] = y;
+    io.status[pidx] = (uint8_t)st;
+    if (io.err) io.err[pidx] = errv;
+}
 
 // Track corner `pt` of stream `b` through one frame.  Called by all 64*NW threads of a workgroup; lds:
 // lk_lds_bytes, 16-B aligned.  Returns the new position in (ox, oy) (identical in every thread).
@@ -260,11 +282,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         if (io.have_pos) pst = io.pst;
         else if (P->prev_status) pst = P->prev_status[pidx];
         if (!agt_uniform(pst)) {
-            if (tid == 0) {
-                io.next_pts[pidx * 2] = ppx; io.next_pts[pidx * 2 + 1] = ppy;
-                io.status[pidx] = 0;
-                if (io.err) io.err[pidx] = 0.f;
-            }
+            if (tid == 0) lk_publish(io, pidx, b, ppx, ppy, 0, 0.f);
             ox = ppx; oy = ppy; ost = 0;
             return;
         }
@@ -472,12 +490,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     }
 
     STAMP(3);
-    if (tid == 0) {
-        io.next_pts[pidx * 2] = outx;
-        io.next_pts[pidx * 2 + 1] = outy;
-        io.status[pidx] = (uint8_t)st;
-        if (io.err) io.err[pidx] = errv;
-    }
+    if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
     ox = outx; oy = outy; ost = st;
 }
 

@@ -476,12 +476,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     }
 
     STAMP(3);
-    if (tid == 0) {
-        io.next_pts[pidx * 2] = outx;
-        io.next_pts[pidx * 2 + 1] = outy;
-        io.status[pidx] = (uint8_t)st;
-        if (io.err) io.err[pidx] = errv;
-    }
+    if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
     ox = outx; oy = outy; ost = st;
 }
 

@@ -46,7 +46,7 @@ struct PnpShared {
     double tot[NACC + 4];
     double LL[144];
     double vec[48];
-    unsigned long long tab[3 * AGT_MAX_GROUP];     // fused step: copy of AgtStepParams::pnp_img / pnp_mask / pnp_so
+    unsigned long long tab[5 * AGT_MAX_GROUP];     // fused step: copy of AgtPnpTables (img / mask / so / wait / target per frame)
 };
 
 // sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
@@ -456,7 +456,7 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
 // Solve problem `b`.  Called by ONE wave (threadIdx.x < 64 of its workgroup); sh: that workgroup's scratch.
 template <typename T, int PPL>
 __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
-                                         double* so_p)
+                                         double* so_p, int extra_flags = 0)
 {
     const int lane = threadIdx.x;
     const int n = P.n;
@@ -483,7 +483,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         }
     }
     const int n_used = (int)agt_wave_sum_i64(cnt);
-    int flags = 0;
+    int flags = extra_flags;          // AGT_TRK_CHAIN_TIMEOUT from the chained launch, reported with the frame's record
     double param[6];
     AgtTrackState* ts = P.track ? P.track + b : nullptr;
     bool use_guess = P.use_guess != 0;
@@ -509,7 +509,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 if (so_p) {
                     double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
+                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW | flags;
                 }
             }
             return;
@@ -829,7 +829,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 if (so_p) {
                     double* so = so_p + (long)b * AGT_STATE_STRIDE;
                     for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
-                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW;
+                    so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_PNP_TOO_FEW | flags;
                 }
             }
             return;

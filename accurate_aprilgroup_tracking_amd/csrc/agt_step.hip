@@ -90,12 +90,12 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         if (k == 0) {
 #pragma unroll
             for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
-            io.next_pts = T.lk.next[0]; io.status = T.lk.status[0];
+            io.next_pts = T.lk.next[0]; io.status = T.lk.status[0]; io.done = T.lk.done[0];
         } else {
             agt_lk::block_sync<NW>();          // the previous frame's LDS tiles are free again; the table copy is visible
 #pragma unroll
             for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
-            io.next_pts = tab->next[k]; io.status = tab->status[k];
+            io.next_pts = tab->next[k]; io.status = tab->status[k]; io.done = tab->done[k];
         }
         if constexpr (WIN == 21 && NW == 1) {
             // one wave per corner: the row-segment body while the window stays inside the image and the corner is alive
@@ -158,23 +158,47 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
 // ---- PnP role: one wave per stream, consecutive frames: frame k+1 starts from the tracker state frame k left in
 // global memory (written and read by this one wave; the barrier orders the two).  Frames 2.. read their pointers
 // from an LDS copy of the tables requested up front (see the LK role).
+// Chained launch: a frame whose corners come from the LK role of THIS launch carries the address of its arrival counter;
+// the wave waits until the counter reaches the frame's corner count (every lk_publish of the frame has been acknowledged by
+// memory), then drops whatever its own L1 / L2 hold of the corner arrays (acquire at device scope).  The LK workgroups
+// have lower indices than this one, so they were dispatched before it and never wait for anything themselves; should the
+// count still not arrive within 20 ms the frame is solved on what is there and flagged AGT_TRK_CHAIN_TIMEOUT, and the
+// remaining frames of the launch do not wait again -- the launch always drains.
 template <int PPL>
 __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
 {
-    static_assert(sizeof(AgtPnpTables) == 24 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
-    if (S.pnp_nf > 1 && threadIdx.x < sizeof(AgtPnpTables) / 4)
-        reinterpret_cast<uint32_t*>(sh.tab)[threadIdx.x] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[threadIdx.x];
+    static_assert(sizeof(AgtPnpTables) == 40 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
+    if (S.pnp_nf > 1)
+        for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE)
+            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+    int late = 0;
     for (int k = 0; k < S.pnp_nf; k++) {
         const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
+        const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
         if (k) {
             __syncthreads();
             img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
+            wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
         }
-        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so);
+        if (wait) {
+            if (!late) {
+                int timed_out = 0;
+                if (threadIdx.x == 0) {
+                    const unsigned long long t0 = wall_clock64();               // 100 MHz
+                    while ((int)(__hip_atomic_load(wait + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (wall_clock64() - t0 > 2000000ull) { timed_out = 1; break; }
+                    }
+                }
+                late = agt_uniform(__shfl(timed_out, 0));
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so, late ? AGT_TRK_CHAIN_TIMEOUT : 0);
     }
 }
 
-// One heterogeneous launch: block ranges [PnP | LK | pyr stage 0 | stage 1 | ..].
+// One heterogeneous launch: block ranges [LK | PnP | pyr stage 0 | stage 1 | ..].
 // OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).
 template <int WIN, int NW, int NLEV, bool PNP, int OCC>
 __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OCC))) void step_kernel(const AgtStepParams S, const AgtStepTables T)
@@ -182,18 +206,11 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     KParams KS = kernarg_params();
     KTables KT = kernarg_tables();
-    // Workgroups are dispatched in index order: the long serial chains (PnP, then LK) take the lowest
-    // indices so they start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.
+    // Workgroups are dispatched in index order: the long serial chains (LK, then PnP) take the lowest indices so they
+    // start at t = 0 and the short, bandwidth-bound pyramid tiles fill in around them.  LK comes first: in a chained
+    // launch the PnP workgroups wait for corners of the LK role, which must therefore never queue up behind them.
     int blk = blockIdx.x;
     SSTAMP_MIN(6);                                   // earliest entry of any block
-    if (PNP && blk < S.n_pnp) {
-        if (threadIdx.x >= AGT_WAVE) return;
-        if (blk == 0) SSTAMP_SET(0);
-        pnp_role<1>(S, T, KT, blk, *reinterpret_cast<agt_pnp::PnpShared*>(lds));     // fused path: n <= 64
-        if (blk == 0) SSTAMP_SET(1);
-        return;
-    }
-    if (PNP) blk -= S.n_pnp;
     if (blk < S.n_lk) {
         if (blk == 0) SSTAMP_SET(2);
         lk_role<WIN, NW, NLEV, STEP_THREADS>(S, T, KS, KT, blk, lds);
@@ -202,6 +219,14 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
         return;
     }
     blk -= S.n_lk;
+    if (PNP && blk < S.n_pnp) {
+        if (threadIdx.x >= AGT_WAVE) return;
+        if (blk == 0) SSTAMP_SET(0);
+        pnp_role<1>(S, T, KT, blk, *reinterpret_cast<agt_pnp::PnpShared*>(lds));     // fused path: n <= 64
+        if (blk == 0) SSTAMP_SET(1);
+        return;
+    }
+    if (PNP) blk -= S.n_pnp;
     pyr_role(KS, KT, blk, (PNP ? S.n_pnp : 0) + S.n_lk, lds);
     SSTAMP_MAX(5);
 }

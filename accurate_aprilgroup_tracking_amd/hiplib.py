@@ -32,7 +32,7 @@ SYMBOLS = [
     "agt_last_hip_error", "agt_synchronize", "agt_pyr_down_u8", "agt_pyramid_build",
     "agt_pyramid_level", "agt_pyramid_max_level", "agt_lk_track", "agt_solve_pnp",
     "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
-    "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_tracker_buffers",
+    "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_track_frames", "agt_tracker_buffers",
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
     "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense", "agt_upload", "agt_download",
@@ -93,6 +93,7 @@ def lib():
     L.agt_tracker_state_size.restype = i32
     L.agt_tracker_state_read.argtypes = [vp, vp, i32]
     L.agt_track_frame.argtypes = [vp, vp, sz, sz, i32, vp]
+    L.agt_track_frames.argtypes = [vp, vp, sz, sz, sz, i32, i32, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.agt_tracker_pipeline.argtypes = [vp, i32]
     L.agt_tracker_join.argtypes = [vp]

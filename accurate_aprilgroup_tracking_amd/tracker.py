@@ -78,6 +78,20 @@ class StreamTracker:
             del self._alive[0]
         return state_out
 
+    def step_many(self, clip, state_out=None):
+        """A clip of consecutive frames in one call: clip cuda u8 [K,B,H,W], state_out cuda f64 [K,B,STATE_STRIDE] or None.
+        Same as K calls of step() (same launches, same records) without the per-call host cost.  Enqueues only."""
+        assert clip.dtype == torch.uint8 and clip.is_cuda and clip.dim() == 4 and clip.shape[1] == self.B
+        K = clip.shape[0]
+        if state_out is not None:
+            assert state_out.is_contiguous() and tuple(state_out.shape) == (K, self.B, H.STATE_STRIDE)
+        H.check(self.ctx.L.agt_track_frames(self.ctx.h, _ptr(clip), clip.stride(2), clip.stride(1), clip.stride(0), self.B, K,
+                                            _ptr(state_out)), "agt_track_frames")
+        self._alive.append(clip)                  # the whole clip stays referenced while any of its frames may be in flight
+        while len(self._alive) > self._keep_frames:
+            del self._alive[0]
+        return state_out
+
     def dense_model(self, model_xyz, model_t, iters=5, photo_weight=0.05, reseed=True):
         """BASELINE configs[4]: register the dense model (cuda f32 [M,3] object-frame samples, cuda f32 [M] template
         intensities; kept alive here) -- step_dense() then refines every accepted pose photometrically on the device.

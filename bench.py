@@ -160,6 +160,7 @@ class Bench:
             self.npts, self.render_s, self.seqs, self.rendered = 48, 0.0, [], None
             self.trk = StubTracker(rank)
             self.pos = self.since = 0
+            self.clips = False
             return
         # up to 4 rendered seeds; further streams are copies at distinct HBM addresses.  The ring exceeds the 256 MiB
         # Infinity Cache, so every step reads cold addresses.
@@ -184,6 +185,7 @@ class Bench:
         sq0 = self.seqs[0]
         self.trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
         self.pos = 0            # ring index of the newest frame handed to the tracker
+        self.clips = not args.per_step_calls
         self.since = 0          # frames since the corner set was last refreshed
 
     # -- stream control
@@ -199,13 +201,21 @@ class Bench:
         self.since = 0
 
     def run(self, n, out):
-        """n steps; out: [n, B, 16] state records or None.  A detector refresh falls inside only when n > REDETECT."""
-        for k in range(n):
+        """n steps; out: [n, B, 16] state records or None.  A detector refresh falls inside only when n > REDETECT.
+        Consecutive ring entries go to the tracker as one clip (agt_track_frames: the same n steps, same launches and records
+        as n calls of step(), without ~5 us of Python per call -- a third of the device time of a 720p frame)."""
+        k = 0
+        while k < n:
             if self.since >= 2 * REDETECT:
                 self.refresh()
-            self.pos += 1
-            self.trk.step(self.ring[self.pos % self.ring_slots], out[k] if out is not None else None)
-            self.since += 1
+            a = (self.pos + 1) % self.ring_slots
+            m = min(n - k, self.ring_slots - a, 2 * REDETECT - self.since)
+            if m > 1 and self.clips:
+                self.trk.step_many(self.ring[a:a + m], out[k:k + m] if out is not None else None)
+            else:
+                m = 1
+                self.trk.step(self.ring[a], out[k] if out is not None else None)
+            self.pos += m; self.since += m; k += m
 
     # -- the measurement the contract asks for
     def timed_blocks(self, D, R):
@@ -268,13 +278,14 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
     ap.add_argument("--blocks", type=int, default=15, help="timed blocks of --steps steps each (median / p10 / p90 over them)")
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (default: the workload's)")
     ap.add_argument("--render-frames", type=int, default=24)
     ap.add_argument("--depth", type=int, default=0,
-                    help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = 8 for >= 200 timed steps, 4 for >= 100, "
-                         "2 for >= 8, else 1 (short blocks are dominated by filling and draining the pipeline; measured at 20 steps: "
-                         "43.8 k / 47.1 k / 46.1 k frames/s at depth 1 / 2 / 4)")
+                    help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = 32 for >= 200 timed steps, else "
+                         "min(steps, 16): the launches are chained (PnP follows LK inside the launch), so a short block is one or two launches "
+                         "deep (measured at 20 steps: 43.5 k / 50.7 k / 52.2 k frames/s at depth 1 / 4 / 16)")
     ap.add_argument("--dry-run", action="store_true",
                     help="TEST HOOK (CPU, gloo): launcher + rendezvous + block timing + gather with a stub tracker; the line it prints "
                          "is marked data = dry-run and is not a measurement")
@@ -305,8 +316,8 @@ def main():
     bench = Bench(torch, wl, args, rank, world, dev)
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
-    auto_depth = 8 if K >= 200 else (4 if K >= 100 else (2 if K >= 8 else 1))
-    depth = max(1, min(args.depth or (auto_depth if fused else 2), 8))       # split mode (not fused): two launches per group of `depth` frames
+    auto_depth = 32 if K >= 200 else min(K, 16)      # chained launches: a short block is one or two launches deep
+    depth = max(1, min(args.depth or (auto_depth if fused else 2), 32 if fused else 8))      # split mode (not fused): two launches per group of `depth` frames
     bench.trk.pipeline(depth)
     dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
     med, p10, p90 = percentiles(dts)
@@ -323,7 +334,7 @@ def main():
             launch_us = bench.launch_period_us(depth, M)
             launch_us_d1 = bench.launch_period_us(1, M) if depth != 1 else launch_us
             achieved = depth * B * ab["frame"] / (launch_us * 1e-6) / 1e9
-            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: PnP | LK | pyrDown, %d consecutive frames of each stage per launch)" % depth,
+            roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: LK | PnP chained to it | pyrDown of the next group, %d consecutive frames per launch)" % depth,
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth) if (B == 1 and args.workload == "c2") else None,
                     "frac_of_measured_copy_6290GBs": round(achieved / 6290.0, 6),
@@ -364,8 +375,8 @@ def main():
                "config": {"workload": wl["label"] % B, "streams_per_gpu": B,
                           "frames_resident": "HBM ring %d slots (%.0f MiB)" % (bench.ring_slots, bench.ring_slots * B * bench.W * bench.H / 2**20),
                           "parallelism": "stream-per-GPU x%d, %s all_gather of poses once per block" % (world, "gloo (REHEARSAL: ranks share GPUs)" if rehearsal else "RCCL"),
-                          "launch": ("fused software-pipelined step, %d frames per launch (record of frame t written ~%d steps later)"
-                                     % (depth, LEVELS * depth)) if fused else
+                          "launch": ("fused chained step, %d frames per launch: pyramid of the next group | LK | PnP one frame behind LK (arrival counters); "
+                                     "frames handed over as clips (agt_track_frames)%s" % (depth, " -- one call per frame" if args.per_step_calls else "")) if fused else
                                     "split pipeline: pyramid + LK launch (caller's stream) | PnP launch (library stream), %d frames per group" % depth},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5),

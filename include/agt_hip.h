@@ -78,6 +78,7 @@ extern "C" {
 #define AGT_ST_FLAGS   11   /* AGT_PNP_* bits | AGT_TRK_* bits */
 #define AGT_ST_TVEC_F32 12  /* 1.0 = tvec carries float32 precision (cv2 wrote it into the f32 guess array) */
 #define AGT_TRK_ZERO_VELOCITY 256  /* a velocity element was exactly 0: reference raises ValueError (detect_pose.py:236-237) */
+#define AGT_TRK_CHAIN_TIMEOUT 512  /* pipelined tracker: the pose solve gave up waiting (20 ms) for the frame's corners; the record is invalid */
 
 typedef struct agt_ctx agt_ctx;
 
@@ -169,18 +170,25 @@ int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const floa
  * gate_px: reprojection gate (default 2.0, detect_pose.py:539). */
 int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate_px);
 /* Software pipelining across frames.  depth 0: separate launches per stage, the record of frame t is complete
- * in stream order after its call.  depth F in 1..8 (default 1; needs reproject == 0 and at most 2048 corners in
- * flight, otherwise the call falls back to depth 0 behaviour): agt_track_frame registers the frame and, every F
- * calls, issues ONE fused launch in which every pipeline stage advances by F frames -- pyramid stage s works on
- * frames t-sF.., LK on frames t-LF.., PnP on frames t-(L+1)F.. (L = pyramid stages) -- so a step costs max(stage)
- * instead of their sum and the launch boundary is paid once per F frames; results are bit-identical to the serial
- * order.  Frame t's state record is written about (L+2)*F calls later; agt_tracker_join enqueues the remaining
- * stages of all supplied frames (no host synchronisation) and agt_synchronize joins and waits.  Frames handed to
- * agt_track_frame must stay valid and unmodified until their pose has been produced ((L+2)*F + F frames are in
- * flight at most), and the frames of one group must share pitch and batch stride.  Changing the depth joins first.
- * With more than 2048 corners in flight (depth >= 1) the same pipeline runs as TWO launches per group: the pyramid and LK
- * roles on the context's stream, the PnP role (its FP64 register budget) on a library-owned stream, ordered by two events per
- * group; agt_tracker_join makes the context's stream wait for the library's.  Frame lifetime is the same as above. */
+ * in stream order after its call.  depth F in 1..32 (default 1; needs reproject == 0, otherwise the call falls back to
+ * depth 0 behaviour): agt_track_frame registers the frame and, every F calls, issues ONE fused launch that advances every
+ * pipeline stage by F frames, stages of different frames side by side in disjoint workgroup ranges: the pyramid of
+ * frames t-F+1..t, the LK of the F frames before those, and the pose solves.  Up to 2048 corners in flight the launch is
+ * CHAINED: its PnP workgroups follow its LK workgroups frame by frame through per-frame arrival counters in device
+ * memory (the LK role counts each corner in after a write-through store of its result; the PnP wave of the stream polls
+ * the frame's counter, then acquires) -- one frame behind the LK role while frames keep coming, so neither role ever
+ * stalls, and right behind it in the launches agt_tracker_join issues, so the last record of a clip is complete one LK
+ * + one PnP latency after its pyramid.  A wait that is not satisfied within 20 ms gives up and flags the record
+ * AGT_TRK_CHAIN_TIMEOUT (the LK workgroups have lower indices than the waiting ones and wait for nothing themselves, so
+ * this needs a fault elsewhere).  A step costs max(stage) instead of their sum and the launch boundary is paid once
+ * per F frames; results are bit-identical to the serial order.  Frame t's state record is written up to (L+2)*F calls
+ * later; agt_tracker_join enqueues the remaining stages of all supplied frames (no host synchronisation) and
+ * agt_synchronize joins and waits.  Frames handed to agt_track_frame must stay valid and unmodified until their pose
+ * has been produced ((L+2)*F + F frames are in flight at most), and the frames of one group must share pitch and batch
+ * stride.  Changing the depth joins first.
+ * With more than 2048 corners in flight (depth >= 1) the same pipeline runs as one launch per role and
+ * group: the pyramid role on the context's stream, the LK and PnP roles on two library-owned streams, ordered by events
+ * (PnP one group behind LK); agt_tracker_join makes the context's stream wait for the library's.  Frame lifetime as above. */
 int agt_tracker_pipeline(agt_ctx* ctx, int depth);
 int agt_tracker_join(agt_ctx* ctx);
 /* PoseDetector._estimate_pose (detect_pose.py:467-574) for B streams with device-resident
@@ -197,6 +205,12 @@ int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronis
  * (device memory; read it back whenever convenient).  No host synchronisation. */
 int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out);
+/* A clip: `count` consecutive frames of the B streams in one call, frame k at d_frames + k * frame_stride (bytes), its
+ * record at d_state_out + k * B * AGT_STATE_STRIDE (or NULL).  Exactly `count` calls of agt_track_frame, made without the
+ * per-call host cost (at ~16 us of device time per 720p frame a Python caller's ~5 us per call is a third of the budget):
+ * same pipeline, same launches, same records. */
+int agt_track_frames(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
+                     double* d_state_out);
 /* ---- frame pre-processing (the step right before the path) ---- */
 /* cv.getOptimalNewCameraMatrix(K, dist, (w,h), alpha, (new_w,new_h)) -- host arithmetic only
  * (detect_pose.py:167-173).  newK: 9 doubles out, roi: {x, y, w, h} out (may be NULL). */
