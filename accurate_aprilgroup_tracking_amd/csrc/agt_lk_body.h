@@ -89,7 +89,10 @@ __device__ __noinline__ uint32_t load_dword_reflect(const uint8_t* __restrict__ 
 // Tile = rows [ty0, ty0+TH) x the NDW aligned dwords starting at (tx0 & ~3); pixel (x, y) lands at
 // s[(y - ty0) * (4*NDW) + (x - (tx0 & ~3))].  Loads and LDS stores are split so that every
 // level's loads are in flight together.
-template <int TH, int NDW, int T, int N>
+// INL: the border path is expanded in place.  A call in the path makes the compiler assume at every later merge point that
+// loads of unknown registers are outstanding (s_waitcnt vmcnt(0) before the next VALU write), which serialises a caller
+// that keeps loads in flight across such a point (agt_lk_chain_body.h prefetches the next frame's tiles).
+template <int TH, int NDW, int T, int N, bool INL = false>
 __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ img, int w, int h, long pitch,
                                           int tx0, int ty0, int tid, uint32_t (&v)[N])
 {
@@ -103,7 +106,20 @@ __device__ __forceinline__ void tile_load(const uint8_t* __restrict__ img, int w
             const int gy = agt_reflect101(ty0 + r, h);
             const int gx = ax0 + 4 * c4;
             const uint8_t* row = img + (long)gy * pitch;
-            v[k] = (gx >= 0 && gx + 3 < w) ? *reinterpret_cast<const uint32_t*>(row + gx) : load_dword_reflect(row, gx, w);
+            if (INL) {
+                // (explicitly GLOBAL loads: while a FLAT load is outstanding, every wait for LDS data also waits for it)
+                typedef const __attribute__((address_space(1))) uint8_t* G8;
+                typedef const __attribute__((address_space(1))) uint32_t* G32;
+                const G8 grow = (G8)row;
+                if (gx >= 0 && gx + 3 < w) v[k] = *(G32)(grow + gx);
+                else {
+                    uint32_t t = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; q++) t |= (uint32_t)grow[agt_reflect101(gx + q, w)] << (8 * q);
+                    v[k] = t;
+                }
+            } else
+                v[k] = (gx >= 0 && gx + 3 < w) ? *reinterpret_cast<const uint32_t*>(row + gx) : load_dword_reflect(row, gx, w);
         }
     }
 }
@@ -215,16 +231,30 @@ struct LkFrameIo {
 // corners up as soon as the frame's counter reaches the corner count, from a workgroup on another XCD (another L2): the
 // result is written with device-scope stores (write-through past the L2) and the arrival is counted only after every one of
 // them has been acknowledged.
+// count the corner in: every store of the calling lane has been acknowledged first (lk_publish_stores of this frame)
+__device__ __forceinline__ void lk_arrive(unsigned* done, int b)
+{
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __hip_atomic_fetch_add(done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// chained launch, first half of lk_publish: the device-scope stores only; the caller counts the corner in (lk_arrive, same
+// lane) once it can wait for their acknowledgement without standing still -- a write-through to HBM takes ~0.8 us
+template <int NLEV>
+__device__ __forceinline__ void lk_publish_stores(const LkFrameIo<NLEV>& io, long pidx, float x, float y, int st)
+{
+    __hip_atomic_store(io.next_pts + pidx * 2, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(io.next_pts + pidx * 2 + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(io.status + pidx, (uint8_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int NLEV>
 __device__ __forceinline__ void lk_publish(const LkFrameIo<NLEV>& io, long pidx, int b, float x, float y, int st, float errv)
 {
     if (io.done) {
-        __hip_atomic_store(io.next_pts + pidx * 2, x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(io.next_pts + pidx * 2 + 1, y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(io.status + pidx, (uint8_t)st, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lk_publish_stores(io, pidx, x, y, st);
         if (io.err) io.err[pidx] = errv;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __hip_atomic_fetch_add(io.done + b, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        lk_arrive(io.done, b);
         return;
     }
     io.next_pts[pidx * 2] = x; io.next_pts[pidx * 2 + 1] = y;

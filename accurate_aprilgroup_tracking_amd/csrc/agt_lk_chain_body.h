@@ -1,0 +1,524 @@
+// agt_lk_chain_body.h -- the LK role of the fused step when one corner has a whole workgroup (four waves): ALL frames of a
+// launch group are tracked by the same workgroup, and what one frame leaves behind is what the next one starts from.
+//
+// Same arithmetic as agt_lk_body.h (cv::calcOpticalFlowPyrLK, bit-identical to oracle/cv_lk.c), different schedule.  One
+// frame of the general body is a serial chain of ~16 us: tile loads (3 us), then per level Scharr -> patch + covariance sums
+// (1.35 us, three barriers) and the iterations (~1 us each).  Here:
+//   * the previous image's tiles are never loaded twice: frame k+1 differentiates image k, and image k is already in LDS
+//     as frame k's 40 x 40 search tiles -- the 24 x 24 neighbourhood of the tracked position lies inside them unless the
+//     corner moved more than ~8 px at that level (then the tile is re-staged).  Two tile buffers alternate;
+//   * the NEXT frame's search tiles are requested when the last level of THIS frame starts iterating, centred on the
+//     estimate of that moment (the 9 px margin absorbs the last corrections): the HBM latency runs under the iterations;
+//   * the image-k side of all levels (Scharr, interpolated patch, covariance sums, their inverse) does not depend on the
+//     flow, so it is evaluated for every level at once: two barriers and one cross-wave sum per frame instead of three of
+//     each, with three independent levels per thread in flight.
+// Only what the fused tracker uses is covered: flags == 0, no error output (lk_role falls back to lk_body otherwise).
+#pragma once
+#include "agt_lk_body.h"
+
+// Timeline of corner 0 over the first four frames of a launch (diagnostic build only: -DAGT_STEP_STAMPS; tools/chainstamps.py)
+#ifdef AGT_STEP_STAMPS
+__device__ unsigned long long agt_chain_stamps[4 * 16];
+__device__ unsigned agt_chain_counts[8];      // corner-frames | with a previous-image tile reload | with a search tile load | re-stages | iterations
+#define CCOUNT(i, n) do { if (threadIdx.x == 0) atomicAdd(&agt_chain_counts[i], (unsigned)(n)); } while (0)
+#define CSTAMP(i) do { if (pidx == 0 && threadIdx.x == 0 && k < 4) agt_chain_stamps[k * 16 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int agt_debug_chain_stamps(unsigned long long* host64)
+{
+    return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(agt_chain_stamps), sizeof(agt_chain_stamps));
+}
+extern "C" int agt_debug_chain_counts(unsigned* host8)
+{
+    return (int)hipMemcpyFromSymbol(host8, HIP_SYMBOL(agt_chain_counts), sizeof(agt_chain_counts));
+}
+#else
+#define CSTAMP(i)
+#define CCOUNT(i, n)
+#endif
+
+namespace agt_lk {
+
+template <int NLEV>
+struct ChainCfg {
+    using C = LkCfg<21, 4>;
+    static constexpr int TILE = C::JT * C::JP;                          // one search tile (40 rows x 44 B)
+    static constexpr int SD = ((C::DW * C::DW + 3) & ~3) * 4;           // one derivative tile (22 x 22 ints)
+    static constexpr int OFF_SD = 2 * NLEV * TILE;
+    static constexpr int OFF_SLOTS = OFF_SD + NLEV * SD;                // iteration sums: [2 phases][4 waves][4] long long
+    static constexpr int OFF_RED = OFF_SLOTS + 2 * 4 * 4 * 8;           // covariance partials: [3 * NLEV][256 threads] int
+    static constexpr int OFF_LVL = OFF_RED + 3 * NLEV * 256 * 4;        // per level: A11, A12, A22, 1 / det, usable (8 floats)
+    static constexpr int BYTES = OFF_LVL + NLEV * 8 * 4;
+    static_assert(TILE % 16 == 0 && SD % 16 == 0, "16-byte aligned LDS sections");
+};
+
+template <int NLEV>
+__host__ __device__ constexpr size_t lk_chain_lds_bytes() { return (size_t)ChainCfg<NLEV>::BYTES; }
+
+// a[i] for a small per-level array and a run-time level, as a chain of selects (callers make the result uniform again).  Each candidate passes through
+// an empty asm statement: left as plain loads, the selects are folded into ONE load with a run-time index, which pins the
+// array (and every neighbour the compiler packs with it) in scratch memory.
+template <int N, typename V>
+__device__ __forceinline__ V pick(const V (&a)[N], int i)
+{
+    V r = a[0];
+    asm("" : "+v"(r));
+#pragma unroll
+    for (int l = 1; l < N; l++) {
+        V t = a[l];
+        asm("" : "+v"(t));
+        r = (i == l) ? t : r;
+    }
+    return r;
+}
+
+// LDS-only workgroup barrier: the plain __syncthreads() also waits for every outstanding GLOBAL load of the wave, which would
+// put the prefetched tiles of the next frame back on the critical path of the first iteration after their request
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+// 64-lane int32 sum (no overflow checks: callers bound the operands), wave-uniform result
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+    v += agt_dpp_i32<0xB1>(v);
+    v += agt_dpp_i32<0x4E>(v);
+    v += agt_dpp_i32<0x141>(v);
+    v += agt_dpp_i32<0x140>(v);
+    return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// The two mismatch sums of one iteration over the four waves, as the floats the 2 x 2 solve needs.  Exact: every operand is
+// split v = 65536 * hi + lo (|v| < 2^26 per thread), the hi and lo parts are summed separately in int32 (|sum hi| < 2^18,
+// sum lo < 2^24 over 256 threads), and fmaf(hi, 65536, lo) rounds the exact total once -- the same float as
+// (float)(double)(int64 total) in block_sum_exact's caller.  v_permlane32_swap puts both sums in one DPP chain (value 0 in
+// the lower half-wave, value 1 in the upper one).
+__device__ __forceinline__ void iter_sum2(const int (&v)[2], float& f0, float& f1, int* slots, int& phase, int wave, int lane)
+{
+    const auto swl = __builtin_amdgcn_permlane32_swap((unsigned)(v[0] & 0xffff), (unsigned)(v[1] & 0xffff), false, false);
+    const auto swh = __builtin_amdgcn_permlane32_swap((unsigned)(v[0] >> 16), (unsigned)(v[1] >> 16), false, false);
+    int xl = (int)swl[0] + (int)swl[1], xh = (int)swh[0] + (int)swh[1];
+    xl += agt_dpp_i32<0xB1>(xl); xh += agt_dpp_i32<0xB1>(xh);
+    xl += agt_dpp_i32<0x4E>(xl); xh += agt_dpp_i32<0x4E>(xh);
+    xl += agt_dpp_i32<0x141>(xl); xh += agt_dpp_i32<0x141>(xh);
+    xl += agt_dpp_i32<0x140>(xl); xh += agt_dpp_i32<0x140>(xh);
+    // (finishing the sums with row_bcast DPP steps and a store from lanes 31 / 63 measured 11 % slower than the read-lanes)
+    const int l0 = __builtin_amdgcn_readlane(xl, 0) + __builtin_amdgcn_readlane(xl, 16), l1 = __builtin_amdgcn_readlane(xl, 32) + __builtin_amdgcn_readlane(xl, 48);
+    const int h0 = __builtin_amdgcn_readlane(xh, 0) + __builtin_amdgcn_readlane(xh, 16), h1 = __builtin_amdgcn_readlane(xh, 32) + __builtin_amdgcn_readlane(xh, 48);
+    int4* s = reinterpret_cast<int4*>(slots) + phase * 4;
+    if (lane == 0) s[wave] = make_int4(l0, h0, l1, h1);
+    lds_barrier();
+    const int4 a = s[0], b = s[1], c = s[2], d = s[3];
+    f0 = fmaf((float)(a.y + b.y + c.y + d.y), 65536.f, (float)(a.x + b.x + c.x + d.x));
+    f1 = fmaf((float)(a.w + b.w + c.w + d.w), 65536.f, (float)(a.z + b.z + c.z + d.z));
+    phase ^= 1;
+}
+
+// Request one 40 x 44 B tile (origin tx0, ty0) into registers.  A tile that lies inside the image (wave-uniform test; nearly
+// always) costs one multiply-add and one global load per dword: (row, 4 * column) of this thread's dwords are computed once
+// per kernel, the base address is scalar.  Otherwise the general, reflecting tile_load.
+template <int N>
+__device__ __forceinline__ void tile_request(const uint8_t* img, int w, int h, long pitch, int tx0, int ty0, int tid,
+                                             const int (&tr)[N], const int (&tc)[N], const bool (&tv)[N], uint32_t (&v)[N])
+{
+    using C = LkCfg<21, 4>;
+    const int ax0 = tx0 & ~3;
+    if (agt_uniform((int)(ax0 >= 0 && ax0 + 4 * C::JNDW <= w && ty0 >= 0 && ty0 + C::JT <= h))) {
+        typedef const __attribute__((address_space(1))) uint8_t* G8;
+        typedef const __attribute__((address_space(1))) uint32_t* G32;
+        const G8 base = (G8)img + (long)ty0 * pitch + ax0;
+        const int p32 = (int)pitch;
+#pragma unroll
+        for (int k = 0; k < N; k++) {
+            v[k] = 0;
+            if (tv[k]) v[k] = *(G32)(base + (tr[k] * p32 + tc[k]));
+        }
+    } else {
+        tile_load<C::JT, C::JNDW, C::T, N, true>(img, w, h, pitch, tx0, ty0, tid, v);
+    }
+}
+
+// frame(k) -> LkFrameIo<NLEV> of frame k of the group (image pointers, outputs, arrival counter)
+template <int NLEV, typename PP, typename FrameFn>
+__device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, int nf, FrameFn&& frame)
+{
+    constexpr int WIN = 21, NW = 4;
+    using C = LkCfg<WIN, NW>;
+    using K = ChainCfg<NLEV>;
+    constexpr int T = C::T, JP = C::JP, JT = C::JT, DW = C::DW, MARGIN = C::MARGIN;
+    constexpr int SRC_PAD = (JT - C::IW) / 2;                   // 8: the 24 x 24 neighbourhood centred in a 40 x 40 tile
+    const int tid = (int)threadIdx.x, lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
+    const long pidx = (long)b * P->n + pt;
+    const int maxl = P->max_level;
+    int* sDall = reinterpret_cast<int*>(lds + K::OFF_SD);
+    int* slots = reinterpret_cast<int*>(lds + K::OFF_SLOTS);      // [2 phases][4 waves] int4
+    int* red = reinterpret_cast<int*>(lds + K::OFF_RED);
+    float* lvl = reinterpret_cast<float*>(lds + K::OFF_LVL);
+    int phase = 0;
+
+    // this thread's window pixels / derivative positions as offsets into a 44-B-pitch tile resp. the 22-int-pitch derivative
+    // tile (threads without a k-th element point at offset 0 and are masked arithmetically)
+    int oW[C::NPX], oD[C::NPX], oC[C::NSD], iD[C::NSD], dX[C::NSD], dY[C::NSD];
+    bool pv[C::NPX], dv[C::NSD];
+#pragma unroll
+    for (int k = 0; k < C::NPX; k++) {
+        const int p = tid + k * T;
+        pv[k] = p < WIN * WIN;
+        const int y = pv[k] ? p / WIN : 0, x = pv[k] ? p - y * WIN : 0;
+        oW[k] = y * JP + x; oD[k] = y * DW + x;
+    }
+#pragma unroll
+    for (int k = 0; k < C::NSD; k++) {
+        const int idx = tid + k * T;
+        dv[k] = idx < DW * DW;
+        const int dyy = dv[k] ? idx / DW : 0, dxx = dv[k] ? idx - dyy * DW : 0;
+        oC[k] = dyy * JP + dxx; iD[k] = dyy * DW + dxx; dX[k] = dxx; dY[k] = dyy;
+    }
+
+    int tr[C::JLD], tc[C::JLD];                // (row, byte column) of this thread's dwords of a 40 x 44 B tile
+    bool tv[C::JLD];
+#pragma unroll
+    for (int k = 0; k < C::JLD; k++) {
+        const int i = tid + k * T;
+        tv[k] = i < JT * C::JNDW;
+        tr[k] = tv[k] ? i / C::JNDW : 0; tc[k] = tv[k] ? 4 * (i - tr[k] * C::JNDW) : 0;
+    }
+
+    int toff[NLEV][C::JLD];                    // the same as byte offsets inside each level's image
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) {
+        const int p32 = l <= maxl ? (int)P->next[l].pitch : 0;
+#pragma unroll
+        for (int k = 0; k < C::JLD; k++) toff[l][k] = tr[k] * p32 + tc[k];
+    }
+
+    const float halfw = (WIN - 1) * 0.5f;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float eps2_lo = (float)(P->eps2 * (1.0 - 1e-6)), eps2_hi = (float)(P->eps2 * (1.0 + 1e-6));
+
+    // ---- state carried from frame to frame (all wave-uniform)
+    float px = 0.f, py = 0.f;
+    int pst = 1;
+    int cur = 0;                               // tile buffer that holds THIS frame's search tiles (image k); cur ^ 1: image k-1
+    int jox[NLEV], joy[NLEV], sox[NLEV], soy[NLEV];        // tile origins (x as requested, the stored tile starts at x & ~3)
+    int jmask = 0, smask = 0;                  // levels whose tile in buf[cur] / buf[cur ^ 1] is valid
+    unsigned* owed = nullptr;                  // arrival counter of the previous frame, not yet counted into (see the frame's end)
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) { jox[l] = joy[l] = sox[l] = soy[l] = 0; }
+
+    for (int k = 0; k < nf; k++) {
+        if (k) lds_barrier();                  // everyone is done with the previous frame's LDS; the table copy is visible
+        const LkFrameIo<NLEV> io = frame(k);
+        if (k == 0) {
+            px = io.prev_pts[pidx * 2]; py = io.prev_pts[pidx * 2 + 1];
+            pst = P->prev_status ? (int)P->prev_status[pidx] : 1;
+            px = agt_uniform(px); py = agt_uniform(py); pst = agt_uniform(pst);
+        }
+#ifdef AGT_STEP_STAMPS
+        if (pidx == 0 && threadIdx.x == 0 && k < 4) agt_chain_stamps[k * 16 + 14] = 0;
+#endif
+        CSTAMP(0);
+        if (!pst) {                            // sticky: a lost corner stays lost, position carried (see lk_body)
+            if (tid == 0) {
+                if (owed) lk_arrive(owed, b);
+                lk_publish(io, pidx, b, px, py, 0, 0.f);
+            }
+            owed = nullptr;
+            jmask = smask = 0;
+            continue;
+        }
+
+        // ---- geometry of the image-(k-1) side (straight-line code: the levels are independent and meant to overlap); tiles
+        // that are not in LDS yet (first frame of the group, a corner that moved ~8 px at a level)
+        int ipx[NLEV], ipy[NLEV];
+        float fa[NLEV], fb[NLEV];              // bilinear fractions of the previous position
+        int lvA = 0, needI = 0, needJ = 0;
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            const float scale = 1.f / (float)(1 << l);
+            const float prevx = px * scale - halfw, prevy = py * scale - halfw;
+            ipx[l] = agt_uniform((int)floorf(prevx)); ipy[l] = agt_uniform((int)floorf(prevy));
+            fa[l] = prevx - (float)ipx[l]; fb[l] = prevy - (float)ipy[l];
+            const int w = P->prev[l].w, h = P->prev[l].h;
+            const bool a = l <= maxl && !(ipx[l] < -WIN || ipx[l] >= w || ipy[l] < -WIN || ipy[l] >= h);
+            const bool inside = ((smask >> l) & 1) && ipx[l] - 1 >= sox[l] && ipx[l] - 1 + C::IW <= sox[l] + JT &&
+                                ipy[l] - 1 >= soy[l] && ipy[l] - 1 + C::IW <= soy[l] + JT;
+            lvA |= a ? 1 << l : 0;
+            needI |= (a && !inside) ? 1 << l : 0;
+            needJ |= (a && !((jmask >> l) & 1)) ? 1 << l : 0;
+        }
+        CCOUNT(0, 1); CCOUNT(1, needI != 0); CCOUNT(2, needJ != 0);
+        if (agt_uniform(needI | needJ)) {
+            uint32_t ti[NLEV][C::JLD], tj[NLEV][C::JLD];
+#pragma unroll
+            for (int l = 0; l < NLEV; l++) {
+                if ((needI >> l) & 1) {
+                    const AgtLevel LI = get_level(P->prev[l]);
+                    sox[l] = ipx[l] - 1 - SRC_PAD; soy[l] = ipy[l] - 1 - SRC_PAD;
+                    tile_request(io.imgI[l] + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, sox[l], soy[l], tid, tr, tc, tv, ti[l]);
+                }
+                if ((needJ >> l) & 1) {
+                    const AgtLevel LJ = get_level(P->next[l]);
+                    jox[l] = ipx[l] - MARGIN; joy[l] = ipy[l] - MARGIN;           // centred on the initial guess = previous position
+                    tile_request(io.imgJ[l] + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jox[l], joy[l], tid, tr, tc, tv, tj[l]);
+                }
+            }
+            CSTAMP(1);
+#pragma unroll
+            for (int l = 0; l < NLEV; l++) {
+                if ((needI >> l) & 1) tile_store<JT, C::JNDW, T>(lds + ((cur ^ 1) * NLEV + l) * K::TILE, tid, ti[l]);
+                if ((needJ >> l) & 1) tile_store<JT, C::JNDW, T>(lds + (cur * NLEV + l) * K::TILE, tid, tj[l]);
+            }
+            smask |= needI; jmask |= needJ;
+            block_sync<NW>();
+        }
+        CSTAMP(2);
+
+        // where each level's window starts inside its image-(k-1) tile (a level without a window points at a harmless spot)
+        int offS[NLEV];
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            const int inside = (ipy[l] - soy[l]) * JP + (ipx[l] - (sox[l] & ~3));
+            offS[l] = ((cur ^ 1) * NLEV + l) * K::TILE + (((lvA >> l) & 1) ? inside : JP + 4);
+        }
+
+        // ---- image-(k-1) side of every level: Scharr -> derivative tiles
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            const int w = P->prev[l].w, h = P->prev[l].h;
+            const uint8_t* s0 = lds + offS[l];
+            int* sD = sDall + l * (K::SD / 4);
+#pragma unroll
+            for (int q = 0; q < C::NSD; q++) {
+                const int gx = ipx[l] + dX[q], gy = ipy[l] + dY[q];
+                const uint8_t* c = s0 + oC[q];
+                const int v00 = c[-JP - 1], v01 = c[-JP], v02 = c[-JP + 1];
+                const int v10 = c[-1], v12 = c[1];
+                const int v20 = c[JP - 1], v21 = c[JP], v22 = c[JP + 1];
+                const int dx = (3 * (v02 + v22) + 10 * v12) - (3 * (v00 + v20) + 10 * v10);
+                const int dy = 3 * ((v20 - v00) + (v22 - v02)) + 10 * (v21 - v01);
+                // the derivative image has a ZERO (BORDER_CONSTANT) border
+                const int val = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? ((dx & 0xffff) | (dy << 16)) : 0;
+                if (dv[q]) sD[iD[q]] = val;
+            }
+        }
+        lds_barrier();
+        CSTAMP(3);
+
+        // ---- interpolated patch of every level (registers) + this thread's share of the covariance sums
+        int Iv[NLEV][C::NPX], Ix[NLEV][C::NPX], Iy[NLEV][C::NPX];
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            int iw00, iw01, iw10, iw11;
+            bilinear_weights(fa[l], fb[l], iw00, iw01, iw10, iw11);
+            const uint8_t* s0 = lds + offS[l];
+            const int* sD = sDall + l * (K::SD / 4);
+            int a0 = 0, a1 = 0, a2 = 0;
+#pragma unroll
+            for (int q = 0; q < C::NPX; q++) {
+                const uint8_t* p = s0 + oW[q];
+                const int iv = descale(bil4(p[0], p[1], p[JP], p[JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5);
+                const int* d = sD + oD[q];
+                const int d00 = d[0], d01 = d[1], d10 = d[DW], d11 = d[DW + 1];
+                const int ix = descale(bil4((short)d00, (short)d01, (short)d10, (short)d11, iw00, iw01, iw10, iw11), W_BITS);
+                const int iy = descale(bil4(d00 >> 16, d01 >> 16, d10 >> 16, d11 >> 16, iw00, iw01, iw10, iw11), W_BITS);
+                Iv[l][q] = pv[q] ? iv : 0; Ix[l][q] = pv[q] ? ix : 0; Iy[l][q] = pv[q] ? iy : 0;
+                a0 += __mul24(Ix[l][q], Ix[l][q]); a1 += __mul24(Ix[l][q], Iy[l][q]); a2 += __mul24(Iy[l][q], Iy[l][q]);
+            }
+            // (|a| <= 2 * 4080^2 < 2^25)
+            red[(3 * l) * T + tid] = a0; red[(3 * l + 1) * T + tid] = a1; red[(3 * l + 2) * T + tid] = a2;
+        }
+        lds_barrier();
+        // ---- wave w finishes level w (w + 4, ..): exact sums over the 256 partials, the 2 x 2 system and its eigenvalue test
+        for (int l = wave; l < NLEV; l += NW) {
+            float A[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) {
+                const int* r = red + (3 * l + i) * T + lane;
+                const int s4 = r[0] + r[64] + r[128] + r[192];                   // < 2^27
+                // exact total = 65536 * sum(hi) + sum(lo), both sums < 2^24 in magnitude: one rounding in the fma, the same
+                // float as (float)(double)(int64 total)
+                const int lo = wave_sum_i32(s4 & 0xffff), hi = wave_sum_i32(s4 >> 16);
+                A[i] = fmaf((float)hi, 65536.f, (float)lo) * FLT_SCALE;
+            }
+            const float D = A[0] * A[2] - A[1] * A[1];
+            const float minEig = (A[2] + A[0] - sqrtf((A[0] - A[2]) * (A[0] - A[2]) + 4.f * A[1] * A[1])) / (float)(2 * WIN * WIN);
+            const bool ok = ((lvA >> l) & 1) && !((double)minEig < P->min_eig_threshold || D < FLT_EPSILON);
+            if (lane == 0) {
+                float* o = lvl + l * 8;
+                o[0] = A[0]; o[1] = A[1]; o[2] = A[2]; o[3] = ok ? 1.f / D : 0.f; o[4] = ok ? 1.f : 0.f;
+            }
+        }
+        lds_barrier();
+        // the previous frame's result was stored ~3 us ago: its stores have long been acknowledged, count the corner in now
+        if (owed && tid == 0) lk_arrive(owed, b);
+        owed = nullptr;
+        CSTAMP(4);
+
+        // ---- the levels, coarse to fine: the iterations against image k
+        int st = 1;
+        float outx = 0.f, outy = 0.f;
+        bool pre = false;                      // next frame's search tiles requested
+        uint32_t tn[NLEV][C::JLD];
+        int nox[NLEV], noy[NLEV], nmask = 0;
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) { nox[l] = noy[l] = 0; }
+        for (int level = maxl; level >= 0; level--) {
+            const float scale = 1.f / (float)(1 << level);
+            float nextx, nexty;
+            if (level == maxl) { nextx = px * scale; nexty = py * scale; }
+            else { nextx = outx * 2.f; nexty = outy * 2.f; }
+            outx = nextx; outy = nexty;
+            CSTAMP(8 + level * 2);
+            if (level == 0 && k + 1 < nf) {
+                // ---- request frame k+1's search tiles (image k+1 around where this corner is about to end up).  Straight-line
+                // code, every load unconditional (a level whose tile is not wholly inside its image loads a harmless tile
+                // at the image origin and is left to the next frame's on-demand path): any branch around a load makes the
+                // compiler copy the register array at the merge, and the copy waits for the loads issued so far.
+                const LkFrameIo<NLEV> nio = frame(k + 1);
+                bool all_safe = true;
+#pragma unroll
+                for (int l = 0; l < NLEV; l++) all_safe = all_safe && (l > maxl || (4 * C::JNDW <= P->next[l].w && JT <= P->next[l].h));
+                if (agt_uniform((int)all_safe)) {
+#pragma unroll
+                    for (int l = 0; l < NLEV; l++) {
+                        typedef const __attribute__((address_space(1))) uint8_t* G8;
+                        typedef const __attribute__((address_space(1))) uint32_t* G32;
+                        const float sc = 1.f / (float)(1 << l);
+                        const int cx = agt_uniform((int)floorf(outx * sc - halfw)), cy = agt_uniform((int)floorf(outy * sc - halfw));
+                        const int w = P->next[l].w, h = P->next[l].h;
+                        const long pitch = P->next[l].pitch, bstride = P->next[l].bstride;
+                        const int ox = cx - MARGIN, oy = cy - MARGIN, ax0 = ox & ~3;
+                        const bool ok = l <= maxl && ax0 >= 0 && ax0 + 4 * C::JNDW <= w && oy >= 0 && oy + JT <= h;
+                        const int lx = ok ? ax0 : 0, ly = ok ? oy : 0;
+                        const uint8_t* img = l <= maxl ? nio.imgJ[l] : nio.imgJ[0];
+                        const G8 base = (G8)img + (long)b * (l <= maxl ? bstride : 0) + (long)ly * (l <= maxl ? pitch : 0) + lx;
+#pragma unroll
+                        for (int q = 0; q < C::JLD; q++) tn[l][q] = *(G32)(base + toff[l][q]);
+                        nox[l] = ox; noy[l] = oy;
+                        nmask |= ok ? 1 << l : 0;
+                    }
+                    pre = true;
+                }
+            }
+            if (!((lvA >> level) & 1)) { if (level == 0) st = 0; continue; }
+            const float4 lv4 = *reinterpret_cast<const float4*>(lvl + level * 8);
+            if (!agt_uniform((int)(lvl[level * 8 + 4] != 0.f))) { if (level == 0) st = 0; continue; }
+            const AgtLevel LJ = get_level(P->next[level]);
+            const uint8_t* imgJ;
+            {
+                const unsigned long long v = (unsigned long long)pick(io.imgJ, level);
+                const unsigned lo = (unsigned)agt_uniform((int)(unsigned)v), hi = (unsigned)agt_uniform((int)(unsigned)(v >> 32));
+                imgJ = (const uint8_t*)(((unsigned long long)hi << 32) | lo) + (long)b * LJ.bstride;
+            }
+            uint8_t* sJ = lds + (cur * NLEV + level) * K::TILE;
+            const float a11 = agt_uniform(lv4.x), a12 = agt_uniform(lv4.y), a22 = agt_uniform(lv4.z), D = agt_uniform(lv4.w);
+            int iv[C::NPX], ix[C::NPX], iy[C::NPX];
+#pragma unroll
+            for (int q = 0; q < C::NPX; q++) {
+                iv[q] = Iv[0][q]; ix[q] = Ix[0][q]; iy[q] = Iy[0][q];
+#pragma unroll
+                for (int l = 1; l < NLEV; l++) {
+                    iv[q] = level == l ? Iv[l][q] : iv[q]; ix[q] = level == l ? Ix[l][q] : ix[q]; iy[q] = level == l ? Iy[l][q] : iy[q];
+                }
+            }
+            int jx0 = agt_uniform(pick(jox, level)), jy0 = agt_uniform(pick(joy, level));
+
+            nextx -= halfw; nexty -= halfw;
+            float pdx = 0.f, pdy = 0.f;
+            int iw00, iw01, iw10, iw11;
+            // while the window's corner stays in this box, it is inside the image band and inside the search tile: one float
+            // test per iteration instead of the two integer ones (which remain, word for word, behind it)
+            float bx0, bx1, by0, by1;
+            auto set_box = [&]() {
+                const int lx = jx0 > -WIN ? jx0 : -WIN, hx = (jx0 + JT - WIN - 1 < LJ.w - 1 ? jx0 + JT - WIN - 1 : LJ.w - 1) + 1;
+                const int ly = jy0 > -WIN ? jy0 : -WIN, hy = (jy0 + JT - WIN - 1 < LJ.h - 1 ? jy0 + JT - WIN - 1 : LJ.h - 1) + 1;
+                bx0 = (float)lx; bx1 = (float)hx; by0 = (float)ly; by1 = (float)hy;
+            };
+            set_box();
+            for (int j = 0; j < P->max_count; j++) {
+                const float fx = floorf(nextx), fy = floorf(nexty);
+                if (!agt_uniform((int)(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1))) {
+                    const int inx = agt_uniform((int)fx), iny = agt_uniform((int)fy);
+                    if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+                        if (level == 0) st = 0;
+                        break;
+                    }
+                    if (inx < jx0 || inx + WIN >= jx0 + JT || iny < jy0 || iny + WIN >= jy0 + JT) {
+                        jx0 = inx - MARGIN; jy0 = iny - MARGIN;
+                        uint32_t t[C::JLD];
+                        block_sync<NW>();
+                        tile_load<JT, C::JNDW, T, C::JLD, true>(imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, t);
+                        tile_store<JT, C::JNDW, T>(sJ, tid, t);
+                        // every load of this (rare) path has landed -- said in a form the compiler's wait-count bookkeeping reads:
+                        // left implicit, the lanes that loaded nothing keep "a load into t may be pending" alive up to the merge
+                        // with the common path, which then waits for ALL outstanding loads (the next frame's tiles) every iteration
+                        __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0)
+                        block_sync<NW>();
+                        set_box();
+                    }
+                }
+                const int inx = (int)fx, iny = (int)fy;
+                bilinear_weights(nextx - fx, nexty - fy, iw00, iw01, iw10, iw11);
+                int bsum[2] = { 0, 0 };
+                const uint8_t* q0 = sJ + (iny - jy0) * JP + (inx - jx0) + (jx0 - (jx0 & ~3));
+#pragma unroll
+                for (int q = 0; q < C::NPX; q++) {
+                    const uint8_t* c = q0 + oW[q];
+                    const int diff = descale(bil4(c[0], c[1], c[JP], c[JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5) - iv[q];
+                    bsum[0] += __mul24(diff, ix[q]); bsum[1] += __mul24(diff, iy[q]);          // ix = iy = 0 where !pv
+                }
+                float fb1, fb2;
+                iter_sum2(bsum, fb1, fb2, slots, phase, wave, lane);
+                fb1 *= FLT_SCALE; fb2 *= FLT_SCALE;
+                const float dx = (a12 * fb2 - a22 * fb1) * D;
+                const float dy = (a12 * fb1 - a11 * fb2) * D;
+                nextx += dx; nexty += dy;
+                outx = nextx + halfw; outy = nexty + halfw;
+#ifdef AGT_STEP_STAMPS
+                if (pidx == 0 && threadIdx.x == 0 && k < 4 && level < 3) agt_chain_stamps[k * 16 + 14] += 1ull << (level * 8);
+#endif
+                // (double)dx * dx + (double)dy * dy <= eps2, evaluated in FP64 only inside a 1e-6 band around the threshold
+                const float d2 = dx * dx + dy * dy;
+                bool conv = d2 < eps2_lo;
+                if (agt_uniform((int)(!conv && !(d2 > eps2_hi)))) conv = (double)dx * dx + (double)dy * dy <= P->eps2;      // (rare)
+                if (agt_uniform((int)conv)) break;
+                // fabs((double)f) < 0.01  <=>  fabsf(f) <= 0.01f  (0.01f is the largest float below 0.01)
+                if (j > 0 && agt_uniform((int)(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f))) {
+                    outx -= dx * 0.5f; outy -= dy * 0.5f;
+                    break;
+                }
+                pdx = dx; pdy = dy;
+            }
+#pragma unroll
+            for (int l = 0; l < NLEV; l++) { jox[l] = level == l ? agt_uniform(jx0) : jox[l]; joy[l] = level == l ? agt_uniform(jy0) : joy[l]; }
+            CSTAMP(9 + level * 2);
+        }
+        CSTAMP(5);
+        // the result: stores now; the arrival is counted after their acknowledgement -- at once for the last frame of the group
+        // (its pose solve is the launch's tail), otherwise under the next frame's image-side work
+        if (io.done) {
+            if (tid == 0) lk_publish_stores(io, pidx, outx, outy, st);
+            if (k + 1 < nf) owed = io.done;
+            else if (tid == 0) lk_arrive(io.done, b);
+        } else if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, 0.f);
+
+        // ---- hand-over: image k's search tiles become the next frame's previous-image tiles; the requested tiles of image
+        // k+1 go into the buffer the image-(k-1) side no longer needs (its last reader was before this frame's barriers)
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) { sox[l] = jox[l]; soy[l] = joy[l]; }
+        smask = jmask;
+        jmask = 0;
+        if (pre) {
+#pragma unroll
+            for (int l = 0; l < NLEV; l++) {
+                if ((nmask >> l) & 1) {
+                    tile_store<JT, C::JNDW, T>(lds + ((cur ^ 1) * NLEV + l) * K::TILE, tid, tn[l]);
+                    jox[l] = nox[l]; joy[l] = noy[l];
+                }
+            }
+            jmask = nmask;
+        }
+        cur ^= 1;
+        px = outx; py = outy; pst = st;
+        CSTAMP(6);
+    }
+}
+
+}  // namespace agt_lk

@@ -16,6 +16,7 @@
 #include <cstddef>
 #include "agt_pyramid2_body.h"
 #include "agt_lk_rs_body.h"
+#include "agt_lk_chain_body.h"
 #include "agt_pnp_body.h"
 
 // Role timeline of the fused step (diagnostic build only, -DAGT_STEP_STAMPS; tools/stepstamps.py): s_memtime at entry and
@@ -57,6 +58,16 @@ __device__ __forceinline__ KTables kernarg_tables()
     return (KTables)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
 }
 
+// LDS of one corner of the LK role: the tracker's tiles (general body, or the frame-chained body where that one applies)
+// and, behind them, the copy of the per-frame tables
+template <int WIN, int NW, int NLEV>
+__host__ __device__ constexpr size_t lk_role_lds(int levels)
+{
+    size_t body = agt_lk::lk_lds_bytes<WIN, NW>(levels);
+    if (WIN == 21 && NW == 4 && agt_lk::lk_chain_lds_bytes<NLEV>() > body) body = agt_lk::lk_chain_lds_bytes<NLEV>();
+    return (body + sizeof(AgtLkTables) + 15) & ~(size_t)15;
+}
+
 // ---- LK role: workgroup `blk` of the role, THREADS threads.  NW = 4: the workgroup is one corner; NW = 1: each wave is
 // its own corner.  Consecutive frames of a corner are tracked in-kernel (position carried in registers).
 template <int WIN, int NW, int NLEV, int THREADS>
@@ -68,7 +79,7 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
     if (corner >= (long)S.lk.n * S.lk_B) return;
     const int b = (int)(corner / S.lk.n), pt = (int)(corner - (long)b * S.lk.n);
     constexpr size_t LKB = sizeof(AgtLkTables);
-    const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(S.lk.max_level + 1) + LKB + 15) & ~(size_t)15;
+    const size_t per = lk_role_lds<WIN, NW, NLEV>(S.lk.max_level + 1);
     uint8_t* my = lds + (NW == 1 ? (size_t)wave * per : 0);
     // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: the kernel-
     // argument segment is host memory, a dependent scalar load from it in the middle of the chain costs a
@@ -81,6 +92,27 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         if (S.lk_nf > 1) {
             const uint32_t* gsrc = (const uint32_t*)src;              // vector loads: one per lane, all in flight at once
             for (int i = tid; i < (int)(LKB / 4); i += AGT_WAVE * NW) reinterpret_cast<uint32_t*>(tab)[i] = gsrc[i];
+        }
+    }
+    if constexpr (WIN == 21 && NW == 4) {
+        // one workgroup per corner: the frame-chained body (agt_lk_chain_body.h) for what the tracker asks for
+        if (S.lk.flags == 0 && S.lk.err == nullptr) {
+            auto frame = [&](int k) {
+                agt_lk::LkFrameIo<NLEV> io;
+                io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = io.py = 0.f; io.pst = 1;
+                if (k == 0) {
+#pragma unroll
+                    for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
+                    io.next_pts = T.lk.next[0]; io.status = T.lk.status[0]; io.done = T.lk.done[0];
+                } else {
+#pragma unroll
+                    for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
+                    io.next_pts = tab->next[k]; io.status = tab->status[k]; io.done = tab->done[k];
+                }
+                return io;
+            };
+            agt_lk::lk_frames_w4<NLEV>(&KS->lk, pt, b, my, S.lk_nf, frame);
+            return;
         }
     }
     float px = 0.f, py = 0.f; int pst = 1;
@@ -288,7 +320,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         const long corners = (long)P.lk.n * P.lk_B;
         P.n_lk = (int)((corners + CPB - 1) / CPB);
         blocks += P.n_lk;
-        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(P.lk.max_level + 1) + sizeof(AgtLkTables) + 15) & ~(size_t)15;
+        const size_t per = P.lk.max_level < 3 ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
         const size_t need = per * (NW == 1 ? CPB : 1);
         lds = lds > need ? lds : need;
     }
@@ -302,7 +334,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (roles == AGT_STEP_LK) {
         constexpr int OCCL = (WIN == 21 && NW == 1) ? 4 : 1;          // as the stand-alone lk_kernel
         const long corners = (long)P.lk.n * P.lk_B;
-        const size_t per = (agt_lk::lk_lds_bytes<WIN, NW>(P.lk.max_level + 1) + sizeof(AgtLkTables) + 15) & ~(size_t)15;
+        const size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
         if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
         return hipGetLastError();

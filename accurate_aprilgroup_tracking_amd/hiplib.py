@@ -22,6 +22,7 @@ PNP_SINGULAR, PNP_PLANAR, PNP_TOO_FEW = 1, 2, 4
 STATE_STRIDE = 16
 ST_RVEC, ST_TVEC, ST_OK, ST_ERR, ST_NTRACK, ST_ITERS, ST_GUESS, ST_FLAGS, ST_TVEC_F32 = 0, 3, 6, 7, 8, 9, 10, 11, 12
 TRK_ZERO_VELOCITY = 256
+TRK_CHAIN_TIMEOUT = 512
 PROF_SPANS = 5
 DENSE_STRIDE = 16
 DN_RVEC, DN_TVEC, DN_REFINED, DN_PHOTO_RMS, DN_GEO_RMS, DN_VALID, DN_ITERS, DN_CORNERS = 0, 3, 6, 7, 8, 9, 10, 11

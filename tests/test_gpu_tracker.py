@@ -173,7 +173,7 @@ def test_pipelined_stream_equals_serial(torch_cuda, seq640, max_level):
     frames = torch.from_numpy(s.frames()).cuda()
     order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2, 3, 4, 5, 4, 3, 2, 1, 0] * 3
     outs = []
-    for depth in (0, 1, 2, 3, 4, 8):
+    for depth in (0, 1, 2, 3, 4, 8, 16, 32):
         trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1, max_level=max_level)
         trk.pipeline(depth)
         trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
@@ -186,6 +186,39 @@ def test_pipelined_stream_equals_serial(torch_cuda, seq640, max_level):
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
     assert outs[0][:, 0, H.ST_OK].all()
+
+
+@pytest.mark.parametrize("B,depth", [(1, 1), (1, 5), (1, 20), (3, 4), (44, 2)])
+def test_clip_submission_equals_per_frame_calls(torch_cuda, seq640, B, depth):
+    """agt_track_frames (StreamTracker.step_many): a clip of K frames in one call is K calls of agt_track_frame -- chained
+    fused launches (B = 1, 3; clips shorter, equal to and longer than the launch depth) and the split mode (B = 44)"""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0] * 2 + [1, 2, 3]
+    clip = torch.stack([frames[k].unsqueeze(0).expand(B, -1, -1) for k in order]).contiguous()       # [23, B, H, W]
+    c0 = torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous()
+    f0 = frames[0].unsqueeze(0).expand(B, -1, -1).contiguous()
+    outs = []
+    for cuts in (None, (0, 7, 8, 23), (0, 23)):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+        trk.pipeline(depth)
+        trk.reset(f0, c0)
+        so = torch.zeros((len(order), B, H.STATE_STRIDE), dtype=torch.float64, device="cuda")
+        if cuts is None:
+            for i in range(len(order)):
+                trk.step(clip[i], so[i])
+        else:
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                trk.step_many(clip[a:b], so[a:b])
+        trk.join()
+        outs.append(so.cpu().numpy())
+        assert trk.read_state()[0].frame == len(order)
+    assert outs[0][:, :, H.ST_OK].all() and not (outs[0][:, :, H.ST_FLAGS].astype(int) & H.TRK_CHAIN_TIMEOUT).any()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
 
 
 def test_pipeline_depth_switch_mid_stream(torch_cuda, seq640):
