@@ -180,10 +180,22 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         tr[k] = tv[k] ? i / C::JNDW : 0; tc[k] = tv[k] ? 4 * (i - tr[k] * C::JNDW) : 0;
     }
 
+    // level geometry, read ONCE: the parameters live in the kernel-argument segment, every scalar load from it inside the
+    // frame loop is a ~200-cycle wait in the middle of the chain (the tracker's previous and next pyramids share it)
+    int gw[NLEV], gh[NLEV], gpitch[NLEV];      // (row pitches fit 31 bits)
+    long gbs[NLEV];
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) {
+        gw[l] = l <= maxl ? P->next[l].w : 0; gh[l] = l <= maxl ? P->next[l].h : 0;
+        gpitch[l] = l <= maxl ? (int)P->next[l].pitch : 0; gbs[l] = l <= maxl ? P->next[l].bstride : 0;
+    }
+    bool all_safe = true;                      // every level can hold a whole tile at its origin (see the prefetch)
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) all_safe = all_safe && (l > maxl || (4 * C::JNDW <= gw[l] && JT <= gh[l]));
     int toff[NLEV][C::JLD];                    // the same as byte offsets inside each level's image
 #pragma unroll
     for (int l = 0; l < NLEV; l++) {
-        const int p32 = l <= maxl ? (int)P->next[l].pitch : 0;
+        const int p32 = gpitch[l];
 #pragma unroll
         for (int k = 0; k < C::JLD; k++) toff[l][k] = tr[k] * p32 + tc[k];
     }
@@ -235,7 +247,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             const float prevx = px * scale - halfw, prevy = py * scale - halfw;
             ipx[l] = agt_uniform((int)floorf(prevx)); ipy[l] = agt_uniform((int)floorf(prevy));
             fa[l] = prevx - (float)ipx[l]; fb[l] = prevy - (float)ipy[l];
-            const int w = P->prev[l].w, h = P->prev[l].h;
+            const int w = gw[l], h = gh[l];
             const bool a = l <= maxl && !(ipx[l] < -WIN || ipx[l] >= w || ipy[l] < -WIN || ipy[l] >= h);
             const bool inside = ((smask >> l) & 1) && ipx[l] - 1 >= sox[l] && ipx[l] - 1 + C::IW <= sox[l] + JT &&
                                 ipy[l] - 1 >= soy[l] && ipy[l] - 1 + C::IW <= soy[l] + JT;
@@ -249,14 +261,12 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 #pragma unroll
             for (int l = 0; l < NLEV; l++) {
                 if ((needI >> l) & 1) {
-                    const AgtLevel LI = get_level(P->prev[l]);
                     sox[l] = ipx[l] - 1 - SRC_PAD; soy[l] = ipy[l] - 1 - SRC_PAD;
-                    tile_request(io.imgI[l] + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, sox[l], soy[l], tid, tr, tc, tv, ti[l]);
+                    tile_request(io.imgI[l] + (long)b * gbs[l], gw[l], gh[l], gpitch[l], sox[l], soy[l], tid, tr, tc, tv, ti[l]);
                 }
                 if ((needJ >> l) & 1) {
-                    const AgtLevel LJ = get_level(P->next[l]);
                     jox[l] = ipx[l] - MARGIN; joy[l] = ipy[l] - MARGIN;           // centred on the initial guess = previous position
-                    tile_request(io.imgJ[l] + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jox[l], joy[l], tid, tr, tc, tv, tj[l]);
+                    tile_request(io.imgJ[l] + (long)b * gbs[l], gw[l], gh[l], gpitch[l], jox[l], joy[l], tid, tr, tc, tv, tj[l]);
                 }
             }
             CSTAMP(1);
@@ -281,7 +291,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         // ---- image-(k-1) side of every level: Scharr -> derivative tiles
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            const int w = P->prev[l].w, h = P->prev[l].h;
+            const int w = gw[l], h = gh[l];
             const uint8_t* s0 = lds + offS[l];
             int* sD = sDall + l * (K::SD / 4);
 #pragma unroll
@@ -372,9 +382,6 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 // at the image origin and is left to the next frame's on-demand path): any branch around a load makes the
                 // compiler copy the register array at the merge, and the copy waits for the loads issued so far.
                 const LkFrameIo<NLEV> nio = frame(k + 1);
-                bool all_safe = true;
-#pragma unroll
-                for (int l = 0; l < NLEV; l++) all_safe = all_safe && (l > maxl || (4 * C::JNDW <= P->next[l].w && JT <= P->next[l].h));
                 if (agt_uniform((int)all_safe)) {
 #pragma unroll
                     for (int l = 0; l < NLEV; l++) {
@@ -382,8 +389,8 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                         typedef const __attribute__((address_space(1))) uint32_t* G32;
                         const float sc = 1.f / (float)(1 << l);
                         const int cx = agt_uniform((int)floorf(outx * sc - halfw)), cy = agt_uniform((int)floorf(outy * sc - halfw));
-                        const int w = P->next[l].w, h = P->next[l].h;
-                        const long pitch = P->next[l].pitch, bstride = P->next[l].bstride;
+                        const int w = gw[l], h = gh[l];
+                        const long pitch = gpitch[l], bstride = gbs[l];
                         const int ox = cx - MARGIN, oy = cy - MARGIN, ax0 = ox & ~3;
                         const bool ok = l <= maxl && ax0 >= 0 && ax0 + 4 * C::JNDW <= w && oy >= 0 && oy + JT <= h;
                         const int lx = ok ? ax0 : 0, ly = ok ? oy : 0;
@@ -400,7 +407,13 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             if (!((lvA >> level) & 1)) { if (level == 0) st = 0; continue; }
             const float4 lv4 = *reinterpret_cast<const float4*>(lvl + level * 8);
             if (!agt_uniform((int)(lvl[level * 8 + 4] != 0.f))) { if (level == 0) st = 0; continue; }
-            const AgtLevel LJ = get_level(P->next[level]);
+            AgtLevel LJ;
+            LJ.ptr = nullptr; LJ.w = agt_uniform(pick(gw, level)); LJ.h = agt_uniform(pick(gh, level));
+            LJ.pitch = agt_uniform(pick(gpitch, level));
+            {
+                const unsigned long long bs = (unsigned long long)pick(gbs, level);
+                LJ.bstride = (long)(((unsigned long long)(unsigned)agt_uniform((int)(unsigned)(bs >> 32)) << 32) | (unsigned)agt_uniform((int)(unsigned)bs));
+            }
             const uint8_t* imgJ;
             {
                 const unsigned long long v = (unsigned long long)pick(io.imgJ, level);
@@ -477,7 +490,10 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 // (double)dx * dx + (double)dy * dy <= eps2, evaluated in FP64 only inside a 1e-6 band around the threshold
                 const float d2 = dx * dx + dy * dy;
                 bool conv = d2 < eps2_lo;
-                if (agt_uniform((int)(!conv && !(d2 > eps2_hi)))) conv = (double)dx * dx + (double)dy * dy <= P->eps2;      // (rare)
+                if (agt_uniform((int)(!conv && !(d2 > eps2_hi)))) {
+                    asm volatile("" ::: "memory");      // (rare; keeps the FP64 evaluation from being hoisted into every iteration)
+                    conv = (double)dx * dx + (double)dy * dy <= P->eps2;
+                }
                 if (agt_uniform((int)conv)) break;
                 // fabs((double)f) < 0.01  <=>  fabsf(f) <= 0.01f  (0.01f is the largest float below 0.01)
                 if (j > 0 && agt_uniform((int)(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f))) {

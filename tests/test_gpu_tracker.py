@@ -535,3 +535,64 @@ def test_lost_corner_stays_lost(torch_cuda, oracle, seq640):
                                   s.rvecs[F - 1], s.tvecs[F - 1], True)
         assert np.abs(st[-1, 0, :3] - r.ravel()).max() < 1e-6 and np.abs(st[-1, 0, 3:6] - t.ravel()).max() < 1e-6
     assert np.array_equal(outs[0], outs[1]) and np.array_equal(outs[0], outs[2])
+
+
+def test_chained_lk_role_big_motion_and_image_border(torch_cuda, oracle, seq640):
+    """The frame-chained LK role of the fused step (agt_lk_chain_body.h) on what its fast path does not cover: frames taken
+    out of order (jumps of up to five frames: flows past the 9 px tile margin -> search tiles re-staged, previous-image
+    tiles reloaded) on a crop that leaves corners a few pixels from the left / top image border (windows and tiles reach
+    outside: reflected tile loads, no prefetch for those levels).  Corners and status after every launch mode equal the
+    oracle's LK chain bit for bit; records equal the stage-by-stage mode."""
+    torch = torch_cuda
+    import ctypes as C
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq640
+    all_c = np.stack([s.corners(k) for k in range(len(s))])
+    x0 = int(max(0, np.floor(all_c[..., 0].min()) - 6)) & ~3
+    y0 = int(max(0, np.floor(all_c[..., 1].min()) - 4))
+    fr = s.frames()[:, y0:, x0:]
+    Hc, Wc = fr.shape[1], fr.shape[2] & ~3
+    fr = np.ascontiguousarray(fr[:, :, :Wc])
+    # two more "frames": frames 2 and 4 displaced by (+11, -7) px as a whole (wrap-around at the far borders), so that a
+    # step onto / off them is a flow beyond the tile margin at level 0
+    fr = np.concatenate([fr, np.roll(fr[2:3], (-7, 11), axis=(1, 2)), np.roll(fr[4:5], (-7, 11), axis=(1, 2))])
+    Kc = s.K.copy(); Kc[0, 2] -= x0; Kc[1, 2] -= y0
+    shift = np.array([x0, y0], np.float32)
+    order = [3, 0, 6, 1, 7, 4, 0, 5, 6, 2, 3]
+    c0 = (s.corners(0) - shift).astype(np.float32)
+    assert c0[:, 0].min() < 10.5 or c0[:, 1].min() < 10.5        # some window starts outside the image
+    # oracle LK chain with the tracker's sticky status
+    pts = c0.copy(); alive = np.ones(len(c0), bool); pyr = oracle.Pyramid(fr[0])
+    big = 0.0
+    for k in order:
+        npyr = oracle.Pyramid(fr[k])
+        nx, st, _ = oracle.calcOpticalFlowPyrLK(pyr, npyr, pts, maxLevel=2)
+        nx = nx.reshape(-1, 2); st = st.ravel().astype(bool)
+        nx[~alive] = pts[~alive]
+        big = max(big, float(np.abs(nx[alive & st] - pts[alive & st]).max()) if (alive & st).any() else 0.0)
+        alive &= st
+        pts = nx.astype(np.float32); pyr = npyr
+    assert big > 9.0 and alive.sum() >= 8
+    frames = torch.from_numpy(fr).cuda()
+    outs = []
+    for depth in (0, 1, 4, 16):
+        trk = StreamTracker(Wc, Hc, s.obj, Kc, None, n_streams=1)
+        trk.pipeline(depth)
+        trk.reset(frames[0:1].contiguous(), torch.from_numpy(c0[None]).cuda().contiguous())
+        so = trk.new_state_buffer(len(order))
+        for i, k in enumerate(order):
+            trk.step(frames[k:k + 1], so[i])
+        trk.join()
+        outs.append(so.cpu().numpy())
+        cp, sp = trk.corners()
+        torch.cuda.synchronize()
+        got_c = np.zeros((len(c0), 2), np.float32); got_s = np.zeros(len(c0), np.uint8)
+        hip = C.CDLL("libamdhip64.so")
+        assert hip.hipMemcpy(got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes, 2) == 0
+        assert hip.hipMemcpy(got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes, 2) == 0
+        assert np.array_equal(got_s.astype(bool), alive), "depth %d" % depth
+        assert np.array_equal(got_c.view(np.uint32), pts.view(np.uint32)), "depth %d" % depth
+        assert not (outs[-1][:, :, H.ST_FLAGS].astype(int) & H.TRK_CHAIN_TIMEOUT).any()
+    for o in outs[1:]:
+        assert np.array_equal(outs[0], o)
