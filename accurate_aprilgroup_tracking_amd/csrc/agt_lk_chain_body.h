@@ -445,9 +445,13 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 bx0 = (float)lx; bx1 = (float)hx; by0 = (float)ly; by1 = (float)hy;
             };
             set_box();
+            // One vector -> scalar decision per iteration.  Every readfirstlane + branch is a ~50-cycle bubble on this chain, so
+            // the tests of an iteration (converged, oscillating, FP64 tie-break needed, next window position outside the box)
+            // are folded into one code that crosses to the scalar unit once.
+            int slow = agt_uniform((int)!(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1));
             for (int j = 0; j < P->max_count; j++) {
                 const float fx = floorf(nextx), fy = floorf(nexty);
-                if (!agt_uniform((int)(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1))) {
+                if (slow) {
                     const int inx = agt_uniform((int)fx), iny = agt_uniform((int)fy);
                     if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
                         if (level == 0) st = 0;
@@ -487,19 +491,23 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 #ifdef AGT_STEP_STAMPS
                 if (pidx == 0 && threadIdx.x == 0 && k < 4 && level < 3) agt_chain_stamps[k * 16 + 14] += 1ull << (level * 8);
 #endif
-                // (double)dx * dx + (double)dy * dy <= eps2, evaluated in FP64 only inside a 1e-6 band around the threshold
-                const float d2 = dx * dx + dy * dy;
-                bool conv = d2 < eps2_lo;
-                if (agt_uniform((int)(!conv && !(d2 > eps2_hi)))) {
-                    asm volatile("" ::: "memory");      // (rare; keeps the FP64 evaluation from being hoisted into every iteration)
-                    conv = (double)dx * dx + (double)dy * dy <= P->eps2;
-                }
-                if (agt_uniform((int)conv)) break;
+                // (double)dx * dx + (double)dy * dy <= eps2: FP64 only inside a 1e-6 band around the threshold (code 4, rare);
                 // fabs((double)f) < 0.01  <=>  fabsf(f) <= 0.01f  (0.01f is the largest float below 0.01)
-                if (j > 0 && agt_uniform((int)(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f))) {
-                    outx -= dx * 0.5f; outy -= dy * 0.5f;
-                    break;
+                const float d2 = dx * dx + dy * dy;
+                const bool osc = j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f;
+                const bool out_of_box = !(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1);
+                int code = out_of_box ? 3 : 0;
+                code = osc ? 2 : code;
+                code = d2 < eps2_lo ? 1 : code;
+                code = (!(d2 < eps2_lo) && !(d2 > eps2_hi)) ? 4 : code;
+                code = agt_uniform(code);
+                if (code == 4) {
+                    const bool conv = (double)dx * dx + (double)dy * dy <= P->eps2;
+                    code = agt_uniform(conv ? 1 : (osc ? 2 : (out_of_box ? 3 : 0)));
                 }
+                if (code == 1) break;
+                if (code == 2) { outx -= dx * 0.5f; outy -= dy * 0.5f; break; }
+                slow = code == 3;
                 pdx = dx; pdy = dy;
             }
 #pragma unroll

@@ -339,7 +339,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
         return hipGetLastError();
     }
-    if (roles != AGT_STEP_ALL) return hipErrorInvalidValue;
+    if (!(roles & (AGT_STEP_LK | AGT_STEP_PNP))) return hipErrorInvalidValue;       // (LK | PnP without the pyramid role: diagnostics)
     // OCC = 1: the FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU,
     // best while <= 256 corners are in flight.  OCC = 2: registers capped at 256 (336 B of scratch for the PnP
     // role), two workgroups per CU: +0.4 us on one stream, but 8 / 32 streams run at 23 / 49 us per step.

@@ -283,9 +283,9 @@ def main():
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (default: the workload's)")
     ap.add_argument("--render-frames", type=int, default=24)
     ap.add_argument("--depth", type=int, default=0,
-                    help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = 32 for >= 200 timed steps, else "
-                         "min(steps, 16): the launches are chained (PnP follows LK inside the launch), so a short block is one or two launches "
-                         "deep (measured at 20 steps: 43.5 k / 50.7 k / 52.2 k frames/s at depth 1 / 4 / 16)")
+                    help="frames per fused launch (agt_tracker_pipeline depth; 1 = lowest latency); 0 = min(steps, 32): the launches are "
+                         "chained (PnP follows LK inside the launch), so a short block is one launch deep (measured at 20 steps: "
+                         "53.7 k / 55.6 k / 56.5 k frames/s at depth 10 / 16 / 20)")
     ap.add_argument("--dry-run", action="store_true",
                     help="TEST HOOK (CPU, gloo): launcher + rendezvous + block timing + gather with a stub tracker; the line it prints "
                          "is marked data = dry-run and is not a measurement")
@@ -316,7 +316,7 @@ def main():
     bench = Bench(torch, wl, args, rank, world, dev)
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
-    auto_depth = 32 if K >= 200 else min(K, 16)      # chained launches: a short block is one or two launches deep
+    auto_depth = min(K, 32)           # chained launches: a short block is ONE launch deep (plus the pyramid launch ahead of it)
     depth = max(1, min(args.depth or (auto_depth if fused else 2), 32 if fused else 8))      # split mode (not fused): two launches per group of `depth` frames
     bench.trk.pipeline(depth)
     dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
