@@ -732,6 +732,18 @@ static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
         }
     }
     const long t = c->trk_frame + 1;
+    // The ring entry frame t takes must be free: its previous tenant, frame t - M, has to be past its pose solve and past the
+    // LK of the frame after it (which reads it as the previous image).  The ring size follows from every stage advancing F
+    // frames per launch; groups cut short (frames of differing pitch) let stages fall behind that rhythm.
+    {
+        const long M = c->live_ring;
+        while (c->n_pnp < t - M || c->n_lk < t - M + 1) {
+            const long before = c->n_pnp + c->n_lk + c->n_stage[0];
+            int rc = launch_group(c, B);
+            if (rc) return rc;
+            if (c->n_pnp + c->n_lk + c->n_stage[0] == before) return AGT_ERR_STATE;      // (cannot happen: work was pending)
+        }
+    }
     const int slot = (int)(t % c->live_ring);
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     c->built_B[slot] = B;

@@ -181,13 +181,15 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
     }
 
     // level geometry, read ONCE: the parameters live in the kernel-argument segment, every scalar load from it inside the
-    // frame loop is a ~200-cycle wait in the middle of the chain (the tracker's previous and next pyramids share it)
-    int gw[NLEV], gh[NLEV], gpitch[NLEV];      // (row pitches fit 31 bits)
-    long gbs[NLEV];
+    // frame loop is a ~200-cycle wait in the middle of the chain.  The frames of a group share their geometry; only the image
+    // BEFORE the group (the previous image of its first frame) may sit in a buffer with another pitch / stream stride.
+    int gw[NLEV], gh[NLEV], gpitch[NLEV], gpitch0[NLEV];      // (row pitches fit 31 bits)
+    long gbs[NLEV], gbs0[NLEV];
 #pragma unroll
     for (int l = 0; l < NLEV; l++) {
         gw[l] = l <= maxl ? P->next[l].w : 0; gh[l] = l <= maxl ? P->next[l].h : 0;
         gpitch[l] = l <= maxl ? (int)P->next[l].pitch : 0; gbs[l] = l <= maxl ? P->next[l].bstride : 0;
+        gpitch0[l] = l <= maxl ? (int)P->prev[l].pitch : 0; gbs0[l] = l <= maxl ? P->prev[l].bstride : 0;
     }
     bool all_safe = true;                      // every level can hold a whole tile at its origin (see the prefetch)
 #pragma unroll
@@ -262,7 +264,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             for (int l = 0; l < NLEV; l++) {
                 if ((needI >> l) & 1) {
                     sox[l] = ipx[l] - 1 - SRC_PAD; soy[l] = ipy[l] - 1 - SRC_PAD;
-                    tile_request(io.imgI[l] + (long)b * gbs[l], gw[l], gh[l], gpitch[l], sox[l], soy[l], tid, tr, tc, tv, ti[l]);
+                    tile_request(io.imgI[l] + (long)b * (k ? gbs[l] : gbs0[l]), gw[l], gh[l], k ? gpitch[l] : gpitch0[l], sox[l], soy[l], tid, tr, tc, tv, ti[l]);
                 }
                 if ((needJ >> l) & 1) {
                     jox[l] = ipx[l] - MARGIN; joy[l] = ipy[l] - MARGIN;           // centred on the initial guess = previous position
