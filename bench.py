@@ -317,7 +317,7 @@ def main():
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
     auto_depth = min(K, 32)           # chained launches: a short block is ONE launch deep (plus the pyramid launch ahead of it)
-    depth = max(1, min(args.depth or (auto_depth if fused else 2), 32 if fused else 8))      # split mode (not fused): two launches per group of `depth` frames
+    depth = max(1, min(args.depth or (auto_depth if fused else min(K, 16)), 32))      # split mode (not fused): two launches per group of `depth` frames
     bench.trk.pipeline(depth)
     dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
     med, p10, p90 = percentiles(dts)
