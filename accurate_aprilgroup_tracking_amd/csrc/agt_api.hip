@@ -607,7 +607,7 @@ static int launch_group(agt_ctx* c, int B)
             for (int l = 0; l <= L; l++) T.lk.img[k][l] = l == 0 ? c->l0_ptr[q] : c->lmem[q][l];
             if (k) {
                 T.lk.next[k - 1] = c->corners[q]; T.lk.status[k - 1] = c->status[q];
-                if (chain) { T.lk.done[k - 1] = c->lk_done + (size_t)q * c->cfg.max_streams; c->lk_target[q] += (unsigned)c->trk_n; }
+                (void)chain;          // (arrival counters are attached below, to the frames the PnP role of THIS launch waits for)
             }
         }
         S.n_lk = 1; S.lk_B = B;
@@ -628,7 +628,13 @@ static int launch_group(agt_ctx* c, int B)
             const long f = c->n_pnp + 1 + k;
             const int q = (int)(f % M);
             T.pnp.img[k] = c->corners[q]; T.pnp.mask[k] = c->status[q]; T.pnp.so[k] = c->so_ring[q];
-            if (f > lk_before) { T.pnp.wait[k] = c->lk_done + (size_t)q * c->cfg.max_streams; T.pnp.target[k] = c->lk_target[q]; }
+            if (f > lk_before) {
+                // tracked by this launch: the LK role counts the frame's corners in (device-scope stores + acknowledgement, only
+                // for the frames somebody waits for), the PnP wave waits for the count
+                c->lk_target[q] += (unsigned)c->trk_n;
+                T.lk.done[f - lk_f0 - 1] = c->lk_done + (size_t)q * c->cfg.max_streams;
+                T.pnp.wait[k] = T.lk.done[f - lk_f0 - 1]; T.pnp.target[k] = c->lk_target[q];
+            }
         }
         S.pnp_nf = (int)cnt;
         S.n_pnp = B;
