@@ -411,13 +411,26 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
 #pragma unroll
             for (int k = 0; k < PX; k++) Jv[k] >>= (W_BITS - 5);
         };
+        // While the window's corner stays in this box it is inside the image band and inside the search tile: one float test per
+        // iteration instead of the two integer ones (which remain, word for word, behind it); and ONE vector -> scalar decision
+        // per iteration: converged / oscillating / FP64 tie-break needed / next position outside the box, folded into one code.
+        float bx0, bx1, by0, by1;
+        auto set_box = [&]() {
+            const int lx = jx0 > -WIN ? jx0 : -WIN, hx = (jx0 + C::JT - WIN - 1 < LJ.w - 1 ? jx0 + C::JT - WIN - 1 : LJ.w - 1) + 1;
+            const int ly = jy0 > -WIN ? jy0 : -WIN, hy = (jy0 + C::JT - WIN - 1 < LJ.h - 1 ? jy0 + C::JT - WIN - 1 : LJ.h - 1) + 1;
+            bx0 = (float)lx; bx1 = (float)hx; by0 = (float)ly; by1 = (float)hy;
+        };
+        set_box();
+        int slow = agt_uniform((int)!(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1));
         for (int j = 0; j < P->max_count; j++) {
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
-            if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
-                if (level == 0) st = 0;
-                break;
+            if (slow) {
+                if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
+                    if (level == 0) st = 0;
+                    break;
+                }
+                if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) { restage_j(inx, iny); set_box(); }
             }
-            if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
             bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
             rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
             int Jv[PX];
@@ -439,16 +452,23 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
 #endif
             // OpenCV tests  (double)dx*dx + (double)dy*dy <= eps^2  in FP64; the float sum is within 2e-7 of it, so the
-            // FP64 evaluation is only needed inside a 1e-6 band around the threshold (wave-uniform, rare)
-            const float d2 = dx * dx + dy * dy;
-            bool conv = d2 < eps2_lo;
-            if (!conv && !(d2 > eps2_hi)) conv = (double)dx * dx + (double)dy * dy <= P->eps2;
-            if (agt_uniform((int)conv)) break;
+            // FP64 evaluation is only needed inside a 1e-6 band around the threshold (code 4: wave-uniform, rare);
             // fabs((double)f) < 0.01  <=>  fabsf(f) <= 0.01f  (0.01f is the largest float below 0.01)
-            if (j > 0 && agt_uniform((int)(fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f))) {
-                outx -= dx * 0.5f; outy -= dy * 0.5f;
-                break;
+            const float d2 = dx * dx + dy * dy;
+            const bool osc = j > 0 && fabsf(dx + pdx) <= 0.01f && fabsf(dy + pdy) <= 0.01f;
+            const bool out_of_box = !(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1);
+            int code = out_of_box ? 3 : 0;
+            code = osc ? 2 : code;
+            code = d2 < eps2_lo ? 1 : code;
+            code = (!(d2 < eps2_lo) && !(d2 > eps2_hi)) ? 4 : code;
+            code = agt_uniform(code);
+            if (code == 4) {
+                const bool conv = (double)dx * dx + (double)dy * dy <= P->eps2;
+                code = agt_uniform(conv ? 1 : (osc ? 2 : (out_of_box ? 3 : 0)));
             }
+            if (code == 1) break;
+            if (code == 2) { outx -= dx * 0.5f; outy -= dy * 0.5f; break; }
+            slow = code == 3;
             pdx = dx; pdy = dy;
         }
 
