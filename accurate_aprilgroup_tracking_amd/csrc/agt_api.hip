@@ -206,6 +206,11 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: fixed iteration counts (AGT_LK_MAX_COUNT=n AGT_LK_EPS=0) separate the per-iteration
+    // cost of the LK role from its per-frame cost
+    { const char* e = getenv("AGT_LK_MAX_COUNT"); if (e) c->lk_max_count = atoi(e); }
+    { const char* e = getenv("AGT_LK_EPS"); if (e) c->lk_eps = atof(e); }
+#endif
     *out = c;
     return AGT_OK;
 }

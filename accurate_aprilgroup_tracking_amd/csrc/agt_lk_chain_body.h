@@ -35,6 +35,17 @@ extern "C" int agt_debug_chain_counts(unsigned* host8)
 #define CCOUNT(i, n)
 #endif
 
+// Diagnostic build only (-DAGT_CHAIN_REPS): run a section of the per-frame work n times (results unchanged) to read its cost
+// off the frame rate -- agt_chain_reps[0] Scharr pass, [1] patch + partial sums, [2] per-level reduction, [3] geometry, [4] next
+// frame's tile requests, [5] hand-over tile stores, [6] result stores
+#ifdef AGT_CHAIN_REPS
+__device__ int agt_chain_reps[8] = { 1, 1, 1, 1, 1, 1, 1, 1 };
+extern "C" int agt_debug_chain_reps(const int* host8) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(agt_chain_reps), host8, 32); }
+#define CREPS(i) for (int rep_ = 0, n_ = *(volatile int*)&agt_chain_reps[i]; rep_ < n_; rep_++)
+#else
+#define CREPS(i)
+#endif
+
 namespace agt_lk {
 
 template <int NLEV>
@@ -243,6 +254,8 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         int ipx[NLEV], ipy[NLEV];
         float fa[NLEV], fb[NLEV];              // bilinear fractions of the previous position
         int lvA = 0, needI = 0, needJ = 0;
+        CREPS(3) {
+        lvA = needI = needJ = 0;
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             const float scale = 1.f / (float)(1 << l);
@@ -256,6 +269,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             lvA |= a ? 1 << l : 0;
             needI |= (a && !inside) ? 1 << l : 0;
             needJ |= (a && !((jmask >> l) & 1)) ? 1 << l : 0;
+        }
         }
         CCOUNT(0, 1); CCOUNT(1, needI != 0); CCOUNT(2, needJ != 0);
         if (agt_uniform(needI | needJ)) {
@@ -291,6 +305,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         }
 
         // ---- image-(k-1) side of every level: Scharr -> derivative tiles
+        CREPS(0)
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             const int w = gw[l], h = gh[l];
@@ -315,6 +330,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 
         // ---- interpolated patch of every level (registers) + this thread's share of the covariance sums
         int Iv[NLEV][C::NPX], Ix[NLEV][C::NPX], Iy[NLEV][C::NPX];
+        CREPS(1)
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             int iw00, iw01, iw10, iw11;
@@ -338,6 +354,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         }
         lds_barrier();
         // ---- wave w finishes level w (w + 4, ..): exact sums over the 256 partials, the 2 x 2 system and its eigenvalue test
+        CREPS(2)
         for (int l = wave; l < NLEV; l += NW) {
             float A[3];
 #pragma unroll
@@ -371,7 +388,11 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         int nox[NLEV], noy[NLEV], nmask = 0;
 #pragma unroll
         for (int l = 0; l < NLEV; l++) { nox[l] = noy[l] = 0; }
-        for (int level = maxl; level >= 0; level--) {
+        // (unrolled: with a compile-time level every per-level quantity below is a plain register -- as a run-time loop each
+        // level paid ~0.7 us of selects, read-first-lanes and their bubbles before its first iteration)
+#pragma unroll
+        for (int level = NLEV - 1; level >= 0; level--) {
+            if (level > maxl) continue;
             const float scale = 1.f / (float)(1 << level);
             float nextx, nexty;
             if (level == maxl) { nextx = px * scale; nexty = py * scale; }
@@ -385,6 +406,8 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 // compiler copy the register array at the merge, and the copy waits for the loads issued so far.
                 const LkFrameIo<NLEV> nio = frame(k + 1);
                 if (agt_uniform((int)all_safe)) {
+                    CREPS(4) {
+                    nmask = 0;
 #pragma unroll
                     for (int l = 0; l < NLEV; l++) {
                         typedef const __attribute__((address_space(1))) uint8_t* G8;
@@ -402,6 +425,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                         for (int q = 0; q < C::JLD; q++) tn[l][q] = *(G32)(base + toff[l][q]);
                         nox[l] = ox; noy[l] = oy;
                         nmask |= ok ? 1 << l : 0;
+                    }
                     }
                     pre = true;
                 }
@@ -520,7 +544,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         // the result: stores now; the arrival is counted after their acknowledgement -- at once for the last frame of the group
         // (its pose solve is the launch's tail), otherwise under the next frame's image-side work
         if (io.done) {
-            if (tid == 0) lk_publish_stores(io, pidx, outx, outy, st);
+            CREPS(6) if (tid == 0) lk_publish_stores(io, pidx, outx, outy, st);
             if (k + 1 < nf) owed = io.done;
             else if (tid == 0) lk_arrive(io.done, b);
         } else if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, 0.f);
@@ -532,6 +556,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         smask = jmask;
         jmask = 0;
         if (pre) {
+            CREPS(5)
 #pragma unroll
             for (int l = 0; l < NLEV; l++) {
                 if ((nmask >> l) & 1) {

@@ -17,6 +17,10 @@ fr = torch.from_numpy(seq.frames()).cuda()
 idx = [(i % (2 * NF - 2)) if (i % (2 * NF - 2)) < NF else 2 * NF - 2 - (i % (2 * NF - 2)) for i in range(K + 1)]
 clip = fr[idx].unsqueeze(1).contiguous()            # [K+1, 1, H, W]
 trk = StreamTracker(1280, 720, seq.obj, seq.K, None, n_streams=1)
+if os.environ.get("AGT_REPS"):          # library built with -DAGT_CHAIN_REPS: repeat sections of the chained LK role's per-frame work
+    import ctypes as C
+    reps = (C.c_int * 8)(*([int(v) for v in os.environ["AGT_REPS"].split(",")] + [1] * 8)[:8])
+    hiplib.lib().agt_debug_chain_reps(reps)
 trk.pipeline(depth)
 so = torch.zeros((K, 1, 16), dtype=torch.float64, device="cuda")
 best = 1e9
