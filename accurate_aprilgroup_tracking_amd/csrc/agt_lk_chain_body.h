@@ -64,23 +64,6 @@ struct ChainCfg {
 template <int NLEV>
 __host__ __device__ constexpr size_t lk_chain_lds_bytes() { return (size_t)ChainCfg<NLEV>::BYTES; }
 
-// a[i] for a small per-level array and a run-time level, as a chain of selects (callers make the result uniform again).  Each candidate passes through
-// an empty asm statement: left as plain loads, the selects are folded into ONE load with a run-time index, which pins the
-// array (and every neighbour the compiler packs with it) in scratch memory.
-template <int N, typename V>
-__device__ __forceinline__ V pick(const V (&a)[N], int i)
-{
-    V r = a[0];
-    asm("" : "+v"(r));
-#pragma unroll
-    for (int l = 1; l < N; l++) {
-        V t = a[l];
-        asm("" : "+v"(t));
-        r = (i == l) ? t : r;
-    }
-    return r;
-}
-
 // LDS-only workgroup barrier: the plain __syncthreads() also waits for every outstanding GLOBAL load of the wave, which would
 // put the prefetched tiles of the next frame back on the critical path of the first iteration after their request
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -433,31 +416,16 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             if (!((lvA >> level) & 1)) { if (level == 0) st = 0; continue; }
             const float4 lv4 = *reinterpret_cast<const float4*>(lvl + level * 8);
             if (!agt_uniform((int)(lvl[level * 8 + 4] != 0.f))) { if (level == 0) st = 0; continue; }
+            // (`level` is a compile-time constant here: plain indexing, no selects)
             AgtLevel LJ;
-            LJ.ptr = nullptr; LJ.w = agt_uniform(pick(gw, level)); LJ.h = agt_uniform(pick(gh, level));
-            LJ.pitch = agt_uniform(pick(gpitch, level));
-            {
-                const unsigned long long bs = (unsigned long long)pick(gbs, level);
-                LJ.bstride = (long)(((unsigned long long)(unsigned)agt_uniform((int)(unsigned)(bs >> 32)) << 32) | (unsigned)agt_uniform((int)(unsigned)bs));
-            }
-            const uint8_t* imgJ;
-            {
-                const unsigned long long v = (unsigned long long)pick(io.imgJ, level);
-                const unsigned lo = (unsigned)agt_uniform((int)(unsigned)v), hi = (unsigned)agt_uniform((int)(unsigned)(v >> 32));
-                imgJ = (const uint8_t*)(((unsigned long long)hi << 32) | lo) + (long)b * LJ.bstride;
-            }
+            LJ.ptr = nullptr; LJ.w = gw[level]; LJ.h = gh[level]; LJ.pitch = gpitch[level]; LJ.bstride = gbs[level];
+            const uint8_t* imgJ = io.imgJ[level] + (long)b * LJ.bstride;
             uint8_t* sJ = lds + (cur * NLEV + level) * K::TILE;
             const float a11 = agt_uniform(lv4.x), a12 = agt_uniform(lv4.y), a22 = agt_uniform(lv4.z), D = agt_uniform(lv4.w);
             int iv[C::NPX], ix[C::NPX], iy[C::NPX];
 #pragma unroll
-            for (int q = 0; q < C::NPX; q++) {
-                iv[q] = Iv[0][q]; ix[q] = Ix[0][q]; iy[q] = Iy[0][q];
-#pragma unroll
-                for (int l = 1; l < NLEV; l++) {
-                    iv[q] = level == l ? Iv[l][q] : iv[q]; ix[q] = level == l ? Ix[l][q] : ix[q]; iy[q] = level == l ? Iy[l][q] : iy[q];
-                }
-            }
-            int jx0 = agt_uniform(pick(jox, level)), jy0 = agt_uniform(pick(joy, level));
+            for (int q = 0; q < C::NPX; q++) { iv[q] = Iv[level][q]; ix[q] = Ix[level][q]; iy[q] = Iy[level][q]; }
+            int jx0 = jox[level], jy0 = joy[level];
 
             nextx -= halfw; nexty -= halfw;
             float pdx = 0.f, pdy = 0.f;
@@ -536,8 +504,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 slow = code == 3;
                 pdx = dx; pdy = dy;
             }
-#pragma unroll
-            for (int l = 0; l < NLEV; l++) { jox[l] = level == l ? agt_uniform(jx0) : jox[l]; joy[l] = level == l ? agt_uniform(jy0) : joy[l]; }
+            jox[level] = agt_uniform(jx0); joy[level] = agt_uniform(jy0);
             CSTAMP(9 + level * 2);
         }
         CSTAMP(5);
