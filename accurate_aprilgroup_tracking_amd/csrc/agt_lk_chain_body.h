@@ -140,6 +140,9 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
     const int tid = (int)threadIdx.x, lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
     const long pidx = (long)b * P->n + pt;
     const int maxl = P->max_level;
+    // (criteria read once: a scalar load from the kernel-argument segment inside the frame loop is a ~200-cycle wait)
+    const int max_count = P->max_count;
+    const double min_eig_threshold = P->min_eig_threshold, eps2 = P->eps2;
     int* sDall = reinterpret_cast<int*>(lds + K::OFF_SD);
     int* slots = reinterpret_cast<int*>(lds + K::OFF_SLOTS);      // [2 phases][4 waves] int4
     int* red = reinterpret_cast<int*>(lds + K::OFF_RED);
@@ -198,7 +201,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
-    const float eps2_lo = (float)(P->eps2 * (1.0 - 1e-6)), eps2_hi = (float)(P->eps2 * (1.0 + 1e-6));
+    const float eps2_lo = (float)(eps2 * (1.0 - 1e-6)), eps2_hi = (float)(eps2 * (1.0 + 1e-6));
 
     // ---- state carried from frame to frame (all wave-uniform)
     float px = 0.f, py = 0.f;
@@ -351,7 +354,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             }
             const float D = A[0] * A[2] - A[1] * A[1];
             const float minEig = (A[2] + A[0] - sqrtf((A[0] - A[2]) * (A[0] - A[2]) + 4.f * A[1] * A[1])) / (float)(2 * WIN * WIN);
-            const bool ok = ((lvA >> l) & 1) && !((double)minEig < P->min_eig_threshold || D < FLT_EPSILON);
+            const bool ok = ((lvA >> l) & 1) && !((double)minEig < min_eig_threshold || D < FLT_EPSILON);
             if (lane == 0) {
                 float* o = lvl + l * 8;
                 o[0] = A[0]; o[1] = A[1]; o[2] = A[2]; o[3] = ok ? 1.f / D : 0.f; o[4] = ok ? 1.f : 0.f;
@@ -443,7 +446,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             // the tests of an iteration (converged, oscillating, FP64 tie-break needed, next window position outside the box)
             // are folded into one code that crosses to the scalar unit once.
             int slow = agt_uniform((int)!(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1));
-            for (int j = 0; j < P->max_count; j++) {
+            for (int j = 0; j < max_count; j++) {
                 const float fx = floorf(nextx), fy = floorf(nexty);
                 if (slow) {
                     const int inx = agt_uniform((int)fx), iny = agt_uniform((int)fy);
@@ -496,7 +499,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 code = (!(d2 < eps2_lo) && !(d2 > eps2_hi)) ? 4 : code;
                 code = agt_uniform(code);
                 if (code == 4) {
-                    const bool conv = (double)dx * dx + (double)dy * dy <= P->eps2;
+                    const bool conv = (double)dx * dx + (double)dy * dy <= eps2;
                     code = agt_uniform(conv ? 1 : (osc ? 2 : (out_of_box ? 3 : 0)));
                 }
                 if (code == 1) break;
