@@ -38,7 +38,7 @@ struct agt_ctx {
     // big batches: the three stages of a step run on three library-owned streams (stage kernels of different frames
     // overlap: 57 us against 93 us back to back at 64 streams); events carry the exact dependencies
     hipStream_t ms_stream[3];                // pyramid, LK, PnP
-    hipEvent_t ms_ev[4][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done
+    hipEvent_t ms_ev[5][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done, LK done (second half of the streams)
     int ms_ready, ms_active;                 // streams / events exist; frames are in flight on them
     // split mode (more corners in flight than the fused launch takes): the pipeline's groups go out as three launches,
     // pyramid on the caller's stream, LK and PnP on library streams (ms_stream[1], [2])
@@ -226,7 +226,7 @@ int agt_destroy(agt_ctx* c)
     }
     if (c->ms_ready) {
         for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->ms_stream[i]);
-        for (int k = 0; k < 4; k++) for (int i = 0; i < AGT_RING_MAX; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
+        for (int k = 0; k < 5; k++) for (int i = 0; i < AGT_RING_MAX; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
         for (int i = 0; i < 3; i++) (void)hipStreamDestroy(c->ms_stream[i]);
     }
     if (c->lkerr) (void)hipFree(c->lkerr);
@@ -353,13 +353,14 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
                        int n, int B, int crit_type, int crit_max_count, double crit_eps,
-                       int flags, double min_eig_threshold)
+                       int flags, double min_eig_threshold, int b0 = 0)
 {
+    // b0: first stream of the launch (streams b0 .. b0 + B - 1 of the slots and of the point arrays)
     if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
     if (prev_slot < 0 || prev_slot >= c->ring || next_slot < 0 || next_slot >= c->ring) return AGT_ERR_ARG;
-    if (n < 0 || B <= 0) return AGT_ERR_ARG;
+    if (n < 0 || B <= 0 || b0 < 0) return AGT_ERR_ARG;
     if (n == 0) return AGT_OK;
-    if (c->built_B[prev_slot] < B || c->built_B[next_slot] < B) return AGT_ERR_STATE;
+    if (c->built_B[prev_slot] < b0 + B || c->built_B[next_slot] < b0 + B) return AGT_ERR_STATE;
     AgtLkParams p;
     memset(&p, 0, sizeof(p));
     fill_levels(c, prev_slot, p.prev);
@@ -373,6 +374,12 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     p.flags = flags;
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
+    if (b0) {
+        for (int l = 0; l <= c->eff_max_level; l++) { p.prev[l].ptr += (long)b0 * p.prev[l].bstride; p.next[l].ptr += (long)b0 * p.next[l].bstride; }
+        p.prev_pts += (size_t)b0 * n * 2; p.next_pts += (size_t)b0 * n * 2; p.status += (size_t)b0 * n;
+        if (p.prev_status) p.prev_status += (size_t)b0 * n;
+        if (p.err) p.err += (size_t)b0 * n;
+    }
     hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
@@ -675,45 +682,67 @@ static int launch_group(agt_ctx* c, int B)
     // Ten HIP calls per GROUP of F frames (round 1 issued thirteen per frame).
     int rc = ms_init(c);
     if (rc) return rc;
-    hipStream_t sL = c->ms_stream[1], sY = c->ms_stream[2];
-    hipEvent_t *evP = c->ms_ev[0], *evL = c->ms_ev[1], *evY = c->ms_ev[3];
+    hipStream_t sL = c->ms_stream[1], sL2 = c->ms_stream[0], sY = c->ms_stream[2];
+    hipEvent_t *evP = c->ms_ev[0], *evL = c->ms_ev[1], *evY = c->ms_ev[3], *evL2 = c->ms_ev[4];
+    // The per-frame LK launches of a group depend on each other (a corner starts where it ended) and leave ~4 us between one
+    // kernel's end and the next one's start on their stream.  A batch that is still "big" in halves (the one-wave-per-corner
+    // kernel in both) goes out as two launches per frame on two streams, streams [0, B1) and [B1, B): each half's gaps are
+    // filled by the other half's kernel.  Every wait on / record of the LK role below is done for both streams.
+    const int B1 = (!agt_lk_wide(c->trk_n, B / 2)) ? B / 2 : B;
+    const bool two = B1 < B;
     const int slot_ev = (int)(c->split_seq % AGT_RING_MAX);
     bool p_work = false;
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) p_work |= S.n_pyr[s] > 0;
     const int p_before = c->last_p_ev, l_before = c->l_ev_hist[0];
     hipError_t e = hipSuccess;
     if (p_work) {
-        if (c->l_ev_hist[AGT_SPLIT_SLACK] >= 0) e = hipStreamWaitEvent(c->stream, evL[c->l_ev_hist[AGT_SPLIT_SLACK]], 0);
+        if (c->l_ev_hist[AGT_SPLIT_SLACK] >= 0) {
+            e = hipStreamWaitEvent(c->stream, evL[c->l_ev_hist[AGT_SPLIT_SLACK]], 0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, evL2[c->l_ev_hist[AGT_SPLIT_SLACK]], 0);
+        }
         if (e == hipSuccess) e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_PYR);
         if (e == hipSuccess) e = hipEventRecord(evP[slot_ev], c->stream);
         if (e != hipSuccess) return hip_fail(c, e);
         c->last_p_ev = slot_ev;
     }
     if (S.n_lk > 0) {
-        if (p_before >= 0) e = hipStreamWaitEvent(sL, evP[p_before], 0);
+        hipEvent_t first = nullptr;
+        if (p_before >= 0) first = evP[p_before];
         else {
-            // no pyramid launch since the last join (single-level pyramids, or the first LK of a run): order the LK stream
+            // no pyramid launch since the last join (single-level pyramids, or the first LK of a run): order the LK streams
             // behind the caller's stream explicitly (reset's corner copy, earlier modes' pyramids)
             e = hipEventRecord(c->ms_ev[2][2], c->stream);
-            if (e == hipSuccess) e = hipStreamWaitEvent(sL, c->ms_ev[2][2], 0);
+            first = c->ms_ev[2][2];
         }
-        if (e == hipSuccess && c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(sL, evY[c->y_ev_hist[1]], 0);
+        for (int h = 0; h < (two ? 2 : 1) && e == hipSuccess; h++) {
+            hipStream_t sh = h ? sL2 : sL;
+            e = hipStreamWaitEvent(sh, first, 0);
+            if (e == hipSuccess && c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(sh, evY[c->y_ev_hist[1]], 0);
+        }
         if (e != hipSuccess) return hip_fail(c, e);
-        // one stand-alone LK launch per frame of the group, back to back on the LK stream (as a role with an in-kernel frame
-        // loop the one-wave-per-corner kernel needs 240 B of scratch per lane at its 128-register budget and runs at half speed)
+        // one stand-alone LK launch per frame of the group (and half), back to back on its stream (as a role with an in-kernel
+        // frame loop the one-wave-per-corner kernel needs 240 B of scratch per lane at its 128-register budget and runs at half speed)
         for (int k = 1; k <= S.lk_nf; k++) {
             const int ps = (int)((lk_f0 + k - 1) % M), sl = (int)((lk_f0 + k) % M);
-            rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B,
+            rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B1,
                              AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+            if (rc == AGT_OK && two)
+                rc = lk_track_on(c, sL2, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B - B1,
+                                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, B1);
             if (rc) return rc;
         }
         e = hipEventRecord(evL[slot_ev], sL);
+        // (recorded on the second stream in any case: an idle stream's event is complete at once, the waits stay uniform)
+        if (e == hipSuccess) e = hipEventRecord(evL2[slot_ev], two ? sL2 : sL);
         if (e != hipSuccess) return hip_fail(c, e);
         c->l_ev_hist[2] = c->l_ev_hist[1]; c->l_ev_hist[1] = c->l_ev_hist[0]; c->l_ev_hist[0] = slot_ev;
         c->ms_active = 1;
     }
     if (S.n_pnp > 0) {
-        if (l_before >= 0) e = hipStreamWaitEvent(sY, evL[l_before], 0);
+        if (l_before >= 0) {
+            e = hipStreamWaitEvent(sY, evL[l_before], 0);
+            if (e == hipSuccess) e = hipStreamWaitEvent(sY, evL2[l_before], 0);
+        }
         if (e == hipSuccess) e = agt_launch_step(sY, S, T, c->cfg.win, AGT_STEP_PNP);
         if (e == hipSuccess) e = hipEventRecord(evY[slot_ev], sY);
         if (e != hipSuccess) return hip_fail(c, e);
@@ -804,7 +833,7 @@ static int ms_init(agt_ctx* c)
     (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
     for (int i = 0; i < 3; i++)
         if (hipStreamCreateWithPriority(&c->ms_stream[i], hipStreamNonBlocking, pr_hi) != hipSuccess) return hip_fail(c, hipGetLastError());
-    for (int k = 0; k < 4; k++)
+    for (int k = 0; k < 5; k++)
         for (int i = 0; i < AGT_RING_MAX; i++)
             if (hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) return hip_fail(c, hipGetLastError());
     c->ms_ready = 1;
@@ -815,9 +844,11 @@ static int ms_init(agt_ctx* c)
 static int ms_join(agt_ctx* c)
 {
     if (!c->ms_active) return AGT_OK;
-    hipEvent_t ev1 = c->ms_ev[2][0], ev2 = c->ms_ev[2][1];
+    hipEvent_t ev1 = c->ms_ev[2][0], ev2 = c->ms_ev[2][1], ev0 = c->ms_ev[2][3];
     hipError_t e = hipEventRecord(ev1, c->ms_stream[1]);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev1, 0);
+    if (e == hipSuccess) e = hipEventRecord(ev0, c->ms_stream[0]);
+    if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev0, 0);
     if (e == hipSuccess) e = hipEventRecord(ev2, c->ms_stream[2]);
     if (e == hipSuccess) e = hipStreamWaitEvent(c->stream, ev2, 0);
     if (e != hipSuccess) return hip_fail(c, e);
