@@ -9,10 +9,16 @@
 //     corner moved more than ~8 px at that level (then the tile is re-staged).  Two tile buffers alternate;
 //   * the NEXT frame's search tiles are requested when the last level of THIS frame starts iterating, centred on the
 //     estimate of that moment (the 9 px margin absorbs the last corrections): the HBM latency runs under the iterations;
-//   * the image-k side of all levels (Scharr, interpolated patch, covariance sums, their inverse) does not depend on the
-//     flow, so it is evaluated for every level at once: two barriers and one cross-wave sum per frame instead of three of
-//     each, with three independent levels per thread in flight.
-// Only what the fused tracker uses is covered: flags == 0, no error output (lk_role falls back to lk_body otherwise).
+//   * the image-(k-1) side of all levels (Scharr, interpolated patch, covariance sums, their inverse) does not depend on the
+//     flow, so it is evaluated for every level at once, as straight-line code: the partial sums are transposed through LDS
+//     and wave w finishes level w -- three barriers per frame instead of nine;
+//   * the level loop is unrolled (per-level quantities are plain registers), the iteration makes one vector -> scalar decision,
+//     its sums cross the waves as int32 hi / lo pairs;
+//   * the result is stored at once (device-scope stores when the PnP role of the same launch waits for it) and counted into
+//     the arrival counter one frame later, under the next frame's image-side work.
+// Measured on production code with fixed iteration counts: 6.1 us per frame + 0.63 us per iteration (profiles/r02_summary.md).
+// Only what the fused tracker uses is covered: flags == 0, no error output, launches of more than one frame (lk_role keeps
+// lk_body otherwise); the frames of a group share their geometry, the image before the group may differ in pitch.
 #pragma once
 #include "agt_lk_body.h"
 
@@ -54,7 +60,7 @@ struct ChainCfg {
     static constexpr int TILE = C::JT * C::JP;                          // one search tile (40 rows x 44 B)
     static constexpr int SD = ((C::DW * C::DW + 3) & ~3) * 4;           // one derivative tile (22 x 22 ints)
     static constexpr int OFF_SD = 2 * NLEV * TILE;
-    static constexpr int OFF_SLOTS = OFF_SD + NLEV * SD;                // iteration sums: [2 phases][4 waves][4] long long
+    static constexpr int OFF_SLOTS = OFF_SD + NLEV * SD;                // iteration sums: [2 phases][4 waves] int4 (256 B reserved)
     static constexpr int OFF_RED = OFF_SLOTS + 2 * 4 * 4 * 8;           // covariance partials: [3 * NLEV][256 threads] int
     static constexpr int OFF_LVL = OFF_RED + 3 * NLEV * 256 * 4;        // per level: A11, A12, A22, 1 / det, usable (8 floats)
     static constexpr int BYTES = OFF_LVL + NLEV * 8 * 4;
