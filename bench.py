@@ -377,7 +377,7 @@ def main():
                           "parallelism": "stream-per-GPU x%d, %s all_gather of poses once per block" % (world, "gloo (REHEARSAL: ranks share GPUs)" if rehearsal else "RCCL"),
                           "launch": ("fused chained step, %d frames per launch: pyramid of the next group | LK | PnP one frame behind LK (arrival counters); "
                                      "frames handed over as clips (agt_track_frames)%s" % (depth, " -- one call per frame" if args.per_step_calls else "")) if fused else
-                                    "split pipeline: pyramid + LK launch (caller's stream) | PnP launch (library stream), %d frames per group" % depth},
+                                    "split pipeline: pyramid launch per group (caller's stream) | per-frame LK launches, half the streams each on two library streams | PnP launch per group (library stream), %d frames per group" % depth},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5),
                           "value_p10": round(world * B * K / p90, 2), "value_p90": round(world * B * K / p10, 2)},
