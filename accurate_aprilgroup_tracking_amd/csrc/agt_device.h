@@ -74,6 +74,30 @@ __device__ __forceinline__ float agt_uniform(float v)
 // length of most of its links.  Contraction is therefore switched on for this section only.
 #pragma clang fp contract(fast)
 
+// 1 / x and sqrt(x) for the FP64 pose code where the last bit does not matter (values, not decisions): the hardware estimate
+// (v_rcp_f64 / v_rsq_f64, ~26 bits) + two Newton steps -- 7 / 8 dependent instructions instead of the 11 / 14 of the
+// correctly rounded sequences (v_div_scale / v_div_fmas / v_div_fixup; scaled sqrt).  Error <= 1 ulp; no range scaling: callers
+// pass finite, normal, positive (agt_sqrtp: >= 0) operands.  The PnP parity bound is 1e-9 on the pose.
+__device__ __forceinline__ double agt_rcp(double x)
+{
+    double r = __builtin_amdgcn_rcp(x);
+    double e = __builtin_fma(-x, r, 1.0);
+    r = __builtin_fma(r, e, r);
+    e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, e, r);
+}
+__device__ __forceinline__ double agt_sqrtp(double x)
+{
+    if (x == 0.0) return 0.0;
+    const double y = __builtin_amdgcn_rsq(x);
+    double g = x * y, h = 0.5 * y;
+    double r = __builtin_fma(-h, g, 0.5);
+    g = __builtin_fma(g, r, g); h = __builtin_fma(h, r, h);
+    const double d = __builtin_fma(-g, g, x);
+    return __builtin_fma(d, h, g);
+}
+
+
 // cvRodrigues2 vector->matrix.  When JAC, G (3x3 row-major) is the LEFT JACOBIAN of SO(3) at r,
 //     G = I + (1 - cos t)/t^2 [r]x + (t - sin t)/t^3 [r]x^2,      R(r + d) = exp([G d]x) R(r) + O(d^2),
 // so that d(R X)/dr_j = G_j x (R X) (G_j = column j).  This is the same derivative OpenCV forms through its
@@ -106,7 +130,7 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
 {
     double rx = r_in[0], ry = r_in[1], rz = r_in[2];
     const double t2 = rx * rx + ry * ry + rz * rz;
-    double theta = sqrt(t2);
+    double theta = agt_sqrtp(t2);
     if (theta < DBL_EPSILON) {
 #pragma unroll
         for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
@@ -118,7 +142,7 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
     }
     double s, c;
     agt_sincos(theta, s, c);
-    double c1 = 1.0 - c, itheta = 1.0 / theta;
+    double c1 = 1.0 - c, itheta = agt_rcp(theta);
     if (JAC) {
         // a = (1 - cos t)/t^2, b = (t - sin t)/t^3; series below t = 1e-2 (cancellation), relative error < 1e-16 there
         double a, bq;
@@ -162,7 +186,7 @@ __device__ __forceinline__ void agt_project(const AgtCamera& cam, const double R
     double x = wx + t[0];
     double y = wy + t[1];
     double z = wz + t[2];
-    z = z != 0.0 ? 1.0 / z : 1.0;
+    z = z != 0.0 ? agt_rcp(z) : 1.0;
     x *= z; y *= z;
     if (!DIST) {
         u = x * cam.fx + cam.cx;
@@ -345,7 +369,7 @@ __device__ inline void agt_rodrigues_inv(const double Rin[9], double r[3])
         agt_mat3_mul(U, Vt, R);
     }
     double rx = R[7] - R[5], ry = R[2] - R[6], rz = R[3] - R[1];
-    double s = sqrt((rx * rx + ry * ry + rz * rz) * 0.25);
+    double s = agt_sqrtp((rx * rx + ry * ry + rz * rz) * 0.25);
     double c = (R[0] + R[4] + R[8] - 1) * 0.5;
     c = c > 1.0 ? 1.0 : c < -1.0 ? -1.0 : c;
     double theta = acos(c);
@@ -361,7 +385,7 @@ __device__ inline void agt_rodrigues_inv(const double Rin[9], double r[3])
             rx *= theta; ry *= theta; rz *= theta;
         }
     } else {
-        double vth = 1 / (2 * s);
+        double vth = agt_rcp(2 * s);      // (s >= 1e-5 here)
         vth *= theta;
         rx *= vth; ry *= vth; rz *= vth;
     }
@@ -381,7 +405,7 @@ __device__ __forceinline__ bool agt_solve6(const double A[36], const double b[6]
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
         if (!(d > 0.0)) ok = false;
         D[j] = d;
-        double id = 1.0 / d;
+        double id = agt_rcp(d);           // (d > 0 checked above; a non-positive pivot already reports failure)
         iD[j] = id;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {

@@ -406,7 +406,7 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
     mat3_tvec(rot_vel, dv, tran_acc);
     mat3_tmul(rot_vel, old_rv, rot_acc);
     // rotation_matrix_to_euler_angles (transform_helper.py:239-259), three atan2 on three lanes
-    const double sy = sqrt(rot_acc[0] * rot_acc[0] + rot_acc[3] * rot_acc[3]);
+    const double sy = agt_sqrtp(rot_acc[0] * rot_acc[0] + rot_acc[3] * rot_acc[3]);
     const bool sing = sy < 1e-6;
     double ay, ax;
     if (lane == 0) { ay = sing ? -rot_acc[5] : rot_acc[7]; ax = sing ? rot_acc[4] : rot_acc[8]; }
@@ -420,11 +420,11 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
     // (atan2's range (-pi, pi] makes cos(t/2) >= 0; atan2(+-0, negative) = +-pi keeps the sign of ay.)
     double sn, cs;
     {
-        const double r = sqrt(ax * ax + ay * ay);
+        const double r = agt_sqrtp(ax * ax + ay * ay);
         if (r > 0.0) {
-            const double ir = 1.0 / r, c = ax * ir, sv = ay * ir;
-            if (c >= 0.0) { cs = sqrt(0.5 * (1.0 + c)); sn = sv / (2.0 * cs); }
-            else { const double a = sqrt(0.5 * (1.0 - c)); sn = copysign(a, ay); cs = fabs(sv) / (2.0 * a); }
+            const double ir = agt_rcp(r), c = ax * ir, sv = ay * ir;
+            if (c >= 0.0) { cs = agt_sqrtp(0.5 * (1.0 + c)); sn = sv * agt_rcp(2.0 * cs); }
+            else { const double a = agt_sqrtp(0.5 * (1.0 - c)); sn = copysign(a, ay); cs = fabs(sv) * agt_rcp(2.0 * a); }
         } else { cs = 1.0; sn = 0.0; }
     }
     const double sx = lane_bcast(sn, 0), cx = lane_bcast(cs, 0);
