@@ -157,8 +157,8 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 
     // this thread's window pixels / derivative positions as offsets into a 44-B-pitch tile resp. the 22-int-pitch derivative
     // tile (threads without a k-th element point at offset 0 and are masked arithmetically)
-    int oW[C::NPX], oD[C::NPX], oC[C::NSD], iD[C::NSD], dX[C::NSD], dY[C::NSD];
-    bool pv[C::NPX], dv[C::NSD];
+    int oW[C::NPX], oD[C::NPX];
+    bool pv[C::NPX];
 #pragma unroll
     for (int k = 0; k < C::NPX; k++) {
         const int p = tid + k * T;
@@ -166,13 +166,12 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         const int y = pv[k] ? p / WIN : 0, x = pv[k] ? p - y * WIN : 0;
         oW[k] = y * JP + x; oD[k] = y * DW + x;
     }
-#pragma unroll
-    for (int k = 0; k < C::NSD; k++) {
-        const int idx = tid + k * T;
-        dv[k] = idx < DW * DW;
-        const int dyy = dv[k] ? idx / DW : 0, dxx = dv[k] ? idx - dyy * DW : 0;
-        oC[k] = dyy * JP + dxx; iD[k] = dyy * DW + dxx; dX[k] = dxx; dY[k] = dyy;
-    }
+    // Scharr: one horizontal PAIR of derivative positions per thread and level (22 x 11 pairs = 242 threads): the 3 x 4
+    // pixels under a pair are three unaligned dwords -- two aligned LDS reads + one v_alignbyte each -- and every tap sum is a
+    // v_dot4_u32_u8 with constant weights (positive and negative parts apart: the pixels are unsigned)
+    static_assert(DW % 2 == 0 && (DW / 2) * DW <= T && JP % 4 == 0, "pairing of the derivative positions");
+    const bool sv = tid < (DW / 2) * DW;
+    const int sY = sv ? tid / (DW / 2) : 0, sX = sv ? 2 * (tid - sY * (DW / 2)) : 0;     // the pair starts at (sX, sY)
 
     int tr[C::JLD], tc[C::JLD];                // (row, byte column) of this thread's dwords of a 40 x 44 B tile
     bool tv[C::JLD];
@@ -301,21 +300,34 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             const int w = gw[l], h = gh[l];
-            const uint8_t* s0 = lds + offS[l];
-            int* sD = sDall + l * (K::SD / 4);
+            // byte address of the pixel left of and above the pair's first position; rows are JP = 44 B apart, so the three
+            // rows share their alignment
+            const int a = offS[l] + (sY - 1) * JP + (sX - 1);
+            const int sh8 = a & 3;
+            const uint32_t* p = reinterpret_cast<const uint32_t*>(lds + (a & ~3));
+            uint32_t r[3];
 #pragma unroll
-            for (int q = 0; q < C::NSD; q++) {
-                const int gx = ipx[l] + dX[q], gy = ipy[l] + dY[q];
-                const uint8_t* c = s0 + oC[q];
-                const int v00 = c[-JP - 1], v01 = c[-JP], v02 = c[-JP + 1];
-                const int v10 = c[-1], v12 = c[1];
-                const int v20 = c[JP - 1], v21 = c[JP], v22 = c[JP + 1];
-                const int dx = (3 * (v02 + v22) + 10 * v12) - (3 * (v00 + v20) + 10 * v10);
-                const int dy = 3 * ((v20 - v00) + (v22 - v02)) + 10 * (v21 - v01);
+            for (int i = 0; i < 3; i++) r[i] = __builtin_amdgcn_alignbyte(p[i * (JP / 4) + 1], p[i * (JP / 4)], sh8);   // pixels x-1 .. x+2 of row i
+            // position 0 uses bytes 0..2, position 1 bytes 1..3: dx = (3, 10, 3) . (right - left), dy = (3, 10, 3) . (below - above)
+            int val[2];
+#pragma unroll
+            for (int j = 0; j < 2; j++) {
+                const uint32_t wr = j ? 0x03000000u : 0x00030000u, wl = j ? 0x00000300u : 0x00000003u;          // weight 3 on the right / left byte
+                const uint32_t wr10 = j ? 0x0A000000u : 0x000A0000u, wl10 = j ? 0x00000A00u : 0x0000000Au;
+                const uint32_t wrow = j ? 0x030A0300u : 0x00030A03u;
+                unsigned xp = __builtin_amdgcn_udot4(r[0], wr, 0u, false);
+                xp = __builtin_amdgcn_udot4(r[1], wr10, xp, false);
+                xp = __builtin_amdgcn_udot4(r[2], wr, xp, false);
+                unsigned xn = __builtin_amdgcn_udot4(r[0], wl, 0u, false);
+                xn = __builtin_amdgcn_udot4(r[1], wl10, xn, false);
+                xn = __builtin_amdgcn_udot4(r[2], wl, xn, false);
+                const int dx = (int)xp - (int)xn;
+                const int dy = (int)__builtin_amdgcn_udot4(r[2], wrow, 0u, false) - (int)__builtin_amdgcn_udot4(r[0], wrow, 0u, false);
                 // the derivative image has a ZERO (BORDER_CONSTANT) border
-                const int val = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? ((dx & 0xffff) | (dy << 16)) : 0;
-                if (dv[q]) sD[iD[q]] = val;
+                const int gx = ipx[l] + sX + j, gy = ipy[l] + sY;
+                val[j] = (gx >= 0 && gx < w && gy >= 0 && gy < h) ? ((dx & 0xffff) | (dy << 16)) : 0;
             }
+            if (sv) *reinterpret_cast<int2*>(sDall + l * (K::SD / 4) + sY * DW + sX) = make_int2(val[0], val[1]);
         }
         lds_barrier();
         CSTAMP(3);

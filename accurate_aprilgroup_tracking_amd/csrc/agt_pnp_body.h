@@ -41,12 +41,23 @@ constexpr int NACC = 28;            // 21 (upper JtJ) + 6 (JtErr) + 1 (|err|^2)
 constexpr int SLAB = 65;            // padded lane stride of the reduction slab (doubles)
 constexpr int MAX_PPL = 4;          // points per lane -> n <= 256
 
+// Every solver of this file is ONE wave (its workgroup may hold other waves doing something else -- the fused step's PnP role
+// alternates two waves over the frames): cross-lane exchange through LDS needs no workgroup barrier, a wave's LDS operations
+// execute in issue order; only the compiler must be kept from moving accesses across the point.
+__device__ __forceinline__ void pnp_sync()
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
 struct PnpShared {
     double part[NACC * SLAB];
     double tot[NACC + 4];
     double LL[144];
     double vec[48];
     unsigned long long tab[5 * AGT_MAX_GROUP];     // fused step: copy of AgtPnpTables (img / mask / so / wait / target per frame)
+    int seq;                                       // fused step, two alternating waves: frames of this launch whose state update is complete
 };
 
 // sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
@@ -55,10 +66,10 @@ template <int K, bool READBACK = true>
 __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& sh, int lane)
 {
     static_assert(K <= NACC, "the slab holds NACC rows");
-    __syncthreads();
+    pnp_sync();
 #pragma unroll
     for (int k = 0; k < K; k++) sh.part[k * SLAB + lane] = vals[k];
-    __syncthreads();
+    pnp_sync();
     const int k = lane & 31, h = lane >> 5;
     double s = 0.0;
     if (k < K) {
@@ -68,7 +79,7 @@ __device__ __forceinline__ void wave_reduce_slab(double (&vals)[K], PnpShared& s
     }
     s += __shfl_xor(s, 32);
     if (lane < K) sh.tot[lane] = s;
-    __syncthreads();
+    pnp_sync();
     if (READBACK) {
 #pragma unroll
         for (int i = 0; i < K; i++) vals[i] = sh.tot[i];
@@ -142,9 +153,9 @@ __device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpSha
     bfly_stage<0x141, 2>(v, (lane & 4) != 0);      // row_half_mirror   l <-> l ^ 7
     bfly_stage<0x1B, 1>(v, (lane & 2) != 0);       // quad_perm [3,2,1,0]  l <-> l ^ 3
     const double tot = v[0] + ddpp<0xB1>(v[0]);    // quad_perm [1,0,3,2]  l <-> l ^ 1
-    __syncthreads();                               // earlier readers of sh.tot are done
+    pnp_sync();                               // earlier readers of sh.tot are done
     if (!(lane & 1) && (lane >> 1) < K) sh.tot[lane >> 1] = tot;
-    __syncthreads();
+    pnp_sync();
 }
 
 template <typename T>
@@ -300,12 +311,12 @@ __device__ __forceinline__ void smallest_eigvec_wave(double* A, double* v_out, i
         l[j] = (i == j) ? djj : s * id;
     }
     // column i of L for the backward solves: transpose through LDS
-    __syncthreads();
+    pnp_sync();
     if (lane < N) {
 #pragma unroll
         for (int k = 0; k < N; k++) A[i * N + k] = l[k];
     }
-    __syncthreads();
+    pnp_sync();
 #pragma unroll
     for (int k = 0; k < N; k++) lt[k] = A[k * N + i];    // L[k][i], meaningful for k >= i
     double dii = 0.0;                                    // L[i][i]
@@ -334,7 +345,7 @@ __device__ __forceinline__ void smallest_eigvec_wave(double* A, double* v_out, i
         x *= 1.0 / sqrt(nn);
     }
     if (lane < N) v_out[lane] = x;
-    __syncthreads();
+    pnp_sync();
 }
 
 // ---- motion model of PoseDetector (wave-cooperative: independent trig runs on separate lanes) ------------------------------------
@@ -453,12 +464,17 @@ __device__ inline int motion_model_update(AgtTrackState* ts, int lane, const dou
     return 0;
 }
 
-// Solve problem `b`.  Called by ONE wave (threadIdx.x < 64 of its workgroup); sh: that workgroup's scratch.
-template <typename T, int PPL>
+// Solve problem `b`.  Called by ONE wave (any wave of its workgroup); sh: scratch this wave may use now.
+struct PnpNoHook { __device__ __forceinline__ void operator()() const {} };
+
+// before_state(): called once, after this frame's correspondences have been requested and counted and BEFORE the tracker state
+// is read (the fused step's alternating PnP waves wait there for the previous frame's state update: the loads of frame k+1
+// run under the tail of frame k)
+template <typename T, int PPL, typename Hook = PnpNoHook>
 __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
-                                         double* so_p, int extra_flags = 0)
+                                         double* so_p, int extra_flags = 0, Hook before_state = Hook())
 {
-    const int lane = threadIdx.x;
+    const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
     const int n = P.n;
     PSTAMP(0);
     AgtCamera cam;
@@ -483,6 +499,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         }
     }
     const int n_used = (int)agt_wave_sum_i64(cnt);
+    before_state();
     int flags = extra_flags;          // AGT_TRK_CHAIN_TIMEOUT from the chained launch, reported with the frame's record
     double param[6];
     AgtTrackState* ts = P.track ? P.track + b : nullptr;
@@ -606,7 +623,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             wave_reduce_slab<6>(tx, sh, lane);
             wave_reduce_slab<6>(ty, sh, lane);
             wave_reduce_slab<6>(tq, sh, lane);
-            __syncthreads();
+            pnp_sync();
             if (lane == 0) {
                 const int ui[3][3] = { { 0, 1, 2 }, { 1, 3, 4 }, { 2, 4, 5 } };
                 double* LtL = sh.LL;              // 9 x 9
@@ -618,7 +635,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                         LtL[(6 + a) * 9 + c] = -tx[u];   LtL[(6 + a) * 9 + 3 + c] = -ty[u];   LtL[(6 + a) * 9 + 6 + c] = tq[u];
                     }
             }
-            __syncthreads();
+            pnp_sync();
             smallest_eigvec_wave<9>(sh.LL, sh.vec, lane);
             if (lane == 0) {
                 double* hv = sh.vec;
@@ -634,7 +651,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 for (int i = 0; i < 9; i++) sh.vec[32 + i] = h[i] * s8;      // normalised: H[8] = 1
                 sh.vec[41] = ok ? 1.0 : 0.0;
             }
-            __syncthreads();
+            pnp_sync();
             double hx[8];
 #pragma unroll
             for (int i = 0; i < 8; i++) hx[i] = sh.vec[32 + i];
@@ -712,7 +729,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 double lambda_h = 1.0, lc = 0.75;
                 for (int it = 0;;) {
                     // solve (A + lambda D) d = v  -- cv::solve(DECOMP_EIG) in OpenCV; Cholesky here (A + lambda D is SPD)
-                    __syncthreads();
+                    pnp_sync();
                     if (lane == 0) {
                         double* Ap = sh.LL;
                         int idx = 0;
@@ -721,7 +738,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                         for (int a = 0; a < 8; a++) { Ap[a * 9] += lambda_h * Dg[a]; sh.vec[16 + a] = vv[a]; }
                         sh.vec[15] = spd_solve(Ap, 8, sh.vec + 16, sh.vec, nullptr) ? 1.0 : 0.0;
                     }
-                    __syncthreads();
+                    pnp_sync();
                     if (sh.vec[15] == 0.0) break;
                     double dd[8], xd[8];
 #pragma unroll
@@ -750,7 +767,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                         double nu = (Sd - S) / (fabs(tdv) > DBL_EPSILON ? tdv : 1.0) + 2.0;
                         nu = fmin(fmax(nu, 2.0), 10.0);
                         if (lambda_h == 0.0) {
-                            __syncthreads();
+                            pnp_sync();
                             if (lane == 0) {
                                 double* Ap = sh.LL;
                                 int idx = 0;
@@ -761,7 +778,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                                     for (int a = 0; a < 8; a++) mv = fmax(mv, fabs(sh.vec[24 + a]));
                                 sh.vec[14] = mv;
                             }
-                            __syncthreads();
+                            pnp_sync();
                             lambda_h = lc = 1.0 / sh.vec[14];
                             nu *= 0.5;
                         }
@@ -780,7 +797,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                     if (!(it < 10 && dinf >= (double)FLT_EPSILON && rinf >= (double)FLT_EPSILON)) break;
                 }
             }
-            __syncthreads();
+            pnp_sync();
             if (lane == 0) {
                 double h[9];
                 for (int i = 0; i < 8; i++) h[i] = hx[i];
@@ -810,7 +827,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 sh.vec[32] = rv[0]; sh.vec[33] = rv[1]; sh.vec[34] = rv[2];
                 sh.vec[35] = tv[0]; sh.vec[36] = tv[1]; sh.vec[37] = tv[2];
             }
-            __syncthreads();
+            pnp_sync();
 #pragma unroll
             for (int i = 0; i < 6; i++) param[i] = sh.vec[32 + i];
         } else {
@@ -851,7 +868,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         wave_reduce_slab<10>(sx, sh, lane);
         wave_reduce_slab<10>(sy, sh, lane);
         wave_reduce_slab<10>(sq, sh, lane);
-        __syncthreads();
+        pnp_sync();
         if (lane == 0) {
             const int ui[4][4] = { { 0, 1, 2, 3 }, { 1, 4, 5, 6 }, { 2, 5, 7, 8 }, { 3, 6, 8, 9 } };
             for (int a = 0; a < 4; a++)
@@ -862,7 +879,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                     sh.LL[(8 + a) * 12 + c] = sx[u];     sh.LL[(8 + a) * 12 + 4 + c] = sy[u];  sh.LL[(8 + a) * 12 + 8 + c] = sq[u];
                 }
         }
-        __syncthreads();
+        pnp_sync();
         smallest_eigvec_wave<12>(sh.LL, sh.vec, lane);
         if (lane == 0) {
             double* v = sh.vec;
@@ -886,7 +903,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             sh.vec[32] = rv[0]; sh.vec[33] = rv[1]; sh.vec[34] = rv[2];
             sh.vec[35] = tt[0] * nr / sc; sh.vec[36] = tt[1] * nr / sc; sh.vec[37] = tt[2] * nr / sc;
         }
-        __syncthreads();
+        pnp_sync();
 #pragma unroll
         for (int i = 0; i < 6; i++) param[i] = sh.vec[32 + i];
         }   // non-planar (DLT) branch

@@ -198,26 +198,34 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
 // have lower indices than this one, so they were dispatched before it and never wait for anything themselves; should the
 // count still not arrive within 20 ms the frame is solved on what is there and flagged AGT_TRK_CHAIN_TIMEOUT, and the
 // remaining frames of the launch do not wait again -- the launch always drains.
-template <int PPL>
-__device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
+// NWV = 2 (fused step): two waves of the workgroup alternate over the frames.  The wave of frame k+1 waits for that frame's
+// corners, requests and counts them, and only then waits (LDS word sh.seq) for frame k's state update to be complete: the
+// ~1.3 us of HBM latency and bookkeeping at the head of a solve run under the tail of the previous one.  The waves share one
+// scratch area: a wave touches it only between its wait on sh.seq and its own increment of it.  wave: this wave's index.
+template <int PPL, int NWV = 1>
+__device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh, int wave = 0)
 {
     static_assert(sizeof(AgtPnpTables) == 40 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
-    if (S.pnp_nf > 1)
-        for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE)
-            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+    const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
+    if (NWV == 1) {
+        if (S.pnp_nf > 1)
+            for (unsigned i = lane; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE)
+                reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+    }
+    // (NWV == 2: the caller has copied the tables and zeroed sh.seq with the whole workgroup, behind a barrier)
     int late = 0;
-    for (int k = 0; k < S.pnp_nf; k++) {
+    for (int k = wave; k < S.pnp_nf; k += NWV) {
         const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
         const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
         if (k) {
-            __syncthreads();
+            if (NWV == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
             img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
             wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
         }
         if (wait) {
             if (!late) {
                 int timed_out = 0;
-                if (threadIdx.x == 0) {
+                if (lane == 0) {
                     const unsigned long long t0 = wall_clock64();               // 100 MHz
                     while ((int)(__hip_atomic_load(wait + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                         __builtin_amdgcn_s_sleep(4);
@@ -228,7 +236,19 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so, late ? AGT_TRK_CHAIN_TIMEOUT : 0);
+        auto before_state = [&]() {
+            if (NWV > 1) {
+                // frame k - 1 belongs to the other wave: its tracker state (global memory) and the scratch area are ours once
+                // it has counted itself in
+                while (agt_uniform(*(volatile int*)&sh.seq) < k) __builtin_amdgcn_s_sleep(1);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            }
+        };
+        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so, late ? AGT_TRK_CHAIN_TIMEOUT : 0, before_state);
+        if (NWV > 1) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the state and the record are written
+            if (lane == 0) *(volatile int*)&sh.seq = k + 1;
+        }
     }
 }
 
@@ -254,10 +274,17 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
     }
     blk -= S.n_lk;
     if (PNP && blk < S.n_pnp) {
-        if (threadIdx.x >= AGT_WAVE) return;
-        if (blk == 0) SSTAMP_SET(0);
-        pnp_role<1>(S, T, KT, blk, *reinterpret_cast<agt_pnp::PnpShared*>(lds));     // fused path: n <= 64
-        if (blk == 0) SSTAMP_SET(1);
+        // fused path (n <= 64): two waves alternate over the frames (see pnp_role); the whole workgroup sets their scratch up
+        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
+        for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += STEP_THREADS)
+            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+        if (threadIdx.x == 0) sh.seq = 0;
+        __syncthreads();
+        const int wave = (int)(threadIdx.x / AGT_WAVE);
+        if (wave >= 2) return;
+        if (blk == 0 && wave == 0) SSTAMP_SET(0);
+        pnp_role<1, 2>(S, T, KT, blk, sh, wave);
+        if (blk == 0 && wave == 0) SSTAMP_SET(1);
         return;
     }
     if (PNP) blk -= S.n_pnp;
