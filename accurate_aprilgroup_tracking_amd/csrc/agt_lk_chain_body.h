@@ -157,14 +157,19 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 
     // this thread's window pixels / derivative positions as offsets into a 44-B-pitch tile resp. the 22-int-pitch derivative
     // tile (threads without a k-th element point at offset 0 and are masked arithmetically)
+    // window pixels: thread t < 231 owns the horizontal pair (2s, y), (2s + 1, y), s = t mod 11, y = t / 11 (the eleventh
+    // pair of a row has one pixel): the two pixels share two of their bilinear taps per row, in the image tiles (six
+    // byte reads per pair instead of eight) as in the derivative tile (an 8-byte and a 4-byte read per row instead of four)
+    static_assert(C::NPX == 2 && ((WIN + 1) / 2) * WIN <= T, "pairing of the window pixels");
     int oW[C::NPX], oD[C::NPX];
     bool pv[C::NPX];
-#pragma unroll
-    for (int k = 0; k < C::NPX; k++) {
-        const int p = tid + k * T;
-        pv[k] = p < WIN * WIN;
-        const int y = pv[k] ? p / WIN : 0, x = pv[k] ? p - y * WIN : 0;
-        oW[k] = y * JP + x; oD[k] = y * DW + x;
+    {
+        constexpr int PR = (WIN + 1) / 2;
+        const bool v = tid < PR * WIN;
+        const int y = v ? tid / PR : 0, x = v ? 2 * (tid - y * PR) : 0;
+        pv[0] = v; pv[1] = v && x + 1 < WIN;
+        oW[0] = y * JP + x; oW[1] = oW[0] + 1;
+        oD[0] = y * DW + x; oD[1] = oD[0] + 1;
     }
     // Scharr: one horizontal PAIR of derivative positions per thread and level (22 x 11 pairs = 242 threads): the 3 x 4
     // pixels under a pair are three unaligned dwords -- two aligned LDS reads + one v_alignbyte each -- and every tap sum is a
