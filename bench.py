@@ -498,7 +498,7 @@ def h2d_inclusive(torch, bench, K):
 def batch_extra(torch, D, HL, args, rank, dev):
     """BASELINE.json configs[2] side measurement: 64 independent 1280x720 streams per step."""
     a = argparse.Namespace(**vars(args))
-    a.steps, a.warmup, a.streams, a.render_frames = 64, 16, 64, min(args.render_frames, 8)
+    a.steps, a.warmup, a.streams, a.render_frames = 256, 16, 64, min(args.render_frames, 8)
     wl = WORKLOADS["c3"]
     b = Bench(torch, wl, a, rank, 1, dev)
     b.trk.pipeline(16)                       # (the c3 workload's default group size)
