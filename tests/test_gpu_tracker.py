@@ -385,7 +385,9 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
     F = len(s)
     order = (list(range(1, F)) + list(range(F - 2, -1, -1))) * 6 + list(range(1, F))      # 39 steps, never synchronised
     recs = {}
-    for B, depth in ((1, 4), (64, 1), (8, 2)):
+    # (40 streams x 48 corners = 1920: the fused launch with one wave per corner in the LK role, two workgroups per CU, 40
+    # PnP workgroups of two alternating waves chained to it; 64: split mode with the LK launches on two streams)
+    for B, depth in ((1, 4), (64, 1), (8, 2), (40, 8), (64, 16)):
         trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
         trk.pipeline(depth)
         rep = lambda k: frames[k].unsqueeze(0).expand(B, -1, -1).contiguous()
@@ -396,7 +398,7 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
             f = rep(k); keep.append(f)
             trk.step(f, so[i] if len(order) > 1 else so)
         trk.join()
-        recs[B] = so.cpu().numpy().reshape(len(order), B, -1)
+        recs[(B, depth)] = so.cpu().numpy().reshape(len(order), B, -1)
         if B == 64:
             # a reset while frames are still in flight on the library's streams (no join, no sync) starts a clean run
             for i, k in enumerate(order[:7]):
@@ -408,11 +410,11 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
                 f = rep(k); keep.append(f)
                 trk.step(f, so2[i])
             trk.join()
-            assert np.array_equal(so2.cpu().numpy().reshape(6, B, -1), recs[64][:6])
-    for B in (64, 8):
+            assert np.array_equal(so2.cpu().numpy().reshape(6, B, -1), recs[(64, depth)][:6])
+    for (B, depth), r in recs.items():
         for b in range(B):
-            assert np.array_equal(recs[B][:, b], recs[1][:, 0]), "stream %d of %d" % (b, B)
-    assert recs[1][:, 0, 6].all()
+            assert np.array_equal(r[:, b], recs[(1, 4)][:, 0]), "stream %d of %d at depth %d" % (b, B, depth)
+    assert recs[(1, 4)][:, 0, 6].all()
 
 
 def test_mode_changes_between_runs(torch_cuda, seq640):
