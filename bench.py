@@ -416,7 +416,7 @@ def h2d_inclusive(torch, bench, K):
     on the host, detect_pose.py:669-681).  A copy stream uploads chunk c+1 (G frames, one hipMemcpyAsync) while the tracker
     works on chunk c; events order upload -> step and step -> buffer reuse.  Never `value`."""
     W, H, B = bench.W, bench.H, bench.B
-    G, NB, depth = 8, 8, 4                          # frames per upload, chunk buffers on the device, frames per fused launch
+    G, NB, depth = 8, 8, 8                          # frames per upload, chunk buffers on the device, frames per fused launch
     lag = -(-((LEVELS + 2) * depth) // G) + 1       # chunks after which a chunk's frames are dead (pipeline depth, rounded up)
     P = int(np.lcm(bench.period, G))                # whole ping-pong periods AND whole chunks: the sequence stays continuous across the wrap
     assert P + 1 <= bench.ring_slots
@@ -460,10 +460,9 @@ def h2d_inclusive(torch, bench, K):
             up[cb].record(copy_s)
             main_s.wait_event(up[cb])
             tq = time.perf_counter()
-            for g in range(G):
-                k = (c - c0) * G + g
-                bench.trk.step(devb[cb, g], out[k] if out is not None else None)
-                bench.since += 1
+            k0 = (c - c0) * G                              # the chunk as one clip (agt_track_frames): one launch per chunk
+            bench.trk.step_many(devb[cb], out[k0:k0 + G] if out is not None else None)
+            bench.since += G
             tsteps[0] += time.perf_counter() - tq
             done[cb].record(main_s)
     go(20, None, 0)
