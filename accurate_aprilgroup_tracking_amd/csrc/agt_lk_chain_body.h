@@ -16,7 +16,7 @@
 //     its sums cross the waves as int32 hi / lo pairs;
 //   * the result is stored at once (device-scope stores when the PnP role of the same launch waits for it) and counted into
 //     the arrival counter one frame later, under the next frame's image-side work.
-// Measured on production code with fixed iteration counts: 6.1 us per frame + 0.63 us per iteration (profiles/r02_summary.md).
+// Measured on production code with fixed iteration counts: 5.8 us per frame + 0.62 us per iteration (profiles/r02_summary.md).
 // Only what the fused tracker uses is covered: flags == 0, no error output, launches of more than one frame (lk_role keeps
 // lk_body otherwise); the frames of a group share their geometry, the image before the group may differ in pitch.
 #pragma once
@@ -82,6 +82,19 @@ __device__ __forceinline__ int wave_sum_i32(int v)
     v += agt_dpp_i32<0x141>(v);
     v += agt_dpp_i32<0x140>(v);
     return __builtin_amdgcn_readlane(v, 0) + __builtin_amdgcn_readlane(v, 16) + __builtin_amdgcn_readlane(v, 32) + __builtin_amdgcn_readlane(v, 48);
+}
+
+// two 64-lane int32 sums in one DPP chain (v_permlane32_swap: value 0 ends up in the lower half-wave, value 1 in the upper one)
+__device__ __forceinline__ void wave_sum2_i32(int v0, int v1, int& t0, int& t1)
+{
+    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v0, (unsigned)v1, false, false);
+    int x = (int)sw[0] + (int)sw[1];
+    x += agt_dpp_i32<0xB1>(x);
+    x += agt_dpp_i32<0x4E>(x);
+    x += agt_dpp_i32<0x141>(x);
+    x += agt_dpp_i32<0x140>(x);
+    t0 = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16);
+    t1 = __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 
 // The two mismatch sums of one iteration over the four waves, as the floats the 2 x 2 solve needs.  Exact: every operand is
@@ -365,16 +378,21 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         // ---- wave w finishes level w (w + 4, ..): exact sums over the 256 partials, the 2 x 2 system and its eigenvalue test
         CREPS(2)
         for (int l = wave; l < NLEV; l += NW) {
-            float A[3];
+            // exact total = 65536 * sum(hi) + sum(lo) per value, both sums < 2^24 in magnitude: one rounding in the fma, the same
+            // float as (float)(double)(int64 total); the six int32 sums go through three pair chains
+            int s4[3];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 const int* r = red + (3 * l + i) * T + lane;
-                const int s4 = r[0] + r[64] + r[128] + r[192];                   // < 2^27
-                // exact total = 65536 * sum(hi) + sum(lo), both sums < 2^24 in magnitude: one rounding in the fma, the same
-                // float as (float)(double)(int64 total)
-                const int lo = wave_sum_i32(s4 & 0xffff), hi = wave_sum_i32(s4 >> 16);
-                A[i] = fmaf((float)hi, 65536.f, (float)lo) * FLT_SCALE;
+                s4[i] = r[0] + r[64] + r[128] + r[192];                          // < 2^27
             }
+            int lo[3], hi[3];
+            wave_sum2_i32(s4[0] & 0xffff, s4[1] & 0xffff, lo[0], lo[1]);
+            wave_sum2_i32(s4[2] & 0xffff, s4[0] >> 16, lo[2], hi[0]);
+            wave_sum2_i32(s4[1] >> 16, s4[2] >> 16, hi[1], hi[2]);
+            float A[3];
+#pragma unroll
+            for (int i = 0; i < 3; i++) A[i] = fmaf((float)hi[i], 65536.f, (float)lo[i]) * FLT_SCALE;
             const float D = A[0] * A[2] - A[1] * A[1];
             const float minEig = (A[2] + A[0] - sqrtf((A[0] - A[2]) * (A[0] - A[2]) + 4.f * A[1] * A[1])) / (float)(2 * WIN * WIN);
             const bool ok = ((lvA >> l) & 1) && !((double)minEig < min_eig_threshold || D < FLT_EPSILON);
