@@ -383,6 +383,7 @@ def main():
                           "value_p10": round(world * B * K / p90, 2), "value_p90": round(world * B * K / p10, 2)},
                "roofline": roof, "cpu_baseline": cpu,
                "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
+               "chain_timeouts": int(((st_last[:, :, HL.ST_FLAGS].astype(np.int64) & HL.TRK_CHAIN_TIMEOUT) != 0).sum()),
                "render_s": round(bench.render_s, 1), "gathered_shape": list(gathered.shape)}
         out.update(extras)
         if rehearsal:
