@@ -62,12 +62,18 @@ def algorithmic_bytes(W, H, npts):
     return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + npts * LEVELS * 1600 + npts * 21}
 
 
-def pmc_traffic(kernel):
+def pmc_traffic(kernel, launch_us=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/pmc_traffic.json;
-    FETCH_SIZE / WRITE_SIZE are collected in their own runs, never inside this timed program)."""
+    FETCH_SIZE / WRITE_SIZE are collected in their own runs, never inside this timed program).  The entry records the launch
+    duration the kernel had when the counters were taken: a figure whose kernel has since changed by more than 15 % in duration
+    is withheld (null) rather than reported stale."""
     try:
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
-            return json.load(f)[kernel]["traffic_bytes_per_launch"]
+            e = json.load(f)[kernel]
+        ref = e.get("launch_us_at_collection")
+        if launch_us is not None and ref and abs(launch_us / ref - 1.0) > 0.15:
+            return None
+        return e["traffic_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         return None
 
@@ -336,7 +342,7 @@ def main():
             achieved = depth * B * ab["frame"] / (launch_us * 1e-6) / 1e9
             roof = {"bound": "hbm", "kernel": "step_kernel<21,4,3> (fused: LK | PnP chained to it | pyrDown of the next group, %d consecutive frames per launch)" % depth,
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
-                    "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth) if (B == 1 and args.workload == "c2") else None,
+                    "traffic": pmc_traffic("step_kernel<21,4,3> depth %d" % depth, launch_us) if (B == 1 and args.workload == "c2") else None,
                     "frac_of_measured_copy_6290GBs": round(achieved / 6290.0, 6),
                     "avg_launch_us": round(launch_us, 3), "frames_per_launch": depth, "bytes_per_launch": int(depth * B * ab["frame"]),
                     "one_frame_per_launch": {"avg_launch_us": round(launch_us_d1, 3), "frames_per_s": round(B / (launch_us_d1 * 1e-6), 1)},

@@ -82,6 +82,13 @@ for kind in ("fetch", "write"):
             pmc[run]["_frames_per_launch"] = b["roofline"]["frames_per_launch"]
 json.dump(pmc, open(os.path.join(dst, "r02_pmc_raw.json"), "w"), indent=1)
 
+# launch period per depth from the kernel-trace-only runs (the counter passes themselves slow the kernels down by ~30 %)
+stats_launch_us = {}
+for d in sorted(glob.glob(os.path.join(src, "*_stats"))):
+    b = bench_line(os.path.basename(d))
+    r = (b or {}).get("roofline", {})
+    if (b or {}).get("config", {}).get("workload", "").startswith("c2") and r.get("frames_per_launch"):
+        stats_launch_us[r["frames_per_launch"]] = r.get("avg_launch_us")
 tp = os.path.join(dst, "pmc_traffic.json")
 traffic = json.load(open(tp))
 for run, ks in pmc.items():
@@ -93,7 +100,10 @@ for run, ks in pmc.items():
             "workload": "c2: 1 x 1280x720 stream, %d frames per chained launch (full launches only)" % F,
             "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": e["FETCH_SIZE_KiB_mean"], "WRITE_SIZE_KiB_mean": e["WRITE_SIZE_KiB_mean"],
             "traffic_bytes_per_launch": int(round((2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024)),
-            "algorithmic_bytes_per_launch": 1441008 * F, "build": "round 2 final (chained launch, frame-chained LK role)"}
+            "algorithmic_bytes_per_launch": 1441008 * F, "build": "round 2 final (chained launch, frame-chained LK role)",
+            # launch period bench.py measured (HIP events) in the run the counters were taken in: bench.py withholds the figure
+            # when its own launch period has moved away from this by more than 15 %
+            "launch_us_at_collection": stats_launch_us.get(F)}
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({r: {k: v for k, v in d["kernels"].items()} for r, d in durations.items()}, indent=1)[:6000])
 print(json.dumps({k: v for k, v in traffic.items() if "depth" in k}, indent=1))
