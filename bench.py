@@ -370,6 +370,7 @@ def main():
             bench.trk.pipeline(depth)
             extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
             extras["per_call_latency_us"] = per_call_latency(bench)
+            extras["live_frame_latency_us"] = live_latency(bench)
 
         cpu = pose_err = None
         if not args.no_cpu_baseline and world == 1:
@@ -535,6 +536,28 @@ def native_oracle():
         _native.append(cvo.select_native() if cvo._lib is None else cvo.BUILD_FLAGS)
         cvo.build()
     return cvo, _native[0]
+
+
+def live_latency(bench, n=300):
+    """The reference's own use: ONE camera, one frame at a time -- hand the frame over, wait for its pose (step + join +
+    synchronize per frame, one frame per launch: a pyramid launch, then LK + PnP chained in one launch).  Median / p90 of the
+    host-observed time from the call to the finished record, frames resident in HBM."""
+    torch = bench.torch
+    bench.trk.pipeline(1)
+    bench.restart()
+    out = torch.zeros((bench.B, 16), dtype=torch.float64, device=bench.dev)
+    ts = []
+    for k in range(n + 20):
+        f = bench.ring[(k + 1) % bench.ring_slots]
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        bench.trk.step(f, out); bench.trk.join(); torch.cuda.synchronize()
+        if k >= 20:
+            ts.append(time.perf_counter() - t0)
+    ts = np.array(ts) * 1e6
+    ok = float(out.cpu().numpy()[:, 6].mean())
+    return {"median": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1), "frames": n, "last_accepted": ok,
+            "note": "step + join + synchronize per frame at one frame per launch (2 launches per frame)"}
 
 
 def per_call_latency(bench):
