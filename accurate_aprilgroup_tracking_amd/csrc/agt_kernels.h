@@ -68,6 +68,12 @@ struct AgtPnpParams {
     int reproject;
     int min_points;                // corners needed to attempt a pose (8 = two tags)
     double gate_px;                // reprojection gate (2.0, detect_pose.py:539)
+    int tag_gate;                  // 4: a corner counts only while all four corners of its tag are usable (the reference solves on
+                                   // whole tags, detect_pose.py:400-437, :494-496); 0: every usable corner counts
+    int pad_;
+    int* fault;                    // chained launch: host-mapped word set to 1 when a wait gave up (agt_synchronize reports it), or null
+    float* seed_pts;               // agt_track_frame_detected: the detector's corner table (img, mask) becomes the frame's corner set
+    uint8_t* seed_status;          // / LK status ([B][n][2], [B][n]: the tracker's ring entry of the frame), or null
 };
 
 // device-resident per-stream tracker state: the attributes of PoseDetector
@@ -84,7 +90,9 @@ struct AgtTrackState {
     int frame;
     int guess_t_f32;        // dtype of extrinsic_guess[1] is float32 (from get_rmat_tvec, transform_helper.py:158-159)
     int prev_t_f32;         // dtype of prev_transform[1] is float32
-    int pad[2];
+    int chain_fault;        // sticky: a chained launch gave up waiting for this stream's corners (AGT_TRK_CHAIN_TIMEOUT); the stream's
+                            // state is frozen and every later record is flagged invalid until agt_tracker_reset
+    int pad;
 };
 
 // one fused launch (agt_step.hip): block ranges [LK | PnP | pyr stage 0 | stage 1 | ..]; every role advances

@@ -232,6 +232,12 @@ struct LkFrameIo {
 // result is written with device-scope stores (write-through past the L2) and the arrival is counted only after every one of
 // them has been acknowledged.
 // count the corner in: every store of the calling lane has been acknowledged first (lk_publish_stores of this frame)
+// The ordering below is hand-written for the gfx9 family: stores are counted in vmcnt there, and the sc1 write-through stores
+// of lk_publish_stores are acknowledged by memory before vmcnt drops.  A target with a separate store counter (vscnt,
+// gfx10+) would turn this into a silent data race, so the file refuses to compile for anything else.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__) && !defined(__gfx942__)
+#error "agt_lk_body.h: the chained-launch publish/arrive ordering (s_waitcnt vmcnt(0) + relaxed agent-scope add) is only valid on gfx942 / gfx950"
+#endif
 __device__ __forceinline__ void lk_arrive(unsigned* done, int b)
 {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -58,6 +58,7 @@ struct PnpShared {
     double vec[48];
     unsigned long long tab[5 * AGT_MAX_GROUP];     // fused step: copy of AgtPnpTables (img / mask / so / wait / target per frame)
     int seq;                                       // fused step, two alternating waves: frames of this launch whose state update is complete
+    int late;                                      // fused step: one of the two waves gave up a chained wait (the other stops waiting too)
 };
 
 // sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
@@ -498,11 +499,52 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             cnt++;
         }
     }
+    if (P.seed_pts) {
+        // detector-fed frame of the tracker: the supplied table is the corner set LK of the NEXT frame starts from
+        // (detect_pose.py:400-437 -> the north-star LK step), a corner the detector did not deliver is not trackable
+        for (int i = lane; i < n; i += AGT_WAVE) {
+            P.seed_pts[((long)b * n + i) * 2] = (float)img[i * 2]; P.seed_pts[((long)b * n + i) * 2 + 1] = (float)img[i * 2 + 1];
+            P.seed_status[(long)b * n + i] = (!mask || mask[i] != 0) ? 1 : 0;
+        }
+    }
+    if (P.tag_gate) {
+        // the reference solves on whole tags (detect_pose.py:400-437 collects four corners per detection, :494-496 wants two tags):
+        // a corner counts only while its tag's other three do.  Tag t = corners 4t..4t+3 = one aligned quad of lanes (same q).
+        cnt = 0;
+#pragma unroll
+        for (int q = 0; q < PPL; q++) {
+            int u = use[q] ? 1 : 0;
+            u &= agt_dpp_i32<0xB1>(u);          // quad_perm [1,0,3,2]
+            u &= agt_dpp_i32<0x4E>(u);          // quad_perm [2,3,0,1]
+            use[q] = u != 0;
+            if (!use[q]) X[q] = Y[q] = Z[q] = mu_[q] = mv_[q] = 0.0;
+            cnt += u;
+        }
+    }
     const int n_used = (int)agt_wave_sum_i64(cnt);
     before_state();
     int flags = extra_flags;          // AGT_TRK_CHAIN_TIMEOUT from the chained launch, reported with the frame's record
     double param[6];
     AgtTrackState* ts = P.track ? P.track + b : nullptr;
+    if (ts && (agt_uniform(ts->chain_fault) | (extra_flags & AGT_TRK_CHAIN_TIMEOUT))) {
+        // Fail-stop: the chained wait for this stream's corners gave up, now or in an earlier frame.  Nothing is
+        // solved on a possibly stale ring entry and the motion-model state is not touched: the record is invalid and flagged,
+        // and so is every later one of the stream until agt_tracker_reset.
+        if (lane == 0) {
+            ts->chain_fault = 1; ts->frame++;
+            if (P.fault) __hip_atomic_store(P.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            if (P.dense_pose) {
+                for (int i = 0; i < AGT_DENSE_STRIDE; i++) P.dense_rec[(long)b * AGT_DENSE_STRIDE + i] = 0.0;
+                P.dense_done[b] = 1;
+            }
+            if (so_p) {
+                double* so = so_p + (long)b * AGT_STATE_STRIDE;
+                for (int i = 0; i < AGT_STATE_STRIDE; i++) so[i] = 0.0;
+                so[AGT_ST_NTRACK] = n_used; so[AGT_ST_FLAGS] = AGT_TRK_CHAIN_TIMEOUT;
+            }
+        }
+        return;
+    }
     bool use_guess = P.use_guess != 0;
     double unchanged_prev[6] = { 0, 0, 0, 0, 0, 0 };
     int had_guess = 0, guess_f32 = 0, prev_f32 = 0;

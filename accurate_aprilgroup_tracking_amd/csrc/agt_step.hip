@@ -45,6 +45,8 @@ extern "C" int agt_debug_step_stamps(unsigned long long* host16, int reset)
 namespace {
 
 constexpr int STEP_THREADS = 256;
+// chained launch: polls of an arrival counter before the waiting wave gives up (each poll is a device-scope load + s_sleep, >= 0.5 us)
+constexpr unsigned AGT_CHAIN_POLLS = 1u << 16;
 
 typedef const __attribute__((address_space(4))) AgtStepParams* KParams;
 typedef const __attribute__((address_space(4))) AgtStepTables* KTables;
@@ -196,8 +198,11 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
 // the wave waits until the counter reaches the frame's corner count (every lk_publish of the frame has been acknowledged by
 // memory), then drops whatever its own L1 / L2 hold of the corner arrays (acquire at device scope).  The LK workgroups
 // have lower indices than this one, so they were dispatched before it and never wait for anything themselves; should the
-// count still not arrive within 20 ms the frame is solved on what is there and flagged AGT_TRK_CHAIN_TIMEOUT, and the
-// remaining frames of the launch do not wait again -- the launch always drains.
+// count still not arrive within AGT_CHAIN_POLLS polls (>= 30 ms of executing time) the wave gives up: the frame is NOT solved,
+// its record is flagged AGT_TRK_CHAIN_TIMEOUT and invalid, the stream's tracker state is frozen behind a sticky fault word
+// (AgtTrackState::chain_fault; every later record of the stream is flagged too, until agt_tracker_reset), the context's
+// host-mapped fault word is set (agt_synchronize / agt_tracker_join then return AGT_ERR_CHAIN), and neither the remaining
+// frames of the launch nor later launches wait again for that stream -- the launch always drains.
 // NWV = 2 (fused step): two waves of the workgroup alternate over the frames.  The wave of frame k+1 waits for that frame's
 // corners, requests and counts them, and only then waits (LDS word sh.seq) for frame k's state update to be complete: the
 // ~1.3 us of HBM latency and bookkeeping at the head of a solve run under the tail of the previous one.  The waves share one
@@ -226,11 +231,18 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
             if (!late) {
                 int timed_out = 0;
                 if (lane == 0) {
-                    const unsigned long long t0 = wall_clock64();               // 100 MHz
+                    // The give-up budget counts POLLS, not wall time (a preempted queue -- ranks sharing a card, a
+                    // debugger -- must not trip it): 2^16 polls of >= 0.5 us each are >= 30 ms of this wave EXECUTING.  While
+                    // polling the wave also watches for a give-up of the workgroup's other wave (sh.late) and for the stream's
+                    // sticky fault word (set by an earlier launch): a faulted stream never waits again.
+                    const int* fault = &S.pnp.track[blk].chain_fault;
+                    unsigned polls = 0;
                     while ((int)(__hip_atomic_load(wait + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
                         __builtin_amdgcn_s_sleep(4);
-                        if (wall_clock64() - t0 > 2000000ull) { timed_out = 1; break; }
+                        if ((NWV > 1 && *(volatile int*)&sh.late) || ++polls > AGT_CHAIN_POLLS ||
+                            ((polls & 15) == 1 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { timed_out = 1; break; }
                     }
+                    if (timed_out && NWV > 1) *(volatile int*)&sh.late = 1;
                 }
                 late = agt_uniform(__shfl(timed_out, 0));
             }
@@ -278,7 +290,7 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
         agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
         for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += STEP_THREADS)
             reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
-        if (threadIdx.x == 0) sh.seq = 0;
+        if (threadIdx.x == 0) { sh.seq = 0; sh.late = 0; }
         __syncthreads();
         const int wave = (int)(threadIdx.x / AGT_WAVE);
         if (wave >= 2) return;

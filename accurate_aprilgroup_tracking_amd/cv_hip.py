@@ -11,6 +11,7 @@ PyTorch-ROCm is used only as the device-buffer allocator / stream provider
 without the HIP library or a GPU these functions raise.
 """
 import ctypes as C
+import threading
 import numpy as np
 import torch
 
@@ -58,6 +59,11 @@ class Context:
         self.width, self.height, self.max_level, self.win = width, height, max_level, win
         self.max_points, self.max_streams = max_points, max_streams
         self._keep = {}          # frames aliased by pyramid level 0 must stay alive
+        # a context is not re-entrant (include/agt_hip.h): the cv2-shaped functions below, which share cached contexts
+        # between callers, hold this lock from staging their inputs to reading their outputs (cv2's own functions are
+        # re-entrant; two threads calling cv_hip.solvePnP must not see each other's staging buffer)
+        self.lock = threading.RLock()
+        self._staging = None
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -244,15 +250,17 @@ class Context:
 # numpy-in / numpy-out functions with cv2's signatures (one synchronous call per frame,
 # exactly how the reference uses cv2, detect_pose.py:669-681)
 _ctx_cache = {}
+_ctx_cache_lock = threading.Lock()
 
 
 def _context(width, height, max_level, win, n):
+    """cached context for one geometry; the caller takes ctx.lock around its use (and calls ctx.use_current_stream() inside)"""
     key = (width, height, max_level, win, torch.cuda.current_device())
-    ctx = _ctx_cache.get(key)
-    if ctx is None or ctx.max_points < n:
-        ctx = Context(width, height, max_level=max_level, win=win, max_points=max(64, min(256, n)), max_streams=1)
-        _ctx_cache[key] = ctx
-    ctx.use_current_stream()
+    with _ctx_cache_lock:
+        ctx = _ctx_cache.get(key)
+        if ctx is None or ctx.max_points < n:
+            ctx = Context(width, height, max_level=max_level, win=win, max_points=max(64, min(256, n)), max_streams=1)
+            _ctx_cache[key] = ctx
     return ctx
 
 
@@ -292,14 +300,12 @@ class _Staging:
         H.check(self.ctx.L.agt_download(self.ctx.h, C.c_void_p(self.hbase + off), C.c_void_p(self.base + off), nbytes), "agt_download")
 
 
-_staging = {}
-
-
 def _stage(ctx):
-    st = _staging.get(id(ctx))
-    if st is None:
-        st = _staging[id(ctx)] = _Staging(ctx)
-    return st
+    """the context's staging buffers (kept ON the context: an id()-keyed table would hand a dead context's buffers to a new
+    context that happens to reuse the address); call with ctx.lock held"""
+    if ctx._staging is None:
+        ctx._staging = _Staging(ctx)
+    return ctx._staging
 
 
 def getOptimalNewCameraMatrix(cameraMatrix, distCoeffs, imageSize, alpha, newImgSize=(0, 0)):
@@ -328,7 +334,6 @@ def _undistort_context(w, h, K, dist, newK):
         ctx.undistort_init(K, dist, newK, w, h)
         _undist_cache.clear()
         _undist_cache[key] = ctx
-    ctx.use_current_stream()
     return ctx
 
 
@@ -339,9 +344,12 @@ def undistort(src, cameraMatrix, distCoeffs, dst=None, newCameraMatrix=None):
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
         raise error("undistort: an 8-bit 3-channel frame is expected")
     h, w = a.shape[:2]
-    ctx = _undistort_context(w, h, cameraMatrix, distCoeffs, newCameraMatrix)
-    out = ctx.undistort_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0))
-    return out[0].cpu().numpy()
+    with _ctx_cache_lock:
+        ctx = _undistort_context(w, h, cameraMatrix, distCoeffs, newCameraMatrix)
+    with ctx.lock:
+        ctx.use_current_stream()
+        out = ctx.undistort_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0))
+        return out[0].cpu().numpy()
 
 
 def cvtColor(src, code):
@@ -353,8 +361,10 @@ def cvtColor(src, code):
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
         raise error("cvtColor: an 8-bit 3-channel frame is expected")
     ctx = _geom_context(1)
-    out = ctx.preprocess_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0), None, undistort=False)
-    return out[0].cpu().numpy()
+    with ctx.lock:
+        ctx.use_current_stream()
+        out = ctx.preprocess_bgr(torch.from_numpy(np.ascontiguousarray(a)).cuda().unsqueeze(0), None, undistort=False)
+        return out[0].cpu().numpy()
 
 
 def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 21), maxLevel=3,
@@ -377,18 +387,20 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
         ctx = _context(w, h, maxLevel, winSize[0], n)
     except H.AgtError as e:
         raise error(str(e))
-    wp = (w + 3) & ~3
-    dev = torch.device("cuda", ctx.device)
-    fa = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fa[0, :, :w] = torch.from_numpy(a).to(dev)
-    fb = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fb[0, :, :w] = torch.from_numpy(b).to(dev)
-    ctx.pyramid_build(0, fa[:, :, :w])      # views keep the padded pitch (multiple of 4)
-    ctx.pyramid_build(1, fb[:, :, :w])
-    pp = torch.from_numpy(pts).to(dev).reshape(1, n, 2).contiguous()
-    nx = None
-    if nextPts is not None and (flags & OPTFLOW_USE_INITIAL_FLOW):
-        nx = torch.from_numpy(np.ascontiguousarray(np.asarray(nextPts, np.float32).reshape(1, n, 2))).to(dev)
-    nx, st, er = ctx.lk_track(0, 1, pp, nx, criteria=criteria, flags=flags, min_eig_threshold=minEigThreshold)
-    return (nx.cpu().numpy().reshape(n, 1, 2), st.cpu().numpy().reshape(n, 1), er.cpu().numpy().reshape(n, 1))
+    with ctx.lock:
+        ctx.use_current_stream()
+        wp = (w + 3) & ~3
+        dev = torch.device("cuda", ctx.device)
+        fa = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fa[0, :, :w] = torch.from_numpy(a).to(dev)
+        fb = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fb[0, :, :w] = torch.from_numpy(b).to(dev)
+        ctx.pyramid_build(0, fa[:, :, :w])      # views keep the padded pitch (multiple of 4)
+        ctx.pyramid_build(1, fb[:, :, :w])
+        pp = torch.from_numpy(pts).to(dev).reshape(1, n, 2).contiguous()
+        nx = None
+        if nextPts is not None and (flags & OPTFLOW_USE_INITIAL_FLOW):
+            nx = torch.from_numpy(np.ascontiguousarray(np.asarray(nextPts, np.float32).reshape(1, n, 2))).to(dev)
+        nx, st, er = ctx.lk_track(0, 1, pp, nx, criteria=criteria, flags=flags, min_eig_threshold=minEigThreshold)
+        return (nx.cpu().numpy().reshape(n, 1, 2), st.cpu().numpy().reshape(n, 1), er.cpu().numpy().reshape(n, 1))
 
 
 def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tvec=None,
@@ -412,34 +424,36 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
     ctx = _geom_context(n)
     if useExtrinsicGuess and (rvec is None or tvec is None or np.size(rvec) != 3 or np.size(tvec) != 3):
         raise error("solvePnP: useExtrinsicGuess needs 3-element rvec and tvec")
-    # one pinned staging buffer: [obj | img | pose] up in one copy, [pose | info] down in one copy
-    st = _stage(ctx)
-    st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
-    st.view(st.IMG, n * 2, dt)[:] = img.reshape(-1)
-    g = st.f64(st.POSE, 6)
-    if useExtrinsicGuess:
-        g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
-    else:
-        g[:] = 0.0
-    st.upload(0, st.OUT)
-    Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
-    base = st.base
-    rc = ctx.L.agt_solve_pnp(ctx.h, C.c_void_p(base + st.OBJ), 0, C.c_void_p(base + st.IMG), H.F32 if dt == np.float32 else H.F64,
-                             None, n, 1, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
-                             C.c_void_p(base + st.POSE), 1 if useExtrinsicGuess else 0, C.c_void_p(base + st.OUT), None)
-    if rc:
-        raise error(str(H.AgtError(rc, "agt_solve_pnp")))
-    st.download(st.POSE, 64)                                   # pose | info
-    inf = st.view(st.OUT, 4, np.int32)
-    p = st.f64(st.POSE, 6).copy()
-    if not inf[H.INFO_OK]:
-        raise error("solvePnP: not enough usable points (non-planar sets need 6 without a guess)")
-    if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
-            and rvec.dtype in (np.float32, np.float64) and tvec.dtype in (np.float32, np.float64):
-        rvec.reshape(-1)[:] = p[:3]
-        tvec.reshape(-1)[:] = p[3:]
-        return True, rvec, tvec
-    return True, p[:3].reshape(3, 1).copy(), p[3:].reshape(3, 1).copy()
+    with ctx.lock:
+        ctx.use_current_stream()
+        # one pinned staging buffer: [obj | img | pose] up in one copy, [pose | info] down in one copy
+        st = _stage(ctx)
+        st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
+        st.view(st.IMG, n * 2, dt)[:] = img.reshape(-1)
+        g = st.f64(st.POSE, 6)
+        if useExtrinsicGuess:
+            g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
+        else:
+            g[:] = 0.0
+        st.upload(0, st.OUT)
+        Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
+        base = st.base
+        rc = ctx.L.agt_solve_pnp(ctx.h, C.c_void_p(base + st.OBJ), 0, C.c_void_p(base + st.IMG), H.F32 if dt == np.float32 else H.F64,
+                                 None, n, 1, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
+                                 C.c_void_p(base + st.POSE), 1 if useExtrinsicGuess else 0, C.c_void_p(base + st.OUT), None)
+        if rc:
+            raise error(str(H.AgtError(rc, "agt_solve_pnp")))
+        st.download(st.POSE, 64)                                   # pose | info
+        inf = st.view(st.OUT, 4, np.int32)
+        p = st.f64(st.POSE, 6).copy()
+        if not inf[H.INFO_OK]:
+            raise error("solvePnP: not enough usable points (non-planar sets need 6 without a guess)")
+        if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
+                and rvec.dtype in (np.float32, np.float64) and tvec.dtype in (np.float32, np.float64):
+            rvec.reshape(-1)[:] = p[:3]
+            tvec.reshape(-1)[:] = p[3:]
+            return True, rvec, tvec
+        return True, p[:3].reshape(3, 1).copy(), p[3:].reshape(3, 1).copy()
 
 
 def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, jacobian=False):
@@ -450,28 +464,30 @@ def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, jacobian=F
     obj = np.ascontiguousarray(obj.reshape(-1, 3), dtype=dt)
     n = obj.shape[0]
     ctx = _geom_context(min(n, 256))
-    if n <= 256:
-        # staged path: [obj | pose] up in one copy, [points (| Jacobian)] down in one copy
-        st = _stage(ctx)
-        st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
-        g = st.f64(st.POSE, 6)
-        g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
-        st.upload(0, st.OUT)
-        Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
-        rc = ctx.L.agt_project_points(ctx.h, C.c_void_p(st.base + st.OBJ), 0, H.F32 if dt == np.float32 else H.F64, n, 1,
-                                      C.c_void_p(st.base + st.POSE), Kh.ctypes.data_as(C.c_void_p),
-                                      dh.ctypes.data_as(C.c_void_p) if nd else None, nd, C.c_void_p(st.base + st.PTS),
-                                      C.c_void_p(st.base + st.JAC) if jacobian else None)
-        if rc:
-            raise error(str(H.AgtError(rc, "agt_project_points")))
-        st.download(st.PTS, (st.JAC - st.PTS) + (2 * n * 6 * 8 if jacobian else 0) if jacobian else n * 2 * np.dtype(dt).itemsize)
-        pts = st.view(st.PTS, n * 2, dt).reshape(n, 1, 2).copy()
-        return pts, (st.f64(st.JAC, 2 * n * 6).reshape(2 * n, 6).copy() if jacobian else None)
-    dev = torch.device("cuda", ctx.device)
-    g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
-    pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
-    try:
-        out, jac = ctx.project_points(torch.from_numpy(obj).to(dev), pose, cameraMatrix, distCoeffs, jacobian)
-    except H.AgtError as e:
-        raise error(str(e))
-    return out.cpu().numpy().reshape(n, 1, 2), (jac.cpu().numpy().reshape(2 * n, 6) if jacobian else None)
+    with ctx.lock:
+        ctx.use_current_stream()
+        if n <= 256:
+            # staged path: [obj | pose] up in one copy, [points (| Jacobian)] down in one copy
+            st = _stage(ctx)
+            st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
+            g = st.f64(st.POSE, 6)
+            g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
+            st.upload(0, st.OUT)
+            Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
+            rc = ctx.L.agt_project_points(ctx.h, C.c_void_p(st.base + st.OBJ), 0, H.F32 if dt == np.float32 else H.F64, n, 1,
+                                          C.c_void_p(st.base + st.POSE), Kh.ctypes.data_as(C.c_void_p),
+                                          dh.ctypes.data_as(C.c_void_p) if nd else None, nd, C.c_void_p(st.base + st.PTS),
+                                          C.c_void_p(st.base + st.JAC) if jacobian else None)
+            if rc:
+                raise error(str(H.AgtError(rc, "agt_project_points")))
+            st.download(st.PTS, (st.JAC - st.PTS) + (2 * n * 6 * 8 if jacobian else 0) if jacobian else n * 2 * np.dtype(dt).itemsize)
+            pts = st.view(st.PTS, n * 2, dt).reshape(n, 1, 2).copy()
+            return pts, (st.f64(st.JAC, 2 * n * 6).reshape(2 * n, 6).copy() if jacobian else None)
+        dev = torch.device("cuda", ctx.device)
+        g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
+        pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()
+        try:
+            out, jac = ctx.project_points(torch.from_numpy(obj).to(dev), pose, cameraMatrix, distCoeffs, jacobian)
+        except H.AgtError as e:
+            raise error(str(e))
+        return out.cpu().numpy().reshape(n, 1, 2), (jac.cpu().numpy().reshape(2 * n, 6) if jacobian else None)

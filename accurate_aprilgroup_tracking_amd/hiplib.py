@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libagt_hip.so")
 
 AGT_OK = 0
-ERRORS = {-1: "ARG", -2: "ALLOC", -3: "DIST", -4: "NPOINTS", -5: "HIP", -6: "UNSUPPORTED", -7: "STATE"}
+ERRORS = {-1: "ARG", -2: "ALLOC", -3: "DIST", -4: "NPOINTS", -5: "HIP", -6: "UNSUPPORTED", -7: "STATE", -8: "CHAIN"}
 MAX_LEVELS = 6
 LK_USE_INITIAL_FLOW, LK_GET_MIN_EIGENVALS = 4, 8
 TERM_COUNT, TERM_EPS = 1, 2
@@ -37,6 +37,7 @@ SYMBOLS = [
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
     "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense", "agt_upload", "agt_download",
+    "agt_tracker_tag_gate", "agt_track_frame_detected",
 ]
 
 
@@ -95,6 +96,8 @@ def lib():
     L.agt_tracker_state_read.argtypes = [vp, vp, i32]
     L.agt_track_frame.argtypes = [vp, vp, sz, sz, i32, vp]
     L.agt_track_frames.argtypes = [vp, vp, sz, sz, sz, i32, i32, vp]
+    L.agt_tracker_tag_gate.argtypes = [vp, i32]
+    L.agt_track_frame_detected.argtypes = [vp, vp, sz, sz, i32, vp, vp, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]
     L.agt_tracker_pipeline.argtypes = [vp, i32]
     L.agt_tracker_join.argtypes = [vp]

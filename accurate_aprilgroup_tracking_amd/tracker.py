@@ -19,7 +19,7 @@ class TrackState(C.Structure):
     _fields_ = [("guess", C.c_double * 6), ("prev", C.c_double * 6), ("rot_vel", (C.c_double * 9) * 2),
                 ("tran_vel", (C.c_double * 3) * 2), ("prev_R", C.c_double * 9), ("has_guess", C.c_int), ("has_prev", C.c_int),
                 ("n_vel", C.c_int), ("frame", C.c_int), ("guess_t_f32", C.c_int), ("prev_t_f32", C.c_int),
-                ("pad", C.c_int * 2)]
+                ("chain_fault", C.c_int), ("pad", C.c_int)]
 
 
 class StreamTracker:
@@ -48,7 +48,8 @@ class StreamTracker:
         """frames: cuda u8 [B,H,W] in which `corners` (cuda f32 [B,n,2]) were seen.  With both None
         only `estimate_pose` (detector-supplied corners) can be used afterwards."""
         self.ctx.use_current_stream()
-        self.join()                 # frames in flight come first: slot 0 is a ring entry of the running tracker
+        # (frames in flight come first -- slot 0 is a ring entry of the running tracker: agt_pyramid_build and
+        # agt_tracker_reset both drain the pipeline themselves; reset is also the recovery from AGT_ERR_CHAIN)
         if frames is not None:
             self.ctx.pyramid_build(0, frames)
             assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)
@@ -71,8 +72,29 @@ class StreamTracker:
         pyramid ring aliases it).  state_out: cuda f64 [B, STATE_STRIDE] or None; with the pipeline on
         it is written a few steps later -- call join() before consuming it.  Enqueues only."""
         assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
+        assert tuple(frames.shape[1:]) == (self.ctx.height, self.ctx.width) and frames.stride(2) == 1, "frames must be [B, H, W] with unit pixel stride"
         H.check(self.ctx.L.agt_track_frame(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
                                            _ptr(state_out)), "agt_track_frame")
+        self._alive.append(frames)
+        if len(self._alive) > self._keep_frames:
+            del self._alive[0]
+        return state_out
+
+    def tag_gate(self, corners_per_tag=4):
+        """4: the pose solve uses a corner only while all four corners of its tag are usable, min_points = 8 then is the
+        reference's ">= 2 tags" (detect_pose.py:494-496).  0: every usable corner counts (the default of the C ABI)."""
+        H.check(self.ctx.L.agt_tracker_tag_gate(self.ctx.h, int(corners_per_tag)), "agt_tracker_tag_gate")
+
+    def step_detected(self, frames, corners, mask=None, state_out=None):
+        """A detector-fed frame (detect_pose.py:576-609 with >= 2 tags found): `frames` joins the stream (the next step()
+        tracks FROM it), `corners` cuda f32 [B,n,2] / `mask` cuda u8 [B,n] become its corner set and LK status and
+        _estimate_pose runs on them.  Enqueues only; the record is complete in stream order."""
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B and frames.stride(2) == 1
+        assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)
+        if mask is not None:
+            assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (self.B, self.n)
+        H.check(self.ctx.L.agt_track_frame_detected(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,
+                                                    _ptr(corners), _ptr(mask), _ptr(state_out)), "agt_track_frame_detected")
         self._alive.append(frames)
         if len(self._alive) > self._keep_frames:
             del self._alive[0]
@@ -82,6 +104,7 @@ class StreamTracker:
         """A clip of consecutive frames in one call: clip cuda u8 [K,B,H,W], state_out cuda f64 [K,B,STATE_STRIDE] or None.
         Same as K calls of step() (same launches, same records) without the per-call host cost.  Enqueues only."""
         assert clip.dtype == torch.uint8 and clip.is_cuda and clip.dim() == 4 and clip.shape[1] == self.B
+        assert tuple(clip.shape[2:]) == (self.ctx.height, self.ctx.width) and clip.stride(3) == 1, "clip frames must be H x W with unit pixel stride"
         K = clip.shape[0]
         if state_out is not None:
             assert state_out.is_contiguous() and tuple(state_out.shape) == (K, self.B, H.STATE_STRIDE)

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 200
+#define AGT_VERSION 300
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -44,6 +44,8 @@ extern "C" {
 #define AGT_ERR_HIP         (-5)   /* a HIP runtime call failed; see agt_last_hip_error */
 #define AGT_ERR_UNSUPPORTED (-6)   /* e.g. LK window size not compiled in */
 #define AGT_ERR_STATE       (-7)   /* pyramid slot not built, context mismatch */
+#define AGT_ERR_CHAIN       (-8)   /* a chained launch gave up waiting for a stream's corners (records flagged AGT_TRK_CHAIN_TIMEOUT);
+                                      reported by agt_synchronize / agt_tracker_join until agt_tracker_reset */
 
 #define AGT_MAX_LEVELS 6
 
@@ -78,7 +80,8 @@ extern "C" {
 #define AGT_ST_FLAGS   11   /* AGT_PNP_* bits | AGT_TRK_* bits */
 #define AGT_ST_TVEC_F32 12  /* 1.0 = tvec carries float32 precision (cv2 wrote it into the f32 guess array) */
 #define AGT_TRK_ZERO_VELOCITY 256  /* a velocity element was exactly 0: reference raises ValueError (detect_pose.py:236-237) */
-#define AGT_TRK_CHAIN_TIMEOUT 512  /* pipelined tracker: the pose solve gave up waiting (20 ms) for the frame's corners; the record is invalid */
+#define AGT_TRK_CHAIN_TIMEOUT 512  /* pipelined tracker: the pose solve gave up waiting for the frame's corners (or did so for an earlier frame of
+                                      the stream): nothing was solved, the record is invalid, the stream's state is frozen until agt_tracker_reset */
 
 typedef struct agt_ctx agt_ctx;
 
@@ -101,7 +104,7 @@ int  agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out);
 int  agt_destroy(agt_ctx* ctx);
 int  agt_set_stream(agt_ctx* ctx, void* hip_stream);
 int  agt_last_hip_error(const agt_ctx* ctx);   /* hipError_t of the last failing HIP call */
-int  agt_synchronize(agt_ctx* ctx);            /* hipStreamSynchronize(ctx stream) */
+int  agt_synchronize(agt_ctx* ctx);            /* joins the tracker pipeline, then hipStreamSynchronize(ctx stream); AGT_ERR_CHAIN after a chain give-up */
 
 /* ---- staging copies for host-array callers (the cv2-shaped Python functions): both on the context's stream;
  * agt_upload enqueues host -> device (pin the host buffer for it to be asynchronous), agt_download enqueues device -> host
@@ -169,6 +172,10 @@ int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const floa
  * min_points: corners needed to attempt a pose (default 8 = the reference's >= 2 tags, detect_pose.py:494-496).
  * gate_px: reprojection gate (default 2.0, detect_pose.py:539). */
 int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate_px);
+/* corners_per_tag = 4: the pose solve of the tracker uses a corner only while all four corners of its tag (corners 4t..4t+3)
+ * are usable, and min_points = 8 then means the reference's ">= 2 tags" (detect_pose.py:494-496; its detections are whole
+ * tags, :400-437).  0 (default): every usable corner counts. */
+int agt_tracker_tag_gate(agt_ctx* ctx, int corners_per_tag);
 /* Software pipelining across frames.  depth 0: separate launches per stage, the record of frame t is complete
  * in stream order after its call.  depth F in 1..32 (default 1; needs reproject == 0, otherwise the call falls back to
  * depth 0 behaviour): agt_track_frame registers the frame and, every F calls, issues ONE fused launch that advances every
@@ -178,9 +185,12 @@ int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate
  * memory (the LK role counts each corner in after a write-through store of its result; the PnP wave of the stream polls
  * the frame's counter, then acquires) -- one frame behind the LK role while frames keep coming, so neither role ever
  * stalls, and right behind it in the launches agt_tracker_join issues, so the last record of a clip is complete one LK
- * + one PnP latency after its pyramid.  A wait that is not satisfied within 20 ms gives up and flags the record
- * AGT_TRK_CHAIN_TIMEOUT (the LK workgroups have lower indices than the waiting ones and wait for nothing themselves, so
- * this needs a fault elsewhere).  A step costs max(stage) instead of their sum and the launch boundary is paid once
+ * + one PnP latency after its pyramid.  A wait that is not satisfied within 2^16 polls (>= 30 ms of the waiting wave
+ * executing; queue preemption does not count) gives up FAIL-STOP: the frame is not solved, its record is zeroed and flagged
+ * AGT_TRK_CHAIN_TIMEOUT, the stream's tracker state is frozen, every later record of that stream is flagged too and no
+ * later frame waits again, agt_synchronize / agt_tracker_join return AGT_ERR_CHAIN -- until agt_tracker_reset.  (The LK
+ * workgroups have lower indices than the waiting ones, are dispatched first and wait for nothing themselves, so a
+ * give-up needs a fault elsewhere; the design depends on in-index-order workgroup dispatch)  A step costs max(stage) instead of their sum and the launch boundary is paid once
  * per F frames; results are bit-identical to the serial order.  Frame t's state record is written up to (L+2)*F calls
  * later; agt_tracker_join enqueues the remaining stages of all supplied frames (no host synchronisation) and
  * agt_synchronize joins and waits.  Frames handed to agt_track_frame must stay valid and unmodified until their pose
@@ -205,6 +215,13 @@ int agt_tracker_state_read(agt_ctx* ctx, void* host_dst, int B);   /* synchronis
  * (device memory; read it back whenever convenient).  No host synchronisation. */
 int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                     double* d_state_out);
+/* One detector-fed frame for B streams (detect_pose.py:576-609 when the detector returned >= 2 tags): the frame becomes frame t
+ * of the stream -- its pyramid is built, so the next agt_track_frame tracks FROM it --, d_corners [B][n][2] f32 / d_mask [B][n]
+ * u8 (NULL = all) become its corner set and LK status (a corner the detector did not deliver is not trackable until the next
+ * detector-fed frame), and PoseDetector._estimate_pose runs on the table (exactly agt_estimate_pose).  Works after an
+ * agt_tracker_reset without corners.  Joins the pipeline first; pyramid pass + one PnP launch in stream order. */
+int agt_track_frame_detected(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
+                             const float* d_corners, const uint8_t* d_mask, double* d_state_out);
 /* A clip: `count` consecutive frames of the B streams in one call, frame k at d_frames + k * frame_stride (bytes), its
  * record at d_state_out + k * B * AGT_STATE_STRIDE (or NULL).  Exactly `count` calls of agt_track_frame, made without the
  * per-call host cost (at ~16 us of device time per 720p frame a Python caller's ~5 us per call is a third of the budget):

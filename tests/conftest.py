@@ -42,3 +42,10 @@ def seq1080():
     """BASELINE.json configs[3] geometry: one 1920x1080 stream (the 8-GPU config shards eight of them)."""
     from accurate_aprilgroup_tracking_amd import synthetic as syn
     return syn.Sequence(1920, 1080, n_tags=12, n_frames=5, seed=4, supersample=2)
+
+
+@pytest.fixture(scope="session")
+def seq720_long():
+    """BASELINE.json configs[1] geometry, 60 tracked frames: one 1280x720 stream, 12 tags / 48 corners"""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    return syn.Sequence(1280, 720, n_tags=12, n_frames=61, seed=1)

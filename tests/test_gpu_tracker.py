@@ -599,3 +599,89 @@ def test_chained_lk_role_big_motion_and_image_border(torch_cuda, oracle, seq640)
         assert not (outs[-1][:, :, H.ST_FLAGS].astype(int) & H.TRK_CHAIN_TIMEOUT).any()
     for o in outs[1:]:
         assert np.array_equal(outs[0], o)
+
+
+_GIVE_UP_CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AGT_REPO_ROOT"])
+from accurate_aprilgroup_tracking_amd import hiplib as H
+H.LIB_PATH = os.path.join(os.environ["AGT_REPO_ROOT"], "accurate_aprilgroup_tracking_amd", "libagt_hip_dbg.so")
+import torch
+from accurate_aprilgroup_tracking_amd import synthetic as syn
+from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+s = syn.Sequence(640, 480, n_tags=12, n_frames=6, seed=0)
+frames = torch.from_numpy(s.frames()).cuda()
+order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+c0 = torch.from_numpy(s.corners(0)[None]).cuda().contiguous()
+trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+trk.pipeline(4)
+out = {}
+def run(tag):
+    trk.reset(frames[0:1].contiguous(), c0)
+    so = trk.new_state_buffer(len(order))
+    codes = []
+    for i, k in enumerate(order):
+        trk.step(frames[k:k + 1], so[i])
+    try:
+        trk.join(); codes.append(0)
+    except H.AgtError as e:
+        codes.append(e.code)
+    codes.append(trk.ctx.L.agt_synchronize(trk.ctx.h))
+    st = trk.read_state()[0]
+    out[tag] = dict(rec=so.cpu().numpy()[:, 0].tolist(), codes=codes, chain_fault=st.chain_fault, frame=st.frame,
+                    prev=list(st.prev[:]), has_prev=st.has_prev)
+run("faulted")          # AGT_CHAIN_WITHHOLD=2: the second launch with chained waits never sees its second waited frame complete
+run("recovered")        # the knob has fired; agt_tracker_reset must bring the stream back
+print("RESULT " + json.dumps(out))
+'''
+
+
+def test_chain_give_up_is_fail_stop(torch_cuda, seq640):
+    """VERDICT r2 #8 / ADVICE r2 (medium): the give-up path of the chained launch, executed once.  The diagnostic library
+    (make dbg: AGT_DEBUG_KNOBS) withholds one arrival from the PnP role of one launch (AGT_CHAIN_WITHHOLD).  Expected:
+    the waiting wave gives up after its poll budget, does NOT solve on the stale ring entry, flags the record
+    AGT_TRK_CHAIN_TIMEOUT and zeroes it; the stream's tracker state stays that of the last good frame; every later record of
+    the stream is flagged too and nothing waits again (the launch drains, the run ends); agt_synchronize returns
+    AGT_ERR_CHAIN; agt_tracker_reset recovers and the records of a clean run come back bit for bit."""
+    import subprocess
+    import sys
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "accurate_aprilgroup_tracking_amd", "libagt_hip_dbg.so")
+    if not os.path.exists(dbg):
+        subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(root, "accurate_aprilgroup_tracking_amd", "csrc"), "dbg"])
+    env = dict(os.environ, AGT_CHAIN_WITHHOLD="2", AGT_REPO_ROOT=root)
+    res = subprocess.run([sys.executable, "-c", _GIVE_UP_CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    # the undisturbed run, on the product library in this process
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+    trk.pipeline(4)
+    trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+    so = trk.new_state_buffer(len(order))
+    for i, k in enumerate(order):
+        trk.step(frames[k:k + 1], so[i])
+    trk.join()
+    clean = so.cpu().numpy()[:, 0]
+    assert clean[:, H.ST_OK].all()
+    f = out["faulted"]
+    rec = np.array(f["rec"])
+    flags = rec[:, H.ST_FLAGS].astype(int)
+    bad = np.nonzero(flags & H.TRK_CHAIN_TIMEOUT)[0]
+    assert len(bad) and bad[0] >= 4, "the withheld arrival belongs to the second chained launch"
+    first = int(bad[0])
+    assert np.array_equal(bad, np.arange(first, len(order))), "every record after the give-up is flagged (sticky fault)"
+    assert np.array_equal(rec[:first], clean[:first]), "records before the give-up are those of the clean run, bit for bit"
+    assert (rec[first:, :8] == 0).all(), "nothing is solved on a stale ring entry: invalid records are zero"
+    assert f["chain_fault"] == 1 and f["frame"] == len(order)
+    assert f["has_prev"] == 1 and np.array_equal(np.array(f["prev"]), clean[first - 1, :6]), "tracker state frozen at the last good frame"
+    assert f["codes"][1] == -8, "agt_synchronize reports AGT_ERR_CHAIN"
+    r = out["recovered"]
+    assert r["codes"] == [0, 0] and r["chain_fault"] == 0
+    assert np.array_equal(np.array(r["rec"]), clean), "agt_tracker_reset recovers the stream"

@@ -62,6 +62,65 @@ def test_error_behaviour():
         Rodrigues(np.zeros((2, 2)))
 
 
+def test_host_rodrigues_numerics(oracle):
+    """host_math.Rodrigues (= cv_hip.Rodrigues; call sites detect_pose.py:275-276, 330, 344,
+    transform_helper.py:87) directly: vs scipy Rotation and vs the C oracle, forward and inverse, the theta -> 0 and
+    theta = pi branches, the 3x9 Jacobian by central differences, output depth = input depth."""
+    from scipy.spatial.transform import Rotation
+    rng = np.random.default_rng(12)
+    for i in range(200):
+        r = rng.normal(size=3)
+        r *= rng.uniform(0, 3.1) / np.linalg.norm(r)
+        R, J = Rodrigues(r.reshape(3, 1))
+        Ro, Jo = oracle.Rodrigues(r)
+        assert R.shape == (3, 3) and J.shape == (3, 9) and R.dtype == np.float64
+        assert np.abs(R - Rotation.from_rotvec(r).as_matrix()).max() < 1e-14
+        assert np.abs(R - Ro).max() < 1e-14 and np.abs(J - Jo).max() < 1e-12
+        num = np.stack([((Rodrigues(r + e)[0] - Rodrigues(r - e)[0]) / 2e-6).ravel() for e in np.eye(3) * 1e-6])
+        assert np.abs(J - num).max() < 1e-8
+        back, Jb = Rodrigues(R)
+        assert back.shape == (3, 1) and Jb.shape == (9, 3)
+        assert np.abs(back.ravel() - Rotation.from_matrix(R).as_rotvec()).max() < 1e-10
+        assert np.abs(back - oracle.Rodrigues(R)[0]).max() < 1e-12
+        # a matrix that is only nearly a rotation is orthonormalised first (SVD), as OpenCV
+        noisy = R + rng.normal(0, 1e-6, (3, 3))
+        assert np.abs(Rodrigues(noisy)[0] - oracle.Rodrigues(noisy)[0]).max() < 1e-10
+    # theta -> 0: identity and the generator Jacobian below DBL_EPSILON, smooth just above it
+    R0, J0 = Rodrigues(np.zeros(3))
+    assert np.array_equal(R0, np.eye(3)) and np.array_equal(J0, oracle.Rodrigues(np.zeros(3))[1])
+    assert J0[0, 5] == -1 and J0[0, 7] == 1 and J0[1, 2] == 1 and J0[1, 6] == -1 and J0[2, 1] == -1 and J0[2, 3] == 1
+    for eps in (1e-300, 1e-17, 3e-16, 1e-12, 1e-8, 1e-5):
+        r = np.array([0.6, -0.48, 0.64]) * eps
+        R, J = Rodrigues(r)
+        assert np.abs(R - oracle.Rodrigues(r)[0]).max() < 1e-15 and np.abs(J - oracle.Rodrigues(r)[1]).max() < 1e-9
+        skew = np.array([[0, -r[2], r[1]], [r[2], 0, -r[0]], [-r[1], r[0], 0]])
+        assert np.abs(R - (np.eye(3) + skew)).max() < max(eps * eps, 1e-16)
+        assert np.abs(Rodrigues(R)[0].ravel() - oracle.Rodrigues(R)[0].ravel()).max() < 1e-15
+    assert np.array_equal(Rodrigues(np.eye(3))[0], np.zeros((3, 1)))
+    # theta = pi (s < 1e-5, c < 0): per axis, negative axes, a general axis, and the sign fix-up on R12
+    axes = [np.eye(3)[0], np.eye(3)[1], np.eye(3)[2], -np.eye(3)[0], np.array([0.6, -0.48, 0.64]),
+            np.array([0.1, 0.7, -0.7]) / np.linalg.norm([0.1, 0.7, -0.7]), np.array([-0.05, 0.6, 0.8]) / np.linalg.norm([-0.05, 0.6, 0.8])]
+    for ax in axes:
+        for ang in (np.pi, np.pi - 3e-6, np.pi - 1e-9):
+            R = Rotation.from_rotvec(ax * ang).as_matrix()
+            r, _ = Rodrigues(R)
+            ro, _ = oracle.Rodrigues(R)
+            assert np.abs(r - ro).max() < 5e-8           # theta = acos(c) at c -> -1 turns one ulp of the trace (numpy SVD vs Jacobi SVD) into 1.5e-8
+            assert abs(np.linalg.norm(r) - ang) < 1e-5
+            assert np.abs(Rodrigues(r)[0] - R).max() < 2e-5        # the pi branch recovers the axis from the diagonal
+    # depth follows the input: the tag rvecs of the model are float32 (detect_pose.py:126-130 -> transform_helper.py:87)
+    for dt in (np.float32, np.float64):
+        r = np.array([[0.3], [-0.2], [0.5]], dt)
+        R, J = Rodrigues(r)
+        assert R.dtype == dt and J.dtype == dt
+        assert np.array_equal(R, oracle.Rodrigues(r)[0])
+        back, _ = Rodrigues(R)
+        assert back.dtype == dt and back.shape == (3, 1)
+        assert np.abs(back.astype(np.float64) - r.astype(np.float64)).max() < (1e-6 if dt == np.float32 else 1e-14)
+    # out-of-range matrix elements: OpenCV's checkRange failure leaves a zero vector
+    assert np.array_equal(Rodrigues(np.full((3, 3), 1e3))[0], np.zeros((3, 1)))
+
+
 def _make_detector(tmp_path, fx, cv):
     group = json.loads(str(fx["group_json"]))
     (tmp_path / "april_group.json").write_text(json.dumps(group))

@@ -147,9 +147,10 @@ def test_lk_recovers_integer_shift(oracle):
     assert good.sum() >= 38
     d = nx.reshape(-1, 2)[good] - pts[good]
     assert np.abs(d - np.array([-5.0, 3.0])).max() < 0.02
-    # exact-integer accumulation vs OpenCV's scalar float accumulation: same answer to ~1e-4 px
+    # exact-integer accumulation (deviation 1) vs OpenCV's scalar float accumulation, one call:
+    # measured 1.4e-4 px on this low-gradient texture (6e-5 px on the tag scenes)
     nx2, st2, _ = oracle.calcOpticalFlowPyrLK(a, b, pts, maxLevel=2, acc_mode=oracle.ACC_FLOAT_SCALAR)
-    assert np.array_equal(st, st2) and np.abs(nx - nx2).max() < 2e-3
+    assert np.array_equal(st, st2) and np.abs(nx - nx2).max() < 2.5e-4
 
 
 def test_lk_status_and_flags(oracle, seq640):
@@ -227,3 +228,83 @@ def test_find_homography_lm_refinement_vs_scipy(oracle):
     # four points: exact fit, no polish (cv::findHomography refines only when npoints > 4)
     M4 = np.array([[-1.0, -1], [-1, 1], [1, 1], [1, -1]]); P4 = np.c_[M4, np.ones(4)] @ Ht.T; m4 = P4[:, :2] / P4[:, 2:]
     assert np.abs(oracle.findHomography(M4, m4, True) - oracle.findHomography(M4, m4, False)).max() == 0.0
+
+
+# --------------------------------------------------------------------------- LK per-point loop, pinned independently
+def _lk_scenes(seq640):
+    """(name, prev, next, points, kwargs): tag corners, a band-limited texture with border / outside points, and sub-pixel
+    positions that make the fourth bilinear weight 0 or negative"""
+    rng = np.random.default_rng(21)
+    a, b = seq640.frame(0), seq640.frame(2)
+    h, w = a.shape
+    yield "tags", a, b, seq640.corners(0), dict(maxLevel=2)
+    base = gaussian_filter(rng.standard_normal((140, 190)), 1.7)
+    base = (base - base.min()) / (base.max() - base.min()) * 255
+    ta = base.astype(np.uint8)
+    tb = np.clip(shift(base, (1.6, -2.3), order=3, mode="reflect"), 0, 255).astype(np.uint8)
+    th, tw = ta.shape
+    border = np.array([[0.0, 0.0], [tw - 1.0, th - 1.0], [-5.5, 10.25], [tw + 3.0, 7.0], [3.2, th + 8.9], [-40.0, -40.0],
+                       [tw + 30.0, th + 30.0], [10.5, 10.5], [tw - 11.0, th - 11.0], [1.0, th / 2.0], [-20.9, 50.0],
+                       [tw + 19.5, 60.0]], np.float32)
+    pts = np.concatenate([border, rng.uniform([-12, -12], [tw + 12, th + 12], size=(28, 2)).astype(np.float32)])
+    yield "texture_border", ta, tb, pts, dict(maxLevel=3)
+    yield "texture_level0_count5", ta, tb, pts, dict(maxLevel=0, criteria=(1, 5, 0.0))
+    yield "texture_mineig", ta, tb, pts, dict(maxLevel=2, flags=8, minEigThreshold=1e-2)
+    tiny = np.float32(2.0 ** -11)             # a * b * 2^14 < 1.5: iw11 rounds to 0 or -1
+    sub = np.concatenate([seq640.corners(0)[:12].round() + np.array([[tiny * (1 + i % 5), tiny * (1 + i % 3)] for i in range(12)], np.float32),
+                          np.floor(seq640.corners(0)[12:18]) + np.float32(0.5),
+                          seq640.corners(0)[18:24].round()]).astype(np.float32)
+    yield "iw11_nonpositive", a, b, sub, dict(maxLevel=2)
+    init = sub + rng.normal(0, 1.2, sub.shape).astype(np.float32)
+    yield "initial_flow", a, b, sub, dict(maxLevel=1, flags=4, nextPts=init)
+
+
+def test_lk_oracle_equals_numpy_statement(oracle, seq640):
+    """The C oracle's per-point LK loop against a second, structurally different statement of SURVEY.md Appendix A
+    (tests/lk_numpy.py: scipy-filtered whole images, 21x21 array windows, int64) -- nextPts (u32 view), status and err
+    BIT-EXACT, in the exact-sum mode the HIP kernels are held to and in OpenCV's scalar float accumulation order."""
+    from tests import lk_numpy
+    seen_neg = False
+    for name, a, b, pts, kw in _lk_scenes(seq640):
+        for mode, forder in ((oracle.ACC_EXACT, False), (oracle.ACC_FLOAT_SCALAR, True)):
+            if forder and name not in ("tags", "texture_border"):
+                continue
+            o = oracle.calcOpticalFlowPyrLK(a, b, pts, acc_mode=mode, **kw)
+            m = lk_numpy.calc_optical_flow_pyr_lk(a, b, pts, next_pts=kw.get("nextPts"), max_level=kw["maxLevel"],
+                                                  criteria=kw.get("criteria", (3, 30, 0.01)), flags=kw.get("flags", 0),
+                                                  min_eig_threshold=kw.get("minEigThreshold", 1e-4), float_order=forder)
+            assert np.array_equal(o[1], m[1]), "%s: status" % name
+            assert np.array_equal(o[0].view(np.uint32), m[0].view(np.uint32)), \
+                "%s: nextPts differ by %g" % (name, np.abs(o[0] - m[0]).max())
+            assert np.array_equal(o[2].view(np.uint32), m[2].view(np.uint32)), "%s: err" % name
+        if name == "iw11_nonpositive":
+            for p in pts:
+                q = p - np.float32(10.0)
+                w = lk_numpy._weights(np.float32(q[0] - np.floor(q[0])), np.float32(q[1] - np.floor(q[1])))
+                seen_neg |= w[3] <= 0
+            assert o[1].sum() >= 20
+    assert seen_neg, "the edge-case set no longer reaches iw11 <= 0"
+
+
+def test_exact_vs_float_accumulation_bounded_at_pose_level(oracle, seq720_long):
+    """DESIGN.md section 2 deviation 1 carried to the quantity north_star bounds (pose, <= 1e-4): the chained c2 stream
+    (1280x720, 60 frames, raw LK chaining, no corner refresh) tracked twice by the oracle, with exact integer window sums
+    (what the HIP kernels compute) and with OpenCV's scalar float accumulation.  Measured: corners 6e-5 px after one
+    frame, pose gap 2e-6 after 60 frames; asserted: <= 1e-5 at every frame (tests/test_gpu_tracker.py repeats this with
+    the HIP tracker on the exact side)."""
+    s = seq720_long
+    runs = {}
+    for mode in (oracle.ACC_EXACT, oracle.ACC_FLOAT_SCALAR):
+        pyr, pts = oracle.Pyramid(s.frame(0)), s.corners(0)
+        r, t = s.rvecs[0].copy(), s.tvecs[0].copy()
+        poses, first, counts = [], None, []
+        for k in range(1, len(s)):
+            pyr, pts, st, er, cnt, r, t = oracle.track_frame(pyr, s.frame(k), pts, s.obj, s.K, None, r, t, acc_mode=mode)
+            counts.append(cnt)
+            poses.append(np.concatenate([r, t]))
+            first = pts.copy() if first is None else first
+        runs[mode] = (np.array(poses), first, counts)
+    assert runs[oracle.ACC_EXACT][2] == runs[oracle.ACC_FLOAT_SCALAR][2] and min(runs[oracle.ACC_EXACT][2]) >= 46
+    gap = np.abs(runs[oracle.ACC_EXACT][0] - runs[oracle.ACC_FLOAT_SCALAR][0]).max(axis=1)
+    assert gap.max() <= 1e-5, gap.max()
+    assert np.abs(runs[oracle.ACC_EXACT][1] - runs[oracle.ACC_FLOAT_SCALAR][1]).max() < 2.5e-4
