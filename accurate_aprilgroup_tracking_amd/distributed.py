@@ -65,3 +65,11 @@ def max_over_ranks(value, device):
     t = torch.tensor([value], dtype=torch.float64, device="cpu" if dist.get_backend() == "gloo" else device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def backend_name():
+    """"nccl" is RCCL on ROCm; "none" when the job is a single process"""
+    if not dist.is_initialized():
+        return "none"
+    b = dist.get_backend()
+    return "rccl (torch.distributed nccl)" if b == "nccl" else str(b)

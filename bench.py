@@ -7,14 +7,15 @@ iterative PnP with the motion-model extrinsic guess.  A step = one frame of ever
 pyramid(new frame) -> LK(prev corners) -> solvePnP(guess) -> gate -> motion model, all on
 the device (agt_track_frame), frames already resident in HBM.
 
-    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c4|c5]
+    python bench.py [--gpus N --steps K --warmup W] [--workload c2|c3|c3pairs|c4|c5]
 
     --gpus N > 1 invoked plainly: this process starts N fresh ranks (python -m torch.distributed.run, rendezvous on
     127.0.0.1) BEFORE anything touches a GPU, relays rank 0's JSON line and exits with the job's code.  Launched by
     torch.distributed.run itself (WORLD_SIZE set) it is one of the ranks.
 
-Workloads: c2 = 1 x 1280x720 stream (configs[1], the metric's configuration); c3 = 64 x 1280x720 per step (configs[2], the
-HBM-bound one); c4 = 1 x 1920x1080 stream per GPU (configs[3]); c5 = 1280x720, 60 tags / 240 corners + dense photometric
+Workloads: c2 = 1 x 1280x720 stream (configs[1], the metric's configuration); c3 = 64 x 1280x720 STREAMS per step (configs[2]
+read as streams: previous pyramid cached, 1,441,008 B per stream-frame); c3pairs = configs[2] exactly as SURVEY.md 8d states it:
+64 COLD frame pairs per step, both pyramids built, 2,650,608 B per pair = 169,638,912 B per batch (bench_pairs.py); c4 = 1 x 1920x1080 stream per GPU (configs[3]); c5 = 1280x720, 60 tags / 240 corners + dense photometric
 refinement per frame (configs[4]).
 
 Timing: W untimed warm-up steps, then R blocks (default 15) of EXACTLY K steps each, every block bracketed by barrier +
@@ -47,6 +48,8 @@ WORKLOADS = {
                label="c2: %d x 1280x720 stream(s) per GPU, 12 tags/48 corners, 3-level LK 21x21, iterative PnP with motion-model guess"),
     "c3": dict(W=1280, H=720, ntags=12, B=64, dense=False,
                label="c3: %d x 1280x720 independent streams per step, 48 corners each (LK HBM-bandwidth run)"),
+    "c3pairs": dict(W=1280, H=720, ntags=12, B=64, dense=False, pairs=True,
+                    label="c3pairs: %d independent cold 1280x720 frame pairs per step (both pyramids built, LK, PnP with guess), 48 corners each"),
     "c4": dict(W=1920, H=1080, ntags=12, B=1, dense=False,
                label="c4: %d x 1920x1080 stream(s) per GPU (one per GPU across the node), 48 corners, 3-level LK 21x21, iterative PnP"),
     "c5": dict(W=1280, H=720, ntags=60, B=1, dense=True,
@@ -234,6 +237,7 @@ class Bench:
         D.gather_poses(state_w)                       # warm the communicator outside the timed region
         first = None
         dts = []
+        self.chain_timeouts = 0
         for r in range(R):
             if r > 0 and self.since + K > REDETECT:
                 self.refresh()                        # detector work: between blocks, outside the timers
@@ -245,8 +249,11 @@ class Bench:
             gathered = D.gather_poses(state)
             self.sync(); D.barrier()
             dts.append(D.max_over_ranks(time.perf_counter() - t0, self.dev))
+            blk = state.cpu().numpy()
+            if blk.shape[2] > 11:
+                self.chain_timeouts += int(((blk[:, :, 11].astype(np.int64) & 512) != 0).sum())       # AGT_ST_FLAGS & AGT_TRK_CHAIN_TIMEOUT, EVERY block
             if first is None:
-                first = state.cpu().numpy().copy()
+                first = blk.copy()
         st_last = state.cpu().numpy()
         return dts, state_w.cpu().numpy(), first, st_last, gathered
 
@@ -284,6 +291,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--split", type=int, default=-1, help="diagnostic builds only (AGT_STEP_MAX_CORNERS): label of a forced fused / split run")
     ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
     ap.add_argument("--blocks", type=int, default=15, help="timed blocks of --steps steps each (median / p10 / p90 over them)")
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (default: the workload's)")
@@ -319,6 +327,9 @@ def main():
     if wl["dense"]:
         from bench_c5 import main_c5                     # configs[4]: its step has a fourth stage (bench_c5.py)
         return main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal)
+    if wl.get("pairs"):
+        from bench_pairs import main_pairs               # configs[2] as cold pairs (bench_pairs.py)
+        return main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal)
     bench = Bench(torch, wl, args, rank, world, dev)
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
     fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
@@ -371,6 +382,7 @@ def main():
             extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
             extras["per_call_latency_us"] = per_call_latency(bench)
             extras["live_frame_latency_us"] = live_latency(bench)
+            extras["drop_in_frame_latency_us"] = drop_in_latency(bench)
 
         cpu = pose_err = None
         if not args.no_cpu_baseline and world == 1:
@@ -390,9 +402,25 @@ def main():
                           "value_p10": round(world * B * K / p90, 2), "value_p90": round(world * B * K / p10, 2)},
                "roofline": roof, "cpu_baseline": cpu,
                "pose_err_vs_cpu": pose_err, "accepted_frac": round(accepted, 4), "mean_lm_iters": round(iters, 2),
-               "chain_timeouts": int(((st_last[:, :, HL.ST_FLAGS].astype(np.int64) & HL.TRK_CHAIN_TIMEOUT) != 0).sum()),
+               "chain_timeouts": int(bench.chain_timeouts),
                "render_s": round(bench.render_s, 1), "gathered_shape": list(gathered.shape)}
         out.update(extras)
+        # `value` is a clip rate (frames handed over in clips, `depth` per launch); the figures comparable to the
+        # reference's live frame-by-frame loop sit beside it at the top level
+        out["pose_latency_frames_max"] = 2 * depth if fused else 4 * depth      # pyramid launch -> chained LK | PnP launch (split: pyramid, LK, PnP a group apart + slack)
+        if fused:
+            out["one_frame_per_launch_fps"] = roof["one_frame_per_launch"]["frames_per_s"]
+        if "live_frame_latency_us" in extras:
+            out["live_frame_us_median"] = extras["live_frame_latency_us"]["median"]
+        if "drop_in_frame_latency_us" in extras:
+            out["drop_in_frame_us_median"] = extras["drop_in_frame_latency_us"]["gray_pinned"]["median"]
+        if cpu:
+            out["vs_cpu_baseline"] = {"x_1_core": round(fps / cpu["value"], 1),
+                                      "x_%d_threads" % cpu["all_cores"]["cores"] if cpu.get("all_cores") else "x_all": round(fps / cpu["all_cores"]["value"], 1) if cpu.get("all_cores") else None,
+                                      "note": "CPU port on %s of this host's %d cores; a reported ratio, not the target (the roofline fraction is)"
+                                              % (("1 and %d" % cpu["all_cores"]["cores"]) if cpu.get("all_cores") else "1", os.cpu_count())}
+        out["rccl_ranks"] = world
+        out["dist_backend"] = D.backend_name()
         if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)
@@ -558,6 +586,55 @@ def live_latency(bench, n=300):
     ok = float(out.cpu().numpy()[:, 6].mean())
     return {"median": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1), "frames": n, "last_accepted": ok,
             "note": "step + join + synchronize per frame at one frame per launch (2 launches per frame)"}
+
+
+def drop_in_latency(bench, n=200):
+    """the class a reference user instantiates (detect_pose.py:57) on the device-resident path --
+    PoseDetector(backend="stream")._detect_and_get_pose(frame), one HOST frame per call: pinned upload -> (BGR: gray kernel)
+    -> agt_track_frame -> 128-byte record download.  Median / p90 of the host-observed call time over n tracked frames;
+    gray (0.9 MB) and BGR (2.8 MB) frames, from the detector's pinned frame buffer and from an ordinary numpy array (one
+    more host copy).  The first frame is seeded by a detector answer (ground truth), then the detector is removed (LK path)."""
+    import json as js, logging, tempfile
+    from accurate_aprilgroup_tracking_amd import formats
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    sq = bench.seqs[0]
+    tmp = tempfile.mkdtemp()
+    open(os.path.join(tmp, "april_group.json"), "w").write(js.dumps(sq.group))
+
+    class Det(PoseDetector):
+        DIRPATH = tmp
+    log = logging.getLogger("bench"); log.setLevel(logging.CRITICAL)
+    tag_ids = [int(t) for t in sq.group["tags"].keys()]
+    frames = bench.rendered[:, 0]
+    out = {}
+    for name, color, pinned in (("gray_pinned", False, True), ("gray_pageable", False, False), ("bgr_pinned", True, True), ("bgr_pageable", True, False)):
+        first = [formats.make_detection(t, c) for t, c in zip(tag_ids, sq.corners(0).reshape(-1, 4, 2))]
+        det = Det(log, sq.K, None, True, detector=lambda gray: first, backend="stream")
+        shape = frames[0].shape + ((3,) if color else ())
+        buf = det.frame_buffer(shape) if pinned else np.empty(shape, np.uint8)
+        srcs = [np.ascontiguousarray(np.stack([f, f, f], -1)) if color else f for f in frames]
+        ts = []
+        for k in range(n + 10):
+            i = pingpong(k, bench.NF)
+            if pinned:
+                np.copyto(buf, srcs[i]); frame = buf          # (the capture's write into the buffer: not part of the call)
+            else:
+                frame = srcs[i]
+            t0 = time.perf_counter()
+            det._detect_and_get_pose(frame)
+            dt = time.perf_counter() - t0
+            if k == 0:
+                det.detector = None
+            if k >= 10:
+                ts.append(dt)
+        ts = np.array(ts) * 1e6
+        ok = det.last_error is not None and det.last_error < 2
+        out[name] = {"median": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1), "last_accepted": bool(ok)}
+        del det
+    out["note"] = ("PoseDetector(backend='stream')._detect_and_get_pose(host frame) at %dx%d, LK path: upload + [gray kernel] + pyramid launch + "
+                   "chained LK|PnP launch + 128 B download, one frame per call; *_pageable adds the host copy into the pinned staging buffer"
+                   % (bench.W, bench.H))
+    return out
 
 
 def per_call_latency(bench):

@@ -82,7 +82,7 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "roofline": roof, "cpu_baseline": cpu, "accepted_frac": round(accepted, 4),
                "refined_frac": round(float(dn[:, :, HL.DN_REFINED].mean()), 4), "tracked_corners_mean": round(float(st_last[:, :, HL.ST_NTRACK].mean()), 1),
                "max_abs_pose_err_vs_truth": {"pnp": float(np.max(err_pnp)), "dense_refined": float(np.max(err_ref))},
-               "render_s": round(bench.render_s, 1), "gathered_shape": list(gathered.shape)}
+               "render_s": round(bench.render_s, 1), "gathered_shape": list(gathered.shape), "rccl_ranks": world, "dist_backend": D.backend_name()}
         if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)

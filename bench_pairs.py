@@ -1,0 +1,172 @@
+"""bench_pairs.py -- BASELINE.json configs[2] exactly as SURVEY.md section 8d states it, for bench.py --workload c3pairs:
+a batch of 64 INDEPENDENT COLD 1280x720 frame pairs per step, 48 corners each.
+
+A step = for 64 pairs at once: build BOTH pyramids (agt_pyramid_build x 2: the previous and the next frame of every pair,
+nothing cached from an earlier step), cv::calcOpticalFlowPyrLK on them (agt_lk_track), cv::solvePnP with the extrinsic guess
+(agt_solve_pnp) -- the stateless C-ABI entry points, stage kernels in stream order.  Algorithmic bytes:
+B_pair = 2 * W * H * 1.3125 + N * L * (24^2 + 32^2) + N * 21 = 2,650,608 B at 1280x720, L = 3, N = 48; 169,638,912 B per batch.
+Four distinct batches (4 x 118 MB of frames > the 256 MiB Infinity Cache) rotate, so every step reads HBM-cold frames.
+"""
+import ctypes as C
+import json
+import os
+import time
+
+import numpy as np
+
+NBATCH = 4
+
+
+def pair_bytes(W, H, npts, levels=3):
+    return int(2 * W * H * 1.3125 + npts * levels * (24 * 24 + 32 * 32) + npts * 21)
+
+
+def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
+    import bench as B_
+    from accurate_aprilgroup_tracking_amd import cv_hip, synthetic as syn
+    W, H, B = wl["W"], wl["H"], args.streams or wl["B"]
+    K, Wm = args.steps, args.warmup
+    t_r = time.time()
+    nseq = 4
+    NF = max(args.render_frames // 3, NBATCH + 1)
+    seqs = [syn.Sequence(W, H, n_tags=wl["ntags"], n_frames=NF, seed=1000 * rank + s, supersample=3, group_seed=0) for s in range(nseq)]
+    npts = seqs[0].obj.shape[0]
+    # batch j, pair b: frames (k, k + 1) of sequence b % nseq with k = (j + b // nseq) % (NF - 1); every pair at its own address
+    prev = torch.empty((NBATCH, B, H, W), dtype=torch.uint8, device=dev)
+    nxt = torch.empty((NBATCH, B, H, W), dtype=torch.uint8, device=dev)
+    pts = np.empty((NBATCH, B, npts, 2), np.float32)
+    guess = np.empty((NBATCH, B, 6), np.float64)
+    truth = np.empty((NBATCH, B, 6), np.float64)
+    rend = [torch.from_numpy(sq.frames()).to(dev) for sq in seqs]
+    for j in range(NBATCH):
+        for b in range(B):
+            sq, k = seqs[b % nseq], (j + b // nseq) % (NF - 1)
+            prev[j, b] = rend[b % nseq][k]; nxt[j, b] = rend[b % nseq][k + 1]
+            pts[j, b] = sq.corners(k)
+            guess[j, b] = np.concatenate([sq.rvecs[k], sq.tvecs[k]])
+            truth[j, b] = np.concatenate([sq.rvecs[k + 1], sq.tvecs[k + 1]])
+    del rend
+    render_s = time.time() - t_r
+    pts_d = torch.from_numpy(pts).to(dev); guess_d = torch.from_numpy(guess).to(dev)
+    obj_d = torch.from_numpy(seqs[0].obj.astype(np.float32)).to(dev)
+    ctx = cv_hip.Context(W, H, max_level=B_.LEVELS - 1, win=B_.WIN, max_points=npts, max_streams=B)
+    L, h = ctx.L, ctx.h
+    nx = torch.zeros((B, npts, 2), dtype=torch.float32, device=dev)
+    st = torch.zeros((B, npts), dtype=torch.uint8, device=dev)
+    pose = torch.zeros((K, B, 6), dtype=torch.float64, device=dev)           # one record per step (the gathered poses)
+    info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    Kh = np.ascontiguousarray(seqs[0].K.reshape(-1)); Kp = Kh.ctypes.data_as(C.c_void_p)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    pitch, bstride = W, W * H
+
+    def step(j, pose_k, events=None):
+        rec = (lambda i: events[i].record()) if events else (lambda i: None)
+        rec(0)
+        HL.check(L.agt_pyramid_build(h, 0, vp(prev[j]), pitch, bstride, B), "agt_pyramid_build")
+        rec(1)
+        HL.check(L.agt_pyramid_build(h, 1, vp(nxt[j]), pitch, bstride, B), "agt_pyramid_build")
+        rec(2)
+        HL.check(L.agt_lk_track(h, 0, 1, vp(pts_d[j]), vp(nx), vp(st), None, npts, B, 3, 30, 0.01, 0, 1e-4), "agt_lk_track")
+        rec(3)
+        pose_k.copy_(guess_d[j])                                              # the extrinsic guess of every pair (3 KB)
+        HL.check(L.agt_solve_pnp(h, vp(obj_d), 0, vp(nx), HL.F32, vp(st), npts, B, Kp, None, 0, vp(pose_k), 1, vp(info), None), "agt_solve_pnp")
+        rec(4)
+
+    ctx.use_current_stream()
+    for k in range(Wm):
+        step(k % NBATCH, pose[k % K])
+    torch.cuda.synchronize()
+    D.gather_poses(pose)
+    dts = []
+    for r in range(max(1, args.blocks)):
+        torch.cuda.synchronize(); D.barrier()
+        t0 = time.perf_counter()
+        for k in range(K):
+            step((r * K + k) % NBATCH, pose[k])
+        gathered = D.gather_poses(pose)
+        torch.cuda.synchronize(); D.barrier()
+        dts.append(D.max_over_ranks(time.perf_counter() - t0, dev))
+    med, p10, p90 = B_.percentiles(dts)
+    pairs_s = world * B * K / med
+    # correctness of what was timed: poses of the last block against the generator's truth, LK status
+    ph = pose.cpu().numpy()
+    err = max(np.abs(ph[k] - truth[((len(dts) - 1) * K + k) % NBATCH]).max() for k in range(K))
+    tracked = float(st.cpu().numpy().mean())
+    if rank == 0:
+        # instrumented pass: HIP events on the launch stream around every call (the context launches on torch's current stream)
+        M = min(K, 100)
+        ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(M)]
+        for k in range(M):
+            step(k % NBATCH, pose[k], ev[k])
+        torch.cuda.synchronize()
+        sp = np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(4)] for e in ev]).mean(axis=0)      # us
+        ab = B_.algorithmic_bytes(W, H, npts)
+        spans = {"pyramid_prev(2 launches)": float(sp[0]), "pyramid_next(2 launches)": float(sp[1]), "lk": float(sp[2]), "pnp(+guess copy)": float(sp[3])}
+        per = {"pyramid": (2 * B * ab["pyramid"], float(sp[0] + sp[1])), "lk": (B * ab["lk"], float(sp[2])), "pnp": (B * ab["pnp"], float(sp[3]))}
+        dom = max(per, key=lambda n: per[n][1])
+        nlaunch = {"pyramid": 4, "lk": 1, "pnp": 1}[dom]
+        kernel_us = per[dom][1] / nlaunch
+        achieved = per[dom][0] / nlaunch / (kernel_us * 1e-6) / 1e9
+        batch_bytes = B * pair_bytes(W, H, npts)
+        whole = batch_bytes / (med / K) / 1e9
+        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down kernels (L0->L1, L1->L2 of both frames: 4 launches per step)", "lk": "lk_kernel<21,1,3> (one wave per corner)",
+                                           "pnp": "pnp_kernel<float,1>"}[dom],
+                "achieved": round(achieved, 3), "peak": B_.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / B_.HBM_PEAK_GBS, 6),
+                "traffic": B_.pmc_traffic({"pyramid": "pyr_down_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us),
+                "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(per[dom][0] / nlaunch),
+                "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / B_.HBM_PEAK_GBS, 4), "bytes_per_step": int(batch_bytes),
+                               "frac_of_measured_copy_6290GBs": round(whole / 6290.0, 4)},
+                "call_spans_us": {k_: round(v, 2) for k_, v in spans.items()}}
+        cpu = None
+        if not args.no_cpu_baseline and world == 1:
+            cpu = cpu_baseline_pairs(seqs, NF)
+        out = {"metric": "frame pairs/sec (both pyramids + LK + PnP) on cold 1280x720 pairs", "value": round(pairs_s, 2), "unit": "pairs/s",
+               "n_gpus": world, "steps": K, "warmup": Wm, "ms_per_step": round(med / K * 1e3, 5), "higher_is_better": True, "scaling": "weak",
+               "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP)", "data": "synthetic",
+               "config": {"workload": wl["label"] % B, "pairs_per_step": B, "frames_resident": "%d batches x %d pairs x 2 frames in HBM (%.0f MiB), rotated"
+                          % (NBATCH, B, NBATCH * B * 2 * W * H / 2**20),
+                          "launch": "stateless C-ABI calls in stream order: agt_pyramid_build x 2 (two single-level passes each), agt_lk_track, agt_solve_pnp (guess)"},
+               "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
+                          "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
+               "roofline": roof, "cpu_baseline": cpu, "max_abs_pose_err_vs_truth": float(err), "tracked_frac": round(tracked, 4),
+               "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape), "rccl_ranks": world, "dist_backend": D.backend_name()}
+        if rehearsal:
+            out["rehearsal"] = True
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+def cpu_baseline_pairs(seqs, NF):
+    """the same pairs on ONE host core with the oracle ("port"), ~10 s: calcOpticalFlowPyrLK (both pyramids, Scharr image
+    per level, per-point LK: OpenCV's dataflow) + solvePnP with the guess; then with 16 threads (bands / points)"""
+    import bench as B_
+    cvo, flags = B_.native_oracle()
+    obj32 = seqs[0].obj.astype(np.float32)
+
+    def run(seconds, nthreads):
+        cvo.lib().cvo_set_num_threads(nthreads)
+        n = 0; t0 = time.perf_counter()
+        try:
+            while True:
+                sq = seqs[n % len(seqs)]; k = (n // len(seqs)) % (NF - 1)
+                nx, st, _ = cvo.calcOpticalFlowPyrLK(sq.frame(k), sq.frame(k + 1), sq.corners(k), maxLevel=2, nthreads=nthreads)
+                m = st.ravel() == 1
+                cvo.solvePnP(obj32[m], nx.reshape(-1, 2)[m], sq.K, None, sq.rvecs[k].copy(), sq.tvecs[k].copy(), True)
+                n += 1
+                if time.perf_counter() - t0 > seconds:
+                    break
+        finally:
+            cvo.lib().cvo_set_num_threads(1)
+        return n, time.perf_counter() - t0
+    n1, dt1 = run(10.0, 1)
+    try:
+        nthr = len(os.sched_getaffinity(0))
+    except AttributeError:
+        nthr = os.cpu_count() or 1
+    nthr = max(1, min(nthr, 16))
+    n2, dt2 = run(5.0, nthr) if nthr > 1 else (0, 1.0)
+    return {"value": round(n1 / dt1, 2), "unit": "pairs/s", "cores": 1, "kind": "port",
+            "sample": "%d cold pairs of the same sequences: oracle calcOpticalFlowPyrLK (two pyramids + Scharr + LK) + solvePnP(guess), 1 thread, %.1f s; host has %d cores"
+                      % (n1, dt1, os.cpu_count()),
+            "cpu_model": B_.cpu_model(), "build": flags,
+            "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr, "sample": "%d pairs, %.1f s" % (n2, dt2)} if n2 else None}
