@@ -751,9 +751,20 @@ static int launch_group(agt_ctx* c, int B)
             if (e == hipSuccess && c->y_ev_hist[1] >= 0) e = hipStreamWaitEvent(sh, evY[c->y_ev_hist[1]], 0);
         }
         if (e != hipSuccess) return hip_fail(c, e);
-        // one stand-alone LK launch per frame of the group (and half), back to back on its stream (as a role with an in-kernel
+        // Up to 1024 corners in flight (the four-waves-per-corner body): the LK role of the WHOLE group as one launch --
+        // lk_group_kernel, the frame-chained body of the fused step with its own register budget (153 VGPRs, three workgroups
+        // per CU) -- instead of one ~17 us launch + ~5 us gap per frame (round 3: 16 streams 33.9 -> see profiles/r03_stream_sweep.txt).
+        bool lk_group = agt_lk_wide(c->trk_n, B);
+#ifdef AGT_DEBUG_KNOBS
+        { static const int on = [] { const char* e = getenv("AGT_SPLIT_LK_GROUP"); return e ? atoi(e) : 1; }(); if (!on) lk_group = false; }
+#endif
+        if (lk_group) {
+            e = agt_launch_step(sL, S, T, c->cfg.win, AGT_STEP_LK);
+            if (e != hipSuccess) return hip_fail(c, e);
+        }
+        // otherwise one stand-alone LK launch per frame of the group (and half), back to back on its stream (as a role with an in-kernel
         // frame loop the one-wave-per-corner kernel needs 240 B of scratch per lane at its 128-register budget and runs at half speed)
-        for (int k = 1; k <= S.lk_nf; k++) {
+        for (int k = 1; k <= S.lk_nf && !lk_group; k++) {
             const int ps = (int)((lk_f0 + k - 1) % M), sl = (int)((lk_f0 + k) % M);
             rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B1,
                              AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
@@ -1002,6 +1013,38 @@ int agt_track_frame_detected(agt_ctx* c, const uint8_t* d_frames, size_t pitch, 
     for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = t;
     c->trk_ready = 2;
     return AGT_OK;
+}
+
+// The live camera loop in ONE call (detect_pose.py:669-681, LK path): host frame -> HBM -> [undistort / gray / crop] -> agt_track_frame
+// -> join -> record back -> wait.  Everything a Python caller would otherwise issue as five separate foreign calls.
+int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int src_w, int src_h, uint8_t* d_staging,
+                         int undistort, int roi_x, int roi_y, uint8_t* d_gray, size_t gpitch, double* d_state, double* h_state)
+{
+    if (!c || !h_frame || !d_gray || !d_state || !h_state || (channels != 1 && channels != 3)) return AGT_ERR_ARG;
+    if (c->trk_ready != 2 || c->trk_B != 1) return AGT_ERR_STATE;
+    const int W = c->cfg.width, H = c->cfg.height;
+    hipError_t e;
+    if (channels == 1) {
+        if (src_w != W || src_h != H || roi_x || roi_y || undistort) return AGT_ERR_ARG;
+        if (gpitch == (size_t)W) e = hipMemcpyAsync(d_gray, h_frame, (size_t)W * H, hipMemcpyHostToDevice, c->stream);
+        else e = hipMemcpy2DAsync(d_gray, gpitch, h_frame, (size_t)W, (size_t)W, (size_t)H, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+    } else {
+        if (!d_staging) return AGT_ERR_ARG;
+        e = hipMemcpyAsync(d_staging, h_frame, (size_t)src_w * src_h * 3, hipMemcpyHostToDevice, c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        int rc = agt_preprocess_bgr(c, d_staging, (size_t)src_w * 3, (size_t)src_w * src_h * 3, src_w, src_h, 1, undistort, roi_x, roi_y, W, H,
+                                    d_gray, gpitch, gpitch * (size_t)H);
+        if (rc) return rc;
+    }
+    int rc = agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_state);
+    if (rc) return rc;
+    rc = join_pipeline(c);
+    if (rc) return rc;
+    e = hipMemcpyAsync(h_state, d_state, AGT_STATE_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    if (e != hipSuccess) return hip_fail(c, e);
+    return *(volatile int*)c->fault_host ? AGT_ERR_CHAIN : AGT_OK;
 }
 
 int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }

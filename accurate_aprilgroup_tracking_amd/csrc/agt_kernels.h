@@ -170,7 +170,7 @@ int agt_dense_blocks(int M);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
-bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used up to 2048 corners in flight
+bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used up to 256 corners in flight
 // role subsets of one pipeline group (split mode launches them separately, each with its own LDS size and register budget)
 #define AGT_STEP_PYR 1
 #define AGT_STEP_LK  2

@@ -218,6 +218,8 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
                 reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
     }
     // (NWV == 2: the caller has copied the tables and zeroed sh.seq with the whole workgroup, behind a barrier)
+    // (measured and dropped, round 3: s_setprio(3) for this wave -- in split mode it shares its SIMD with up to three VALU-bound
+    // LK waves; the step time did not move at any stream count, the LK group launch is the longer chain there)
     int late = 0;
     for (int k = wave; k < S.pnp_nf; k += NWV) {
         const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
@@ -381,32 +383,29 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         return hipGetLastError();
     }
     if (!(roles & (AGT_STEP_LK | AGT_STEP_PNP))) return hipErrorInvalidValue;       // (LK | PnP without the pyramid role: diagnostics)
-    // OCC = 1: the FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU,
-    // best while <= 256 corners are in flight.  OCC = 2: registers capped at 256 (336 B of scratch for the PnP
-    // role), two workgroups per CU: +0.4 us on one stream, but 8 / 32 streams run at 23 / 49 us per step.
-    if ((long)P.lk.n * P.lk_B <= 256 || P.n_lk == 0) {
-        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-    } else {
-        if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 2>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-        else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 2>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-    }
+    // The FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU, which is why the fused
+    // launch is only used while <= 256 corners are in flight (agt_step_fits).  Round 2 also shipped an OCC = 2 build for 257-2048
+    // corners (registers capped at 256: ~500 VGPR spills, 1 KB of scratch in the PnP role); round 3's split mode with the LK role
+    // as one group launch beats it at every stream count (profiles/r03_stream_sweep.txt), so it is gone.
+    if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     return hipGetLastError();
 }
 
 }  // namespace
 
 bool agt_step_supported(int win) { return win == 21; }
-// Fused launch (all roles in one kernel) up to 2048 corners in flight, measured on 48-corner streams: 1 / 4 / 8 / 16 /
-// 32 streams take 20 / 22 / 23 / 42 / 49 us per step against 41 / 42 / 46 / 53 / 67 as separate kernels; at 64 streams
-// (94 vs 85) the one-wave-per-corner LK role wants more than the two waves per SIMD the fused launch can hold.
-// (larger batches: the same pipeline as one launch per role, see AGT_STEP_PYR / _LK / _PNP)
+// Fused launch (all roles in one kernel, PnP chained to LK through arrival counters) while <= 256 corners are in flight:
+// one 256-thread workgroup per CU (the PnP role's registers) holds every LK workgroup of <= 5 streams of 48 corners at once.
+// Beyond that the same pipeline runs in split mode, one launch per role (AGT_STEP_PYR / _LK / _PNP): round-3 sweep at 16 frames
+// per group, us per step fused (round 2's OCC = 2 build) vs split with the LK role as one group launch: 6 streams 23.2 / 19.6,
+// 8: 24.6 / 20.4, 12: 33.9 / 25.4, 16: 38.0 / 33.5, 21: 46.7 / 36.9, 32: 42.9 / 40.6, 42: 56.0 / 46.2 (profiles/r03_stream_sweep.txt).
 bool agt_step_fits(int n, int B)
 {
 #ifdef AGT_DEBUG_KNOBS
-    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 2048L; }();
+    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 256L; }();
 #else
-    const long cap = 2048;
+    const long cap = 256;
 #endif
     return n <= AGT_WAVE && (long)n * B <= cap;
 }

@@ -429,6 +429,8 @@ class _DeviceStream:
 
     # ---- per-frame entry
     def frame(self, det, frame, raw):
+        if det.detector is None and self.has_prev and self.trk is not None:
+            return self._frame_tracked_one_call(det, frame, raw)
         g = self._ingest(det, frame, raw)
         img_list, obj_list, ids = [], [], []
         if det.detector is not None:
@@ -445,6 +447,29 @@ class _DeviceStream:
             self.trk.step(g, self.rec_dev)        # LK from the previous frame's corners: fills detect_pose.py:573-574
             self.trk.join()
         self._finish(det)
+
+    def _frame_tracked_one_call(self, det, frame, raw):
+        """LK path without a detector: upload, pre-processing, agt_track_frame, join, record download and the wait in ONE
+        foreign call (agt_track_host_frame)"""
+        frame = np.asarray(frame)
+        if tuple(frame.shape) != self.shape or raw != self.raw or frame.dtype != np.uint8:
+            raise ValueError("backend='stream': frame shape / kind changed from %r to %r; use a new detector" % (self.shape, frame.shape))
+        C, ctx = self.C, self.trk.ctx
+        ctx.use_current_stream()
+        self.gi = (self.gi + 1) & 3
+        g = self.gray[self.gi]
+        pin = self._pinned(frame)
+        color = frame.ndim == 3
+        if color and self.bgr is None:
+            self.bgr = self.torch.zeros((1,) + frame.shape, dtype=self.torch.uint8, device=self.trk.dev)
+        self.H.check(ctx.L.agt_track_host_frame(ctx.h, C.c_void_p(pin.data_ptr()), 3 if color else 1, self.src_hw[1], self.src_hw[0],
+                                                C.c_void_p(self.bgr.data_ptr()) if color else None, int(self.undistort and color),
+                                                self.roi[0] if color else 0, self.roi[1] if color else 0, C.c_void_p(g.data_ptr()), self.gpitch,
+                                                C.c_void_p(self.rec_dev.data_ptr()), C.c_void_p(self.rec_host.data_ptr())), "agt_track_host_frame")
+        self.trk._alive.append(g)
+        if len(self.trk._alive) > self.trk._keep_frames:
+            del self.trk._alive[0]
+        self._finish(det, downloaded=True)
 
     def estimate(self, det, imgpoints_arr, objpoints_arr):
         """_estimate_pose(img_list, obj_list) with caller-supplied correspondences (no frame)"""
@@ -472,11 +497,12 @@ class _DeviceStream:
             self.pts_np[4 * t:4 * t + 4] = np.asarray(img, np.float32).reshape(4, 2)
             self.mask_np[4 * t:4 * t + 4] = 1
 
-    def _finish(self, det):
+    def _finish(self, det, downloaded=False):
         H = self.H
         ctx = self.trk.ctx
-        H.check(ctx.L.agt_download(ctx.h, self.C.c_void_p(self.rec_host.data_ptr()), self.C.c_void_p(self.rec_dev.data_ptr()),
-                                   8 * H.STATE_STRIDE), "agt_download")
+        if not downloaded:
+            H.check(ctx.L.agt_download(ctx.h, self.C.c_void_p(self.rec_host.data_ptr()), self.C.c_void_p(self.rec_dev.data_ptr()),
+                                       8 * H.STATE_STRIDE), "agt_download")
         self.started = True
         self.dirty = True
         r = self.rec_np

@@ -332,7 +332,7 @@ def main():
         return main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal)
     bench = Bench(torch, wl, args, rank, world, dev)
     B, K, Wm, NPTS = bench.B, bench.K, bench.Wm, bench.npts
-    fused = B * NPTS <= 2048           # fused launch (agt_step_fits)
+    fused = B * NPTS <= 256            # fused launch (agt_step_fits)
     auto_depth = min(K, 32)           # chained launches: a short block is ONE launch deep (plus the pyramid launch ahead of it)
     depth = max(1, min(args.depth or (auto_depth if fused else min(K, 16)), 32))      # split mode (not fused): two launches per group of `depth` frames
     bench.trk.pipeline(depth)

@@ -180,7 +180,7 @@ int agt_tracker_tag_gate(agt_ctx* ctx, int corners_per_tag);
  * in stream order after its call.  depth F in 1..32 (default 1; needs reproject == 0, otherwise the call falls back to
  * depth 0 behaviour): agt_track_frame registers the frame and, every F calls, issues ONE fused launch that advances every
  * pipeline stage by F frames, stages of different frames side by side in disjoint workgroup ranges: the pyramid of
- * frames t-F+1..t, the LK of the F frames before those, and the pose solves.  Up to 2048 corners in flight the launch is
+ * frames t-F+1..t, the LK of the F frames before those, and the pose solves.  Up to 256 corners in flight the launch is
  * CHAINED: its PnP workgroups follow its LK workgroups frame by frame through per-frame arrival counters in device
  * memory (the LK role counts each corner in after a write-through store of its result; the PnP wave of the stream polls
  * the frame's counter, then acquires) -- one frame behind the LK role while frames keep coming, so neither role ever
@@ -196,7 +196,7 @@ int agt_tracker_tag_gate(agt_ctx* ctx, int corners_per_tag);
  * agt_synchronize joins and waits.  Frames handed to agt_track_frame must stay valid and unmodified until their pose
  * has been produced ((L+2)*F + F frames are in flight at most), and the frames of one group must share pitch and batch
  * stride.  Changing the depth joins first.
- * With more than 2048 corners in flight (depth >= 1) the same pipeline runs as one launch per role and
+ * With more than 256 corners in flight (depth >= 1) the same pipeline runs as one launch per role and
  * group: the pyramid role on the context's stream, the LK and PnP roles on two library-owned streams, ordered by events
  * (PnP one group behind LK); agt_tracker_join makes the context's stream wait for the library's.  Frame lifetime as above. */
 int agt_tracker_pipeline(agt_ctx* ctx, int depth);
@@ -222,6 +222,15 @@ int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t 
  * agt_tracker_reset without corners.  Joins the pipeline first; pyramid pass + one PnP launch in stream order. */
 int agt_track_frame_detected(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                              const float* d_corners, const uint8_t* d_mask, double* d_state_out);
+/* The body of the reference's live loop (detect_pose.py:669-681) for ONE stream whose frames live on the HOST, in one call:
+ * h_frame (pinned for an asynchronous copy; channels = 1: gray W x H of the context, channels = 3: BGR src_w x src_h, uploaded
+ * into d_staging and passed through agt_preprocess_bgr with the given undistort flag and ROI origin) -> d_gray (context-size
+ * gray frame, row pitch gpitch; must stay valid while the NEXT frame is tracked: alternate at least two buffers) ->
+ * agt_track_frame -> agt_tracker_join -> the frame's record copied to h_state (AGT_STATE_STRIDE doubles) -> the stream is
+ * waited for.  On return h_state is valid.  Needs B = 1 and a seeded tracker (agt_tracker_reset with corners or
+ * agt_track_frame_detected). */
+int agt_track_host_frame(agt_ctx* ctx, const uint8_t* h_frame, int channels, int src_w, int src_h, uint8_t* d_staging,
+                         int undistort, int roi_x, int roi_y, uint8_t* d_gray, size_t gpitch, double* d_state, double* h_state);
 /* A clip: `count` consecutive frames of the B streams in one call, frame k at d_frames + k * frame_stride (bytes), its
  * record at d_state_out + k * B * AGT_STATE_STRIDE (or NULL).  Exactly `count` calls of agt_track_frame, made without the
  * per-call host cost (at ~16 us of device time per 720p frame a Python caller's ~5 us per call is a third of the budget):
