@@ -928,8 +928,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     AgtPnpParams p;
     fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
     if (d_dense_out) {
-        const size_t need = (size_t)B * (size_t)(agt_dense_blocks(c->dn_M) > 0 ? agt_dense_blocks(c->dn_M) : 1) * 32;
-        rc = dense_scratch(c, need, B);
+        rc = dense_scratch(c, agt_dense_doubles(c->dn_M, B), B);
         if (rc) return rc;
         p.dense_pose = c->pose; p.dense_done = c->dense_done; p.dense_rec = d_dense_out;
     }
@@ -940,10 +939,9 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         // dense photometric + geometric refinement of the frame's accepted pose, then (reseed) the corner set from it
         e = agt_launch_dense(M, d_frames, (long)pitch, (long)batch_stride, c->cfg.width, c->cfg.height, c->dn_xyz, c->dn_t, c->dn_M,
                              c->obj, c->corners[slot], c->status[slot], c->trk_n, c->cam, c->pose, c->dense_partials, nullptr,
-                             c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX);
+                             c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, c->dn_reseed ? c->corners[slot] : nullptr,
+                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX);
         if (pev) c->prof_dense[c->prof_n - 1] = c->dn_iters < AGT_PROF_DENSE_MAX ? c->dn_iters : AGT_PROF_DENSE_MAX;
-        if (e == hipSuccess && c->dn_reseed)
-            e = agt_launch_dense_reseed(M, d_dense_out, c->obj, c->trk_n, c->cam, c->corners[slot], c->status[slot], B);
         if (e != hipSuccess) return hip_fail(c, e);
     }
     c->trk_frame = t; c->n_lk = c->n_pnp = t;
@@ -1244,12 +1242,11 @@ int agt_dense_refine(agt_ctx* c, const uint8_t* d_img, size_t pitch, size_t batc
     AgtCameraHost cam;
     int rc = fill_camera(K, dist, ndist, &cam);
     if (rc) return rc;
-    const size_t need = (size_t)B * (size_t)(agt_dense_blocks(M) > 0 ? agt_dense_blocks(M) : 1) * 32;
-    rc = dense_scratch(c, need, B);
+    rc = dense_scratch(c, agt_dense_doubles(M, B), B);
     if (rc) return rc;
     hipError_t e = agt_launch_dense(c->stream, d_img, (long)pitch, (long)batch_stride, w, h, d_model_xyz, d_model_t, M,
                                     d_obj, d_img_pts, d_mask, N, cam, d_pose, c->dense_partials, d_stats, c->dense_done,
-                                    B, iters, photo_weight, 1e-3, nullptr);
+                                    B, iters, photo_weight, 1e-3, nullptr, nullptr, nullptr);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 

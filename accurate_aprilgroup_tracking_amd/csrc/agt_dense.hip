@@ -12,12 +12,15 @@
 //       the block writes ONE row of 32 doubles: no atomics, bit-reproducible.  The last block of a stream
 //       evaluates the corner (geometric) rows instead, one corner per thread, into a row of the same layout
 //       (round 1 did them serially inside the update kernel: 16 us per iteration at 240 corners, now 4).
-//   dense_update_kernel one block per stream: sums the block rows (8 interleaved groups, fixed order), adds the corner
-//       row, solves the damped 6x6 system, updates the pose and
-//       raises a `done` word when the relative step falls under FLT_EPSILON (later launches of
-//       the same call then fall through).
-// One Gauss-Newton iteration = two launches; a call enqueues 2 * iters launches and never
-// synchronises.  No MFMA: the contraction is 6x6.
+//   the update (sum the block rows in 8 interleaved groups, fixed order; add the corner row; solve the damped 6x6 system;
+//       new pose; `done` when the relative step falls under FLT_EPSILON) is the PROLOGUE of the next accumulate launch
+//       (round 3): every block of iteration k + 1 re-derives the step of iteration k from the 241 rows (62 KB, L2-resident,
+//       same order in every block, so all blocks hold the same bits) and goes on accumulating at the new pose; block 0 also
+//       publishes pose, statistics and the done word.  Rows and intermediate poses are double-buffered by iteration parity (a
+//       fast block of launch k + 1 writes rows while a slow one still reads those of launch k).  dense_final_kernel does the
+//       last update and, as a tracker stage, the corner re-seed (projectPoints of the object points at the refined pose).
+// iters Gauss-Newton iterations = iters + 1 launches (round 2: 2 * iters + 1 re-seed launch); nothing synchronises.
+// No MFMA: the contraction is 6x6.
 #undef AGT_PNP_STAMPS
 #include "agt_pnp_body.h"
 
@@ -34,7 +37,9 @@ struct DenseParams {
     const float* obj; const float* ipts; const uint8_t* mask; int N;
     AgtCameraHost cam;
     double* pose;                      // [B][6]
-    double* partials;                  // [B][nblk][DROW]
+    double* partials;                  // [2][B][nblk + 1][DROW]: block rows, double-buffered by iteration parity
+    double* ppose;                     // [2][B][8]: linearisation point of iteration k + 1 (published by block 0 of launch k + 1)
+    long pstride;                      // doubles between the two row buffers
     int nblk;
     double* stats;                     // [B][stats_stride]: 5 values written per iteration
     int stats_stride;
@@ -42,12 +47,89 @@ struct DenseParams {
     int* done;                         // [B]
     double photo_weight, mu;
     int iter;
+    float* seed_pts; uint8_t* seed_status;     // tracker stage with re-seed: the frame's corner set / LK status ([B][N][2], [B][N]) or null
 };
 
 struct DenseShared {
     double part[4][DN * 65];
     double wtot[4][DROW];
+    double rows8[8][DROW];             // update prologue: partial sums of the previous iteration's rows
+    double tot[2][DROW];
+    double pose[8];                    // [0..5] linearisation point of this launch, [6] = 1: stop (converged / singular)
 };
+
+// The Gauss-Newton update of iteration P.iter - 1 from its block rows: called by all 256 threads of a block; on return
+// sh.pose[0..5] holds the new pose and sh.pose[6] != 0 means "stop" -- the same bits in every block.  `publish`: this
+// block also writes pose / statistics / record / done word to global memory.
+__device__ __forceinline__ void dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
+                                             double* pose_out, bool publish, int iter_done)
+{
+    const int lane = threadIdx.x & 63;
+    {
+        // 16 independent loads in flight per thread (a rolled loop issues them one L2 round trip at a time: 7 us at 240 rows),
+        // summed in row order: the result does not depend on timing
+        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+        double s = 0.0;
+        for (int j0 = g; j0 < P.nblk; j0 += 128) {
+            double v[16];
+#pragma unroll
+            for (int u = 0; u < 16; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
+#pragma unroll
+            for (int u = 0; u < 16; u++) s += v[u];
+        }
+        sh.rows8[g][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < AGT_WAVE) {
+        if (lane < DROW) {
+            sh.tot[0][lane] = ((sh.rows8[0][lane] + sh.rows8[1][lane]) + (sh.rows8[2][lane] + sh.rows8[3][lane])) +
+                              ((sh.rows8[4][lane] + sh.rows8[5][lane]) + (sh.rows8[6][lane] + sh.rows8[7][lane]));
+            sh.tot[1][lane] = P.N > 0 ? rows[(long)P.nblk * DROW + lane] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        double param[6];
+#pragma unroll
+        for (int k = 0; k < 6; k++) param[k] = pose_in[k];
+        double A[36], g[6], dx[6];
+        int idx = 0;
+#pragma unroll
+        for (int q = 0; q < 6; q++)
+#pragma unroll
+            for (int c = q; c < 6; c++) { const double v = sh.tot[1][idx] + sh.tot[0][idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
+#pragma unroll
+        for (int q = 0; q < 6; q++) { g[q] = sh.tot[1][21 + q] + sh.tot[0][21 + q]; A[q * 7] *= 1.0 + P.mu; }
+        const bool ok = agt_solve6(A, g, dx);
+        double dn = 0.0, pn = 0.0;
+#pragma unroll
+        for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
+        const bool stop = !ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
+        if (lane == 0) {
+#pragma unroll
+            for (int q = 0; q < 6; q++) sh.pose[q] = ok ? param[q] - dx[q] : param[q];
+            sh.pose[6] = stop ? 1.0 : 0.0;
+            if (publish) {
+                const double ph_r2 = sh.tot[0][27], ph_n = sh.tot[0][28], geo_r2 = sh.tot[1][27], n_used = sh.tot[1][28];
+                double* st = P.stats + (long)b * P.stats_stride;
+                st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
+                st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
+                st[2] = ph_n; st[3] = (double)iter_done; st[4] = n_used;
+                if (!P.rec) st[5] = st[6] = st[7] = 0.0;
+                if (ok) {
+#pragma unroll
+                    for (int q = 0; q < 6; q++) { P.pose[(long)b * 6 + q] = param[q] - dx[q]; if (pose_out) pose_out[q] = param[q] - dx[q]; }
+                    if (P.rec) {
+                        double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) rc[q] = param[q] - dx[q];
+                        rc[AGT_DN_REFINED] = 1.0;
+                    }
+                }
+                if (stop) P.done[b] = 1;
+            }
+        }
+    }
+    __syncthreads();
+}
 
 __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
 {
@@ -57,14 +139,29 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     if (P.done[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool geo = (int)blockIdx.x == P.nblk;        // the last block of a stream evaluates the corner (geometric) rows
+    const int par = P.iter & 1;
+    double param[6];
+    if (P.iter > 0) {
+        // the update of iteration iter - 1, re-derived by every block (same rows, same order: same bits everywhere)
+        const double* rows_prev = P.partials + (long)(par ^ 1) * P.pstride + (long)b * (P.nblk + 1) * DROW;
+        // ppose[k & 1] = linearisation point of iteration k: written by block 0 of launch k, read by every block of launch k + 1
+        // (launch 0 copies the caller's start pose there: P.pose itself is overwritten by the publishing block)
+        const double* pose_prev = P.ppose + ((long)(par ^ 1) * gridDim.y + b) * 8;
+        double* pose_pub = blockIdx.x == 0 ? P.ppose + ((long)par * gridDim.y + b) * 8 : nullptr;
+        dense_update(P, sh, b, rows_prev, pose_prev, pose_pub, blockIdx.x == 0, P.iter);
+        if (sh.pose[6] != 0.0) return;
+#pragma unroll
+        for (int k = 0; k < 6; k++) param[k] = sh.pose[k];
+    } else {
+#pragma unroll
+        for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
+        if (blockIdx.x == 0 && tid < 6) P.ppose[((long)par * gridDim.y + b) * 8 + tid] = param[tid];
+    }
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
     bool has_dist = false;
 #pragma unroll
     for (int k = 0; k < 12; k++) has_dist |= cam.k[k] != 0.0;
-    double param[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
     double R[9], G[9];
     agt_rodrigues<true>(param, R, G);
 
@@ -146,131 +243,74 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     __syncthreads();
     if (tid < DROW) {
         const double t = tid < DN ? ((sh.wtot[0][tid] + sh.wtot[1][tid]) + (sh.wtot[2][tid] + sh.wtot[3][tid])) : 0.0;
-        P.partials[((long)b * (P.nblk + 1) + blockIdx.x) * DROW + tid] = t;
+        P.partials[(long)par * P.pstride + ((long)b * (P.nblk + 1) + blockIdx.x) * DROW + tid] = t;
     }
 }
 
-// one block per stream: sums the photometric block rows (8 interleaved groups, fixed order), adds the geometric row, solves
-// the damped 6x6 system, updates the pose (every lane of wave 0 redundantly; lane 0 stores)
-__global__ __launch_bounds__(256) void dense_update_kernel(const DenseParams P)
+// After the last accumulate launch, one block per stream: the update of the last iteration and, as a stage of the tracker
+// with re-seed, projectPoints(all object points; refined pose) into the frame's corner set, every corner trackable again
+// (stops the drift of raw LK chaining).
+__global__ __launch_bounds__(256) void dense_final_kernel(const DenseParams P)
 {
-    __shared__ double s_rows[8][DROW];
-    __shared__ double s_tot[2][DROW];
-    const int b = blockIdx.x, lane = threadIdx.x & 63;
-    if (P.done[b]) return;
-    const double* rows = P.partials + (long)b * (P.nblk + 1) * DROW;
-    {
-        // 16 independent loads in flight per thread (a rolled loop issues them one L2 round trip at a time: 7 us at 240 rows),
-        // summed in row order: the result does not depend on timing
-        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-        double s = 0.0;
-        for (int j0 = g; j0 < P.nblk; j0 += 128) {
-            double v[16];
-#pragma unroll
-            for (int u = 0; u < 16; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
-#pragma unroll
-            for (int u = 0; u < 16; u++) s += v[u];
-        }
-        s_rows[g][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x >= AGT_WAVE) return;
-    if (lane < DROW) {
-        s_tot[0][lane] = ((s_rows[0][lane] + s_rows[1][lane]) + (s_rows[2][lane] + s_rows[3][lane])) +
-                         ((s_rows[4][lane] + s_rows[5][lane]) + (s_rows[6][lane] + s_rows[7][lane]));
-        s_tot[1][lane] = P.N > 0 ? rows[(long)P.nblk * DROW + lane] : 0.0;
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double param[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
-    double A[36], g[6], dx[6];
-    int idx = 0;
-#pragma unroll
-    for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int c = q; c < 6; c++) { const double v = s_tot[1][idx] + s_tot[0][idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
-#pragma unroll
-    for (int q = 0; q < 6; q++) { g[q] = s_tot[1][21 + q] + s_tot[0][21 + q]; A[q * 7] *= 1.0 + P.mu; }
-    const bool ok = agt_solve6(A, g, dx);
-    double dn = 0.0, pn = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
-    if (lane == 0) {
-        const double ph_r2 = s_tot[0][27], ph_n = s_tot[0][28], geo_r2 = s_tot[1][27], n_used = s_tot[1][28];
-        double* st = P.stats + (long)b * P.stats_stride;
-        st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
-        st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
-        st[2] = ph_n; st[3] = (double)(P.iter + 1); st[4] = n_used;
-        if (!P.rec) st[5] = st[6] = st[7] = 0.0;
-        if (ok) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) P.pose[(long)b * 6 + q] = param[q] - dx[q];
-            if (P.rec) {
-                double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
-#pragma unroll
-                for (int q = 0; q < 6; q++) rc[q] = param[q] - dx[q];
-                rc[AGT_DN_REFINED] = 1.0;
-            }
-        }
-        if (!ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON) P.done[b] = 1;
-    }
-}
-
-// tracker stage, after the last iteration: streams whose pose was refined get their corner set re-seeded with
-// projectPoints(all object points; refined pose) and every corner trackable again (stops the drift of raw LK chaining)
-__global__ __launch_bounds__(64) void dense_reseed_kernel(const double* __restrict__ rec, const float* __restrict__ obj, int n,
-                                                          const AgtCameraHost camh, float* __restrict__ corners, uint8_t* __restrict__ status)
-{
-    const int b = blockIdx.x, lane = threadIdx.x;
-    const double* rc = rec + (long)b * AGT_DENSE_STRIDE;
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
+    DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
+    const int b = blockIdx.x;
+    const int par = (P.iter - 1) & 1;                 // P.iter = iterations launched
+    if (!P.done[b] && P.iter > 0)
+        dense_update(P, sh, b, P.partials + (long)par * P.pstride + (long)b * (P.nblk + 1) * DROW, P.ppose + ((long)par * gridDim.x + b) * 8,
+                     nullptr, true, P.iter);
+    if (!P.seed_pts || !P.rec) return;
+    const double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
     if (rc[AGT_DN_REFINED] == 0.0) return;
     AgtCamera cam;
-    agt_pnp::load_cam<float>(camh, cam);
+    agt_pnp::load_cam<float>(P.cam, cam);
     double param[6], R[9], G[9];
 #pragma unroll
     for (int k = 0; k < 6; k++) param[k] = rc[k];
     agt_rodrigues<false>(param, R, G);
-    for (int i = lane; i < n; i += AGT_WAVE) {
+    for (int i = threadIdx.x; i < P.N; i += 256) {
         double u, v;
-        agt_project<false>(cam, R, G, param + 3, (double)obj[i * 3], (double)obj[i * 3 + 1], (double)obj[i * 3 + 2], u, v, nullptr, nullptr);
-        corners[((long)b * n + i) * 2] = (float)u; corners[((long)b * n + i) * 2 + 1] = (float)v;
-        status[(long)b * n + i] = 1;
+        agt_project<false>(cam, R, G, param + 3, (double)P.obj[i * 3], (double)P.obj[i * 3 + 1], (double)P.obj[i * 3 + 2], u, v, nullptr, nullptr);
+        P.seed_pts[((long)b * P.N + i) * 2] = (float)u; P.seed_pts[((long)b * P.N + i) * 2 + 1] = (float)v;
+        P.seed_status[(long)b * P.N + i] = 1;
     }
 }
 
 }  // namespace
 
-hipError_t agt_launch_dense_reseed(hipStream_t stream, const double* rec, const float* obj, int n, const AgtCameraHost& cam,
-                                   float* corners, uint8_t* status, int B)
-{
-    hipLaunchKernelGGL(dense_reseed_kernel, dim3(B), dim3(64), 0, stream, rec, obj, n, cam, corners, status);
-    return hipGetLastError();
-}
-
 // rec == null: plain agt_dense_refine (done words cleared here, stats [B][8]).  rec != null: stage of the tracker -- the
 // done words and the start poses were written by the PnP epilogue of the same frame (done = pose not accepted), the
-// statistics go into the record.
+// statistics go into the record; seed_pts / seed_status != null: the corner re-seed rides in the final launch.
+// partials: agt_dense_doubles(M, B) doubles.
 hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,
                             const float* mxyz, const float* mt, int M,
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
-                            int B, int iters, double photo_weight, double mu, double* rec, hipEvent_t* ev, int n_ev)
+                            int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
+                            hipEvent_t* ev, int n_ev)
 {
     DenseParams P;
     P.rec = rec; P.stats_stride = rec ? AGT_DENSE_STRIDE : 8;
     if (rec) stats = rec + AGT_DN_PHOTO_RMS;
     P.img = img; P.pitch = pitch; P.ibatch = ibatch; P.w = w; P.h = h;
     P.mxyz = mxyz; P.mt = mt; P.M = M; P.obj = obj; P.ipts = ipts; P.mask = mask; P.N = N;
-    P.cam = cam; P.pose = pose; P.partials = partials; P.nblk = (M + 255) / 256; P.stats = stats; P.done = done;
+    P.cam = cam; P.pose = pose; P.nblk = (M + 255) / 256; P.stats = stats; P.done = done;
+    P.partials = partials; P.pstride = (long)B * (P.nblk + 1) * DROW; P.ppose = partials + 2 * P.pstride;
     P.photo_weight = photo_weight; P.mu = mu;
+    P.seed_pts = seed_pts; P.seed_status = seed_status;
     hipError_t e = rec ? hipSuccess : hipMemsetAsync(done, 0, (size_t)B * sizeof(int), stream);
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
         hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk + (N > 0 ? 1 : 0), B), dim3(256), sizeof(DenseShared), stream, P);
-        if (ev && 2 * it < n_ev) (void)hipEventRecord(ev[2 * it], stream);                // profiling only
-        hipLaunchKernelGGL(dense_update_kernel, dim3(B), dim3(256), 0, stream, P);
-        if (ev && 2 * it + 1 < n_ev) (void)hipEventRecord(ev[2 * it + 1], stream);
+        // profiling only: span "accumulate" i = launch i (which carries the update of iteration i - 1), span "update" = the final launch
+        if (ev && 2 * it < n_ev) (void)hipEventRecord(ev[2 * it], stream);
+        if (ev && 2 * it + 1 < n_ev && it + 1 < iters) (void)hipEventRecord(ev[2 * it + 1], stream);
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) {
+        P.iter = iters;
+        hipLaunchKernelGGL(dense_final_kernel, dim3(B), dim3(256), sizeof(DenseShared), stream, P);
+        if (ev && iters > 0 && 2 * (iters - 1) + 1 < n_ev) (void)hipEventRecord(ev[2 * (iters - 1) + 1], stream);
         e = hipGetLastError();
     }
     return e;
@@ -278,3 +318,5 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
 
 // rows of block partials per stream: the photometric blocks and one geometric (corner) block
 int agt_dense_blocks(int M) { return (M + 255) / 256 + 1; }
+// doubles of scratch a call needs: two row buffers (iteration parity) + two pose slots per stream
+size_t agt_dense_doubles(int M, int B) { return (size_t)2 * B * (size_t)agt_dense_blocks(M) * DROW + (size_t)2 * B * 8; }

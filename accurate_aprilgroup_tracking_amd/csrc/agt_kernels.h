@@ -163,10 +163,10 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
                             const float* mxyz, const float* mt, int M,
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
-                            int B, int iters, double photo_weight, double mu, double* rec, hipEvent_t* ev = nullptr, int n_ev = 0);
-hipError_t agt_launch_dense_reseed(hipStream_t stream, const double* rec, const float* obj, int n, const AgtCameraHost& cam,
-                                   float* corners, uint8_t* status, int B);
+                            int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
+                            hipEvent_t* ev = nullptr, int n_ev = 0);
 int agt_dense_blocks(int M);
+size_t agt_dense_doubles(int M, int B);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);

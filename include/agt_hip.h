@@ -302,7 +302,8 @@ int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, s
 #define AGT_PROF_DENSE_MAX 16      /* dense GN iterations timed individually per frame (agt_track_frame_dense) */
 #define AGT_PROF_EVENTS (4 + 2 * AGT_PROF_DENSE_MAX)
 #define AGT_PROF_SPANS  5          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine,
-                                      3: sum of the dense accumulate launches of the frame, 4: sum of its dense update launches (0 without the stage) */
+                                      3: sum of the dense Gauss-Newton launches of the frame (launch i: update of iteration i - 1, then the
+                                         accumulate of iteration i), 4: its final launch (last update + corner re-seed); 0 without the stage */
 int agt_profile_begin(agt_ctx* ctx, int max_frames);
 int agt_profile_end(agt_ctx* ctx, float* ms_out, int* n_frames);
 
