@@ -291,7 +291,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--split", type=int, default=-1, help="diagnostic builds only (AGT_STEP_MAX_CORNERS): label of a forced fused / split run")
+    ap.add_argument("--pair-contexts", type=int, default=4, help="c3pairs: contexts / streams the independent batches are pipelined over (1 = serial)")
     ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
     ap.add_argument("--blocks", type=int, default=15, help="timed blocks of --steps steps each (median / p10 / p90 over them)")
     ap.add_argument("--streams", type=int, default=None, help="independent streams per GPU (default: the workload's)")

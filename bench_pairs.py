@@ -6,6 +6,11 @@ nothing cached from an earlier step), cv::calcOpticalFlowPyrLK on them (agt_lk_t
 (agt_solve_pnp) -- the stateless C-ABI entry points, stage kernels in stream order.  Algorithmic bytes:
 B_pair = 2 * W * H * 1.3125 + N * L * (24^2 + 32^2) + N * 21 = 2,650,608 B at 1280x720, L = 3, N = 48; 169,638,912 B per batch.
 Four distinct batches (4 x 118 MB of frames > the 256 MiB Infinity Cache) rotate, so every step reads HBM-cold frames.
+
+Batches are independent of each other, so consecutive steps are software-pipelined: NCTX contexts (each with its own two pyramid
+slots and its own HIP stream) take the steps round-robin, and the chip overlaps the HBM-bound pyramid passes of one batch with the
+VALU- / latency-bound LK and PnP kernels of the batches before it.  Inside a batch the four stages stay in stream order.
+--pair-contexts 1 gives the strictly serial form (one stream).
 """
 import ctypes as C
 import json
@@ -49,18 +54,26 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
     render_s = time.time() - t_r
     pts_d = torch.from_numpy(pts).to(dev); guess_d = torch.from_numpy(guess).to(dev)
     obj_d = torch.from_numpy(seqs[0].obj.astype(np.float32)).to(dev)
-    ctx = cv_hip.Context(W, H, max_level=B_.LEVELS - 1, win=B_.WIN, max_points=npts, max_streams=B)
-    L, h = ctx.L, ctx.h
-    nx = torch.zeros((B, npts, 2), dtype=torch.float32, device=dev)
-    st = torch.zeros((B, npts), dtype=torch.uint8, device=dev)
+    NCTX = max(1, int(getattr(args, "pair_contexts", 4) or 4))
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream() for _ in range(NCTX - 1)]
+    ctxs = []
+    for s_ in streams:
+        with torch.cuda.stream(s_):
+            ctxs.append(cv_hip.Context(W, H, max_level=B_.LEVELS - 1, win=B_.WIN, max_points=npts, max_streams=B))     # bound to s_
+    L = ctxs[0].L
+    nxs = [torch.zeros((B, npts, 2), dtype=torch.float32, device=dev) for _ in range(NCTX)]
+    sts = [torch.zeros((B, npts), dtype=torch.uint8, device=dev) for _ in range(NCTX)]
     pose = torch.zeros((K, B, 6), dtype=torch.float64, device=dev)           # one record per step (the gathered poses)
-    info = torch.zeros((B, 4), dtype=torch.int32, device=dev)
+    infos = [torch.zeros((B, 4), dtype=torch.int32, device=dev) for _ in range(NCTX)]
     Kh = np.ascontiguousarray(seqs[0].K.reshape(-1)); Kp = Kh.ctypes.data_as(C.c_void_p)
     vp = lambda t: C.c_void_p(t.data_ptr())
     pitch, bstride = W, W * H
 
-    def step(j, pose_k, events=None):
-        rec = (lambda i: events[i].record()) if events else (lambda i: None)
+    hip = C.CDLL("libamdhip64.so")
+
+    def step(j, pose_k, events=None, q=0):
+        h, nx, st, info, sq_ = ctxs[q].h, nxs[q], sts[q], infos[q], streams[q]
+        rec = (lambda i: events[i].record(sq_)) if events else (lambda i: None)
         rec(0)
         HL.check(L.agt_pyramid_build(h, 0, vp(prev[j]), pitch, bstride, B), "agt_pyramid_build")
         rec(1)
@@ -68,13 +81,14 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         rec(2)
         HL.check(L.agt_lk_track(h, 0, 1, vp(pts_d[j]), vp(nx), vp(st), None, npts, B, 3, 30, 0.01, 0, 1e-4), "agt_lk_track")
         rec(3)
-        pose_k.copy_(guess_d[j])                                              # the extrinsic guess of every pair (3 KB)
+        # the extrinsic guess of every pair (3 KB), on the step's own stream
+        assert hip.hipMemcpyAsync(vp(pose_k), vp(guess_d[j]), C.c_size_t(B * 48), 3, C.c_void_p(sq_.cuda_stream)) == 0
         HL.check(L.agt_solve_pnp(h, vp(obj_d), 0, vp(nx), HL.F32, vp(st), npts, B, Kp, None, 0, vp(pose_k), 1, vp(info), None), "agt_solve_pnp")
         rec(4)
 
-    ctx.use_current_stream()
+    torch.cuda.synchronize()                  # the frames and tables above were written on the default stream
     for k in range(Wm):
-        step(k % NBATCH, pose[k % K])
+        step(k % NBATCH, pose[k % K], q=k % NCTX)
     torch.cuda.synchronize()
     D.gather_poses(pose)
     dts = []
@@ -82,7 +96,8 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         torch.cuda.synchronize(); D.barrier()
         t0 = time.perf_counter()
         for k in range(K):
-            step((r * K + k) % NBATCH, pose[k])
+            step((r * K + k) % NBATCH, pose[k], q=k % NCTX)
+        torch.cuda.synchronize()                                               # every stream: the poses of all K steps are complete
         gathered = D.gather_poses(pose)
         torch.cuda.synchronize(); D.barrier()
         dts.append(D.max_over_ranks(time.perf_counter() - t0, dev))
@@ -91,13 +106,13 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
     # correctness of what was timed: poses of the last block against the generator's truth, LK status
     ph = pose.cpu().numpy()
     err = max(np.abs(ph[k] - truth[((len(dts) - 1) * K + k) % NBATCH]).max() for k in range(K))
-    tracked = float(st.cpu().numpy().mean())
+    tracked = float(np.mean([s_.cpu().numpy().mean() for s_ in sts]))
     if rank == 0:
         # instrumented pass: HIP events on the launch stream around every call (the context launches on torch's current stream)
         M = min(K, 100)
         ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(M)]
         for k in range(M):
-            step(k % NBATCH, pose[k], ev[k])
+            step(k % NBATCH, pose[k], ev[k], q=0)                                 # serial pass on one stream: the kernels' own durations
         torch.cuda.synchronize()
         sp = np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(4)] for e in ev]).mean(axis=0)      # us
         ab = B_.algorithmic_bytes(W, H, npts)
@@ -116,7 +131,7 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                 "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(per[dom][0] / nlaunch),
                 "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / B_.HBM_PEAK_GBS, 4), "bytes_per_step": int(batch_bytes),
                                "frac_of_measured_copy_6290GBs": round(whole / 6290.0, 4)},
-                "call_spans_us": {k_: round(v, 2) for k_, v in spans.items()}}
+                "call_spans_us_serial_pass": {k_: round(v, 2) for k_, v in spans.items()}}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_pairs(seqs, NF)
@@ -125,7 +140,9 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP)", "data": "synthetic",
                "config": {"workload": wl["label"] % B, "pairs_per_step": B, "frames_resident": "%d batches x %d pairs x 2 frames in HBM (%.0f MiB), rotated"
                           % (NBATCH, B, NBATCH * B * 2 * W * H / 2**20),
-                          "launch": "stateless C-ABI calls in stream order: agt_pyramid_build x 2 (two single-level passes each), agt_lk_track, agt_solve_pnp (guess)"},
+                          "launch": "stateless C-ABI calls, per batch in stream order: agt_pyramid_build x 2 (two single-level passes each), agt_lk_track, "
+                                    "agt_solve_pnp (guess); consecutive batches round-robin over %d contexts / HIP streams (software pipelining across independent batches)" % NCTX,
+                          "contexts": NCTX},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
                "roofline": roof, "cpu_baseline": cpu, "max_abs_pose_err_vs_truth": float(err), "tracked_frac": round(tracked, 4),
