@@ -59,7 +59,12 @@ struct PnpShared {
     unsigned long long tab[5 * AGT_MAX_GROUP];     // fused step: copy of AgtPnpTables (img / mask / so / wait / target per frame)
     int seq;                                       // fused step, two alternating waves: frames of this launch whose state update is complete
     int late;                                      // fused step: one of the two waves gave up a chained wait (the other stops waiting too)
+    AgtTrackState ts;                              // pipelined roles: the stream's tracker state while the launch runs (see pnp_role)
 };
+
+// tracker state in LDS (pnp_role keeps it there for the frames of a launch: the hand-over from frame k to frame k + 1 is an
+// LDS write / read instead of global stores that have to be acknowledged and loads that miss -- ~1.2 us per frame)
+typedef __attribute__((address_space(3))) AgtTrackState AgtTrackStateLds;
 
 // sum K per-lane partials across the wave; totals land in sh.tot[0..K) and (READBACK) come back in
 // vals[] of every lane
@@ -372,7 +377,8 @@ __device__ inline void mat3_tvec(const double A[9], const double v[3], double o[
 // Rc = Rodrigues(curr rvec) is the rotation of the solve's last evaluation; Rp = Rodrigues(prev rvec) was kept
 // from the solve that produced prev (AgtTrackState::prev_R).  `st` = LDS copy of { rot_vel[2][9], tran_vel[2][3],
 // prev_R[9] } taken when the solve started (the global loads are long done by now).
-__device__ inline int motion_model_update(AgtTrackState* ts, int lane, const double curr[6], bool curr_t_f32,
+template <typename TS>
+__device__ inline int motion_model_update(TS* ts, int lane, const double curr[6], bool curr_t_f32,
                                           const double prev[6], bool prev_t_f32, const double Rc[9], const double* st)
 {
     double Rp[9];
@@ -471,10 +477,12 @@ struct PnpNoHook { __device__ __forceinline__ void operator()() const {} };
 // before_state(): called once, after this frame's correspondences have been requested and counted and BEFORE the tracker state
 // is read (the fused step's alternating PnP waves wait there for the previous frame's state update: the loads of frame k+1
 // run under the tail of frame k)
-template <typename T, int PPL, typename Hook = PnpNoHook>
+// LDS_STATE: the tracker state of stream b is sh.ts (the caller loaded it and writes it back), not P.track[b]
+template <typename T, int PPL, typename Hook = PnpNoHook, bool LDS_STATE = false>
 __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
                                          double* so_p, int extra_flags = 0, Hook before_state = Hook())
 {
+    using TS = typename std::conditional<LDS_STATE, AgtTrackStateLds, AgtTrackState>::type;
     const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
     const int n = P.n;
     PSTAMP(0);
@@ -525,7 +533,9 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     before_state();
     int flags = extra_flags;          // AGT_TRK_CHAIN_TIMEOUT from the chained launch, reported with the frame's record
     double param[6];
-    AgtTrackState* ts = P.track ? P.track + b : nullptr;
+    TS* ts;
+    if constexpr (LDS_STATE) ts = (TS*)&sh.ts;
+    else ts = P.track ? P.track + b : nullptr;
     if (ts && (agt_uniform(ts->chain_fault) | (extra_flags & AGT_TRK_CHAIN_TIMEOUT))) {
         // Fail-stop: the chained wait for this stream's corners gave up, now or in an earlier frame.  Nothing is
         // solved on a possibly stale ring entry and the motion-model state is not touched: the record is invalid and flagged,

@@ -36,10 +36,16 @@ extern "C" int agt_debug_step_stamps(unsigned long long* host16, int reset)
     }
     return rc;
 }
+// per-frame timeline of the PnP role of stream 0 (tools/rolestamps.py): [frame][0] loop top, [1] corners acquired, [2] previous
+// frame's state acquired, [3] frame done
+__device__ unsigned long long agt_role_stamps[AGT_MAX_GROUP * 4];
+#define RSTAMP(k, i) do { if (blk == 0 && lane == 0) agt_role_stamps[(k) * 4 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int agt_debug_role_stamps(unsigned long long* host) { return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(agt_role_stamps), sizeof(agt_role_stamps)); }
 #else
 #define SSTAMP_SET(i)
 #define SSTAMP_MAX(i)
 #define SSTAMP_MIN(i)
+#define RSTAMP(k, i)
 #endif
 
 namespace {
@@ -211,21 +217,29 @@ template <int PPL, int NWV = 1>
 __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh, int wave = 0)
 {
     static_assert(sizeof(AgtPnpTables) == 40 * AGT_MAX_GROUP && sizeof(sh.tab) == sizeof(AgtPnpTables), "table layout");
+    static_assert(sizeof(AgtTrackState) % 8 == 0 && sizeof(AgtTrackState) / 8 <= AGT_WAVE, "state copy: one double per lane");
     const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
+    // The stream's tracker state lives in LDS (sh.ts) for the frames of the launch: frame k + 1 starts from what frame k left
+    // there.  Through global memory the hand-over cost ~1.2 us per frame on the critical path -- the writer waits for its
+    // stores to be acknowledged before it may signal, the reader's loads go out to L2.  Loaded here, written back by the wave
+    // that solves the launch's last frame.
     if (NWV == 1) {
         if (S.pnp_nf > 1)
             for (unsigned i = lane; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE)
                 reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+        if (lane < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(&sh.ts)[lane] = reinterpret_cast<const double*>(S.pnp.track + blk)[lane];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
-    // (NWV == 2: the caller has copied the tables and zeroed sh.seq with the whole workgroup, behind a barrier)
+    // (NWV == 2: the caller has copied the tables and the state and zeroed sh.seq with the whole workgroup, behind a barrier)
     // (measured and dropped, round 3: s_setprio(3) for this wave -- in split mode it shares its SIMD with up to three VALU-bound
     // LK waves; the step time did not move at any stream count, the LK group launch is the longer chain there)
     int late = 0;
     for (int k = wave; k < S.pnp_nf; k += NWV) {
         const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
         const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
+        RSTAMP(k, 0);
         if (k) {
-            if (NWV == 1) { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); }
+            if (NWV == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }      // (tables, state: LDS)
             img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
             wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
         }
@@ -250,17 +264,25 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
+        RSTAMP(k, 1);
         auto before_state = [&]() {
+            RSTAMP(k, 1);
             if (NWV > 1) {
                 // frame k - 1 belongs to the other wave: its tracker state (global memory) and the scratch area are ours once
                 // it has counted itself in
                 while (agt_uniform(*(volatile int*)&sh.seq) < k) __builtin_amdgcn_s_sleep(1);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+                asm volatile("" ::: "memory");                  // (state and scratch are LDS: read in order behind sh.seq)
             }
+            RSTAMP(k, 2);
         };
-        agt_pnp::pnp_body<float, PPL>(S.pnp, blk, sh, img, mask, so, late ? AGT_TRK_CHAIN_TIMEOUT : 0, before_state);
+        agt_pnp::pnp_body<float, PPL, decltype(before_state), true>(S.pnp, blk, sh, img, mask, so, late ? AGT_TRK_CHAIN_TIMEOUT : 0, before_state);
+        // the state (LDS) is written: LDS operations of a wave complete in order, the other wave reads sh.seq first.  The
+        // frame's record and the write-back below are global stores nobody in this launch waits for.
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        RSTAMP(k, 3);
+        if (k == S.pnp_nf - 1 && lane < (int)(sizeof(AgtTrackState) / 8))
+            reinterpret_cast<double*>(S.pnp.track + blk)[lane] = reinterpret_cast<const double*>(&sh.ts)[lane];
         if (NWV > 1) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");          // the state and the record are written
             if (lane == 0) *(volatile int*)&sh.seq = k + 1;
         }
     }
@@ -293,6 +315,7 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
         for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += STEP_THREADS)
             reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
         if (threadIdx.x == 0) { sh.seq = 0; sh.late = 0; }
+        if (threadIdx.x < sizeof(AgtTrackState) / 8) reinterpret_cast<double*>(&sh.ts)[threadIdx.x] = reinterpret_cast<const double*>(S.pnp.track + blk)[threadIdx.x];
         __syncthreads();
         const int wave = (int)(threadIdx.x / AGT_WAVE);
         if (wave >= 2) return;
