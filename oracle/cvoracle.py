@@ -12,7 +12,8 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_LIB_PATH = os.path.join(_HERE, "libcvoracle.so")
+# CVORACLE_LIB: another build of the same sources (the AddressSanitizer / UBSan build of `make -C oracle asan`, CPU only)
+_LIB_PATH = os.environ.get("CVORACLE_LIB") or os.path.join(_HERE, "libcvoracle.so")
 
 SOLVEPNP_ITERATIVE = 0
 OPTFLOW_USE_INITIAL_FLOW = 4

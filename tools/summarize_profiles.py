@@ -6,12 +6,13 @@
                                fused step kernel only the full launches (grid = the most frequent grid size)
   r02_pmc_raw.json             per kernel and run: mean FETCH_SIZE / WRITE_SIZE (KiB per dispatch)
   pmc_traffic.json             'step_kernel<21,4,3> depth F' entries for the F the profiled commands ran at
-Usage: python3 tools/summarize_profiles.py gpurun_out/r2final"""
+Usage: python3 tools/summarize_profiles.py gpurun_out/r3final [r03]      (second argument: file prefix, default r02)"""
 import csv, glob, json, os, shutil, sys
 from collections import Counter, defaultdict
 import numpy as np
 
 src = sys.argv[1]
+PFX = sys.argv[2] if len(sys.argv) > 2 else "r02"
 dst = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "profiles")
 short = lambda n: n.replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
 
@@ -39,10 +40,10 @@ durations, pmc = {}, {}
 for d in sorted(glob.glob(os.path.join(src, "*_stats"))):
     run = os.path.basename(d)[:-6]
     ks = glob.glob(os.path.join(d, "*", "*_kernel_stats.csv"))[0]
-    shutil.copy(ks, os.path.join(dst, "r02_%s_kernel_stats.csv" % run))
+    shutil.copy(ks, os.path.join(dst, PFX + "_%s_kernel_stats.csv" % run))
     b = bench_line(run + "_stats")
     if b:
-        json.dump(b, open(os.path.join(dst, "r02_%s_bench.json" % run), "w"), indent=1)
+        json.dump(b, open(os.path.join(dst, PFX + "_%s_bench.json" % run), "w"), indent=1)
     per = defaultdict(list)
     for r in csv.DictReader(open(glob.glob(os.path.join(d, "*", "*_kernel_trace.csv"))[0])):
         per[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"]), int(r["Grid_Size_X"])))
@@ -58,7 +59,7 @@ for d in sorted(glob.glob(os.path.join(src, "*_stats"))):
                   "p90_us": round(float(np.percentile(t, 90)), 2), "grid": Counter(x[1] for x in v).most_common(1)[0][0]}
     durations[run] = {"command_metric": b and {"value": b["value"], "ms_per_step": b["ms_per_step"], "steps": b["steps"],
                                                "launch": b["config"].get("launch")}, "kernels": out}
-json.dump(durations, open(os.path.join(dst, "r02_kernel_durations.json"), "w"), indent=1)
+json.dump(durations, open(os.path.join(dst, PFX + "_kernel_durations.json"), "w"), indent=1)
 
 for kind in ("fetch", "write"):
     for d in sorted(glob.glob(os.path.join(src, "*_" + kind))):
@@ -80,7 +81,7 @@ for kind in ("fetch", "write"):
         b = bench_line(run + "_" + kind)
         if b and "frames_per_launch" in b.get("roofline", {}):
             pmc[run]["_frames_per_launch"] = b["roofline"]["frames_per_launch"]
-json.dump(pmc, open(os.path.join(dst, "r02_pmc_raw.json"), "w"), indent=1)
+json.dump(pmc, open(os.path.join(dst, PFX + "_pmc_raw.json"), "w"), indent=1)
 
 # launch period per depth from the kernel-trace-only runs (the counter passes themselves slow the kernels down by ~30 %)
 stats_launch_us = {}
@@ -100,10 +101,24 @@ for run, ks in pmc.items():
             "workload": "c2: 1 x 1280x720 stream, %d frames per chained launch (full launches only)" % F,
             "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": e["FETCH_SIZE_KiB_mean"], "WRITE_SIZE_KiB_mean": e["WRITE_SIZE_KiB_mean"],
             "traffic_bytes_per_launch": int(round((2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024)),
-            "algorithmic_bytes_per_launch": 1441008 * F, "build": "round 2 final (chained launch, frame-chained LK role)",
+            "algorithmic_bytes_per_launch": 1441008 * F, "build": PFX + " final (chained launch, frame-chained LK role)",
             # launch period bench.py measured (HIP events) in the run the counters were taken in: bench.py withholds the figure
             # when its own launch period has moved away from this by more than 15 %
             "launch_us_at_collection": stats_launch_us.get(F)}
+def raw_entry(run, prefix, name, label, alg=None):
+    """pmc_traffic.json entry `name` from the raw counters of the first kernel of `run` whose short name starts with `prefix`"""
+    for k, e in pmc.get(run, {}).items():
+        if k.startswith(prefix) and "FETCH_SIZE_KiB_mean" in e and "WRITE_SIZE_KiB_mean" in e:
+            us = durations.get(run, {}).get("kernels", {}).get(k, {}).get("mean_us")
+            traffic[name] = {"workload": label, "kernel": k, "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": e["FETCH_SIZE_KiB_mean"],
+                             "WRITE_SIZE_KiB_mean": e["WRITE_SIZE_KiB_mean"],
+                             "traffic_bytes_per_launch": int(round((2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024)),
+                             "algorithmic_bytes_per_launch": alg, "build": PFX, "launch_us_at_collection": us,
+                             "note": "mean over every dispatch of the kernel in the run; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"}
+            return
+raw_entry("c5", "dense_accum_kernel", "dense_accum_kernel", "c5: 61,440 samples + 240 corners, one Gauss-Newton launch (update prologue + accumulate)", 61440 * 28)
+raw_entry("c3pairs", "pyr_down_kernel", "pyr_down_kernel c3pairs", "c3pairs: pyr_down over 64 cold 720p frames, mean of the L0->L1 and L1->L2 launches", None)
+raw_entry("c3pairs", "lk_kernel<21, 1, 3", "lk_kernel<21,1,3> c3pairs", "c3pairs: 3072 corners, one wave per corner", 64 * (48 * 3 * 1600 + 48 * 21))
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({r: {k: v for k, v in d["kernels"].items()} for r, d in durations.items()}, indent=1)[:6000])
 print(json.dumps({k: v for k, v in traffic.items() if "depth" in k}, indent=1))
