@@ -164,6 +164,7 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     for (int k = 0; k < 12; k++) has_dist |= cam.k[k] != 0.0;
     double R[9], G[9];
     agt_rodrigues<true>(param, R, G);
+    const double tvec[3] = { param[3], param[4], param[5] };      // (param + 3 as an argument kept three doubles in scratch: 1.5 MB of writes per launch)
 
     double acc[DN];
 #pragma unroll
@@ -173,8 +174,8 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
         if (i < P.M) {
             const double X = (double)P.mxyz[(long)i * 3], Y = (double)P.mxyz[(long)i * 3 + 1], Z = (double)P.mxyz[(long)i * 3 + 2];
             double u, v, jr[6], jt[6];
-            if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-            else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            if (has_dist) agt_project<true, true>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
+            else agt_project<true, false>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
             const double fx0 = floor(u), fy0 = floor(v);
             if (fx0 >= 1.0 && fx0 <= (double)(P.w - 3) && fy0 >= 1.0 && fy0 <= (double)(P.h - 3)) {
                 const int x0 = (int)fx0, y0 = (int)fy0;
@@ -210,8 +211,8 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
             if (P.mask && !P.mask[(long)b * P.N + i]) continue;
             double u, v, jr[6], jt[6];
             const double X = (double)P.obj[i * 3], Y = (double)P.obj[i * 3 + 1], Z = (double)P.obj[i * 3 + 2];
-            if (has_dist) agt_project<true, true>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
-            else agt_project<true, false>(cam, R, G, param + 3, X, Y, Z, u, v, jr, jt);
+            if (has_dist) agt_project<true, true>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
+            else agt_project<true, false>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
             const double ex = u - (double)P.ipts[((long)b * P.N + i) * 2], ey = v - (double)P.ipts[((long)b * P.N + i) * 2 + 1];
             const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
             const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };

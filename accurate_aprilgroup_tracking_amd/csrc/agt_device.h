@@ -130,19 +130,14 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
 {
     double rx = r_in[0], ry = r_in[1], rz = r_in[2];
     const double t2 = rx * rx + ry * ry + rz * rz;
-    double theta = agt_sqrtp(t2);
-    if (theta < DBL_EPSILON) {
-#pragma unroll
-        for (int i = 0; i < 9; i++) R[i] = (i % 4 == 0) ? 1.0 : 0.0;
-        if (JAC) {
-#pragma unroll
-            for (int i = 0; i < 9; i++) G[i] = (i % 4 == 0) ? 1.0 : 0.0;      // dR/dr_j = [e_j]x at r = 0
-        }
-        return;
-    }
+    const double theta = agt_sqrtp(t2);
+    // theta < DBL_EPSILON: R = I (and G = I: dR/dr_j = [e_j]x at r = 0).  Written as selects on the results, not as an early
+    // return: with two exits the optimiser kept R[0] and G[0] in memory behind a pointer phi -- 32 B of scratch per lane in every
+    // kernel that calls this (1.5 MB of scratch writes per dense launch, a scratch round trip in each LM evaluation).
+    const bool tiny = theta < DBL_EPSILON;
     double s, c;
     agt_sincos(theta, s, c);
-    double c1 = 1.0 - c, itheta = agt_rcp(theta);
+    const double c1 = 1.0 - c, itheta = agt_rcp(tiny ? 1.0 : theta);
     if (JAC) {
         // a = (1 - cos t)/t^2, b = (t - sin t)/t^3; series below t = 1e-2 (cancellation), relative error < 1e-16 there
         double a, bq;
@@ -155,15 +150,20 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
             bq = (theta - s) * it2 * itheta;
         }
         const double d = 1.0 - bq * t2;                       // [r]x^2 = r r^T - t^2 I
-        G[0] = d + bq * rx * rx; G[1] = bq * rx * ry - a * rz; G[2] = bq * rx * rz + a * ry;
-        G[3] = bq * rx * ry + a * rz; G[4] = d + bq * ry * ry; G[5] = bq * ry * rz - a * rx;
-        G[6] = bq * rx * rz - a * ry; G[7] = bq * ry * rz + a * rx; G[8] = d + bq * rz * rz;
+        const double g[9] = { d + bq * rx * rx, bq * rx * ry - a * rz, bq * rx * rz + a * ry,
+                              bq * rx * ry + a * rz, d + bq * ry * ry, bq * ry * rz - a * rx,
+                              bq * rx * rz - a * ry, bq * ry * rz + a * rx, d + bq * rz * rz };
+#pragma unroll
+        for (int i = 0; i < 9; i++) G[i] = tiny ? ((i % 4 == 0) ? 1.0 : 0.0) : g[i];
     }
     rx *= itheta; ry *= itheta; rz *= itheta;
     const double rrt[9] = { rx * rx, rx * ry, rx * rz, rx * ry, ry * ry, ry * rz, rx * rz, ry * rz, rz * rz };
     const double r_x[9] = { 0, -rz, ry, rz, 0, -rx, -ry, rx, 0 };
 #pragma unroll
-    for (int k = 0; k < 9; k++) R[k] = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * r_x[k];
+    for (int k = 0; k < 9; k++) {
+        const double v = c * ((k % 4 == 0) ? 1.0 : 0.0) + c1 * rrt[k] + s * r_x[k];
+        R[k] = tiny ? ((k % 4 == 0) ? 1.0 : 0.0) : v;
+    }
 }
 
 struct AgtCamera {
