@@ -60,7 +60,7 @@ struct ChainCfg {
     static constexpr int TILE = C::JT * C::JP;                          // one search tile (40 rows x 44 B)
     static constexpr int SD = ((C::DW * C::DW + 3) & ~3) * 4;           // one derivative tile (22 x 22 ints)
     static constexpr int OFF_SD = 2 * NLEV * TILE;
-    static constexpr int OFF_SLOTS = OFF_SD + NLEV * SD;                // iteration sums: [2 phases][4 waves] int4 (256 B reserved)
+    static constexpr int OFF_SLOTS = OFF_SD + NLEV * SD;                // iteration sums: three rotating int4 accumulators (256 B reserved)
     static constexpr int OFF_RED = OFF_SLOTS + 2 * 4 * 4 * 8;           // covariance partials: [3 * NLEV][256 threads] int
     static constexpr int OFF_LVL = OFF_RED + 3 * NLEV * 256 * 4;        // per level: A11, A12, A22, 1 / det, usable (8 floats)
     static constexpr int BYTES = OFF_LVL + NLEV * 8 * 4;
@@ -111,16 +111,26 @@ __device__ __forceinline__ void iter_sum2(const int (&v)[2], float& f0, float& f
     xl += agt_dpp_i32<0x4E>(xl); xh += agt_dpp_i32<0x4E>(xh);
     xl += agt_dpp_i32<0x141>(xl); xh += agt_dpp_i32<0x141>(xh);
     xl += agt_dpp_i32<0x140>(xl); xh += agt_dpp_i32<0x140>(xh);
-    // (finishing the sums with row_bcast DPP steps and a store from lanes 31 / 63 measured 11 % slower than the read-lanes)
-    const int l0 = __builtin_amdgcn_readlane(xl, 0) + __builtin_amdgcn_readlane(xl, 16), l1 = __builtin_amdgcn_readlane(xl, 32) + __builtin_amdgcn_readlane(xl, 48);
-    const int h0 = __builtin_amdgcn_readlane(xh, 0) + __builtin_amdgcn_readlane(xh, 16), h1 = __builtin_amdgcn_readlane(xh, 32) + __builtin_amdgcn_readlane(xh, 48);
-    int4* s = reinterpret_cast<int4*>(slots) + phase * 4;
-    if (lane == 0) s[wave] = make_int4(l0, h0, l1, h1);
+    // After the four DPP steps every lane of a 16-lane row holds its row's sum; rows 0 / 1 belong to value 0, rows 2 / 3 to value 1
+    // (the swap).  The first lane of each row adds its row sum straight into the workgroup's accumulator with an LDS atomic
+    // (integer: order-free, still exact): { lo0, hi0, lo1, hi1 }, three rotating slots -- the slot of iteration i + 2 is cleared
+    // by thread 0 right after the barrier of iteration i, when its last readers (iteration i - 1) are past it.  No read-lanes,
+    // no scalar adds, and after the barrier every wave reads ONE 16-byte word instead of four.
+    // (round 2: read-lanes + ds_write_b128 per wave + four ds_read_b128 and twelve adds after the barrier; finishing the sums
+    // with row_bcast DPP steps and a store from lanes 31 / 63 had measured 11 % slower than that)
+    int* s = slots + phase * 4;
+    if ((lane & 15) == 0) {
+        __attribute__((address_space(3))) int* a = (__attribute__((address_space(3))) int*)(s + ((lane >> 5) << 1));
+        __hip_atomic_fetch_add(a, xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        __hip_atomic_fetch_add(a + 1, xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+    }
     lds_barrier();
-    const int4 a = s[0], b = s[1], c = s[2], d = s[3];
-    f0 = fmaf((float)(a.y + b.y + c.y + d.y), 65536.f, (float)(a.x + b.x + c.x + d.x));
-    f1 = fmaf((float)(a.w + b.w + c.w + d.w), 65536.f, (float)(a.z + b.z + c.z + d.z));
-    phase ^= 1;
+    const int4 t = *reinterpret_cast<const int4*>(s);
+    const int nz = phase == 0 ? 2 : phase - 1;                     // (phase + 2) % 3
+    if (threadIdx.x == 0) *reinterpret_cast<int4*>(slots + nz * 4) = make_int4(0, 0, 0, 0);
+    f0 = fmaf((float)t.y, 65536.f, (float)t.x);
+    f1 = fmaf((float)t.w, 65536.f, (float)t.z);
+    phase = phase == 2 ? 0 : phase + 1;
 }
 
 // Request one 40 x 44 B tile (origin tx0, ty0) into registers.  A tile that lies inside the image (wave-uniform test; nearly
@@ -163,7 +173,8 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
     const int max_count = P->max_count;
     const double min_eig_threshold = P->min_eig_threshold, eps2 = P->eps2;
     int* sDall = reinterpret_cast<int*>(lds + K::OFF_SD);
-    int* slots = reinterpret_cast<int*>(lds + K::OFF_SLOTS);      // [2 phases][4 waves] int4
+    int* slots = reinterpret_cast<int*>(lds + K::OFF_SLOTS);      // three rotating int4 accumulators of the iteration sums (iter_sum2)
+    if (threadIdx.x < 12) slots[threadIdx.x] = 0;                 // (visible long before the first iteration: three barriers come first)
     int* red = reinterpret_cast<int*>(lds + K::OFF_RED);
     float* lvl = reinterpret_cast<float*>(lds + K::OFF_LVL);
     int phase = 0;
@@ -512,7 +523,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 const int inx = (int)fx, iny = (int)fy;
                 bilinear_weights(nextx - fx, nexty - fy, iw00, iw01, iw10, iw11);
                 int bsum[2] = { 0, 0 };
-                const uint8_t* q0 = sJ + (iny - jy0) * JP + (inx - jx0) + (jx0 - (jx0 & ~3));
+                const uint8_t* q0 = sJ + __mul24(iny - jy0, JP) + (inx - jx0) + (jx0 - (jx0 & ~3));
 #pragma unroll
                 for (int q = 0; q < C::NPX; q++) {
                     const uint8_t* c = q0 + oW[q];
