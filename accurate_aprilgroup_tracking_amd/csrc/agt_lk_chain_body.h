@@ -521,13 +521,21 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                     }
                 }
                 const int inx = (int)fx, iny = (int)fy;
-                bilinear_weights(nextx - fx, nexty - fy, iw00, iw01, iw10, iw11);
-                int bsum[2] = { 0, 0 };
+                // the six tap bytes are requested FIRST (their address needs only the integer part of the position) and the
+                // bilinear weights -- ~20 dependent float operations on the fraction -- are computed while the LDS answers
                 const uint8_t* q0 = sJ + __mul24(iny - jy0, JP) + (inx - jx0) + (jx0 - (jx0 & ~3));
+                int tap[C::NPX][4];
 #pragma unroll
                 for (int q = 0; q < C::NPX; q++) {
                     const uint8_t* c = q0 + oW[q];
-                    const int diff = descale(bil4(c[0], c[1], c[JP], c[JP + 1], iw00, iw01, iw10, iw11), W_BITS - 5) - iv[q];
+                    tap[q][0] = c[0]; tap[q][1] = c[1]; tap[q][2] = c[JP]; tap[q][3] = c[JP + 1];
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                bilinear_weights(nextx - fx, nexty - fy, iw00, iw01, iw10, iw11);
+                int bsum[2] = { 0, 0 };
+#pragma unroll
+                for (int q = 0; q < C::NPX; q++) {
+                    const int diff = descale(bil4(tap[q][0], tap[q][1], tap[q][2], tap[q][3], iw00, iw01, iw10, iw11), W_BITS - 5) - iv[q];
                     bsum[0] += __mul24(diff, ix[q]); bsum[1] += __mul24(diff, iy[q]);          // ix = iy = 0 where !pv
                 }
                 float fb1, fb2;
