@@ -170,6 +170,44 @@ template <int NW, int STEPS, int NV, bool PAIR_OK = false>
 __device__ __forceinline__ void block_sum_exact(const int (&v)[NV], long long (&out)[NV], long long* slots, int& phase,
                                                 int wave, int lane)
 {
+    if constexpr (NW == 4) {
+        // Four waves per corner (round 3): every value is split v = 65536 * hi + lo, two values share one DPP chain per half
+        // (v_permlane32_swap: value 0 in the lower half-wave, value 1 in the upper one), and the FIRST LANE OF EACH 16-LANE
+        // ROW adds its row sum straight into the workgroup's accumulators with LDS atomics (integer: order-free, exact):
+        // no read-lanes, no per-wave slots, one or two 16-byte reads after the barrier.  |v| < 2^28 per thread keeps every
+        // int32 partial in range (lo: 256 x 65535 < 2^24, hi: 256 x 2^12).  Three accumulator sets rotate; the set of sum
+        // i + 2 is cleared by thread 0 right after the barrier of sum i, when its last readers (sum i - 1) are past it.
+        // Accumulator layout: pair p of values -> ints [4 p + 2 * (value & 1) + { 0: lo, 1: hi }].
+        int* acc = reinterpret_cast<int*>(slots) + phase * 8;
+#pragma unroll
+        for (int p = 0; p < (NV + 1) / 2; p++) {
+            const int a = v[2 * p], b = 2 * p + 1 < NV ? v[2 * p + 1] : 0;
+            const auto swl = __builtin_amdgcn_permlane32_swap((unsigned)(a & 0xffff), (unsigned)(b & 0xffff), false, false);
+            const auto swh = __builtin_amdgcn_permlane32_swap((unsigned)(a >> 16), (unsigned)(b >> 16), false, false);
+            int xl = (int)swl[0] + (int)swl[1], xh = (int)swh[0] + (int)swh[1];
+            xl += agt_dpp_i32<0xB1>(xl); xh += agt_dpp_i32<0xB1>(xh);
+            xl += agt_dpp_i32<0x4E>(xl); xh += agt_dpp_i32<0x4E>(xh);
+            xl += agt_dpp_i32<0x141>(xl); xh += agt_dpp_i32<0x141>(xh);
+            xl += agt_dpp_i32<0x140>(xl); xh += agt_dpp_i32<0x140>(xh);
+            if ((lane & 15) == 0) {
+                __attribute__((address_space(3))) int* q = (__attribute__((address_space(3))) int*)(acc + 4 * p + ((lane >> 5) << 1));
+                __hip_atomic_fetch_add(q, xl, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                __hip_atomic_fetch_add(q + 1, xh, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+        block_sync<NW>();
+        const int4 r0 = *reinterpret_cast<const int4*>(acc);
+        out[0] = (long long)r0.y * 65536 + r0.x;
+        if constexpr (NV > 1) out[1] = (long long)r0.w * 65536 + r0.z;
+        if constexpr (NV > 2) { const int2 r1 = *reinterpret_cast<const int2*>(acc + 4); out[2] = (long long)r1.y * 65536 + r1.x; }
+        const int nz = phase == 0 ? 2 : phase - 1;                 // (phase + 2) % 3
+        if (threadIdx.x == 0) {
+            *reinterpret_cast<int4*>(reinterpret_cast<int*>(slots) + nz * 8) = make_int4(0, 0, 0, 0);
+            *reinterpret_cast<int4*>(reinterpret_cast<int*>(slots) + nz * 8 + 4) = make_int4(0, 0, 0, 0);
+        }
+        phase = phase == 2 ? 0 : phase + 1;
+        return;
+    }
     if constexpr ((NV == 2 || NV == 3) && PAIR_OK) {
         // two sums in one chain: v_permlane32_swap leaves { v0 of lanes 0-31 | v1 of lanes 0-31 } and { v0 of lanes
         // 32-63 | v1 of lanes 32-63 } side by side, so one add gives pair sums of v0 in the lower half-wave and of v1
@@ -291,6 +329,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     int phase = 0;
 
     const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;   // thread index within the corner
+    if (NW == 4 && tid < 24) reinterpret_cast<int*>(slots)[tid] = 0;       // block_sum_exact's accumulators (a barrier precedes the first sum)
     const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
     const long pidx = (long)b * P->n + pt;
 

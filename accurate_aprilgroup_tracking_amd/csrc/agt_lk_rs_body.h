@@ -167,6 +167,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     const float FLT_SCALE = 1.f / (1 << 20);
     const float eps2_lo = (float)(P->eps2 * (1.0 - 1e-6)), eps2_hi = (float)(P->eps2 * (1.0 + 1e-6));
     long long* slots = reinterpret_cast<long long*>(lds + (P->max_level + 1) * C::LEVEL_LDS + ((C::DW * C::DW + 3) & ~3) * sizeof(int));
+    if (NW == 4 && tid < 24) reinterpret_cast<int*>(slots)[tid] = 0;       // block_sum_exact's accumulators (a barrier precedes the first sum)
     int phase = 0;
 
     float outx = 0.f, outy = 0.f;
