@@ -51,7 +51,6 @@ struct DenseParams {
 };
 
 struct DenseShared {
-    double part[4][DN * 65];
     double wtot[4][DROW];
     double rows8[8][DROW];             // update prologue: partial sums of the previous iteration's rows
     double tot[2][DROW];
@@ -66,16 +65,17 @@ __device__ __forceinline__ void dense_update(const DenseParams& P, DenseShared& 
 {
     const int lane = threadIdx.x & 63;
     {
-        // 16 independent loads in flight per thread (a rolled loop issues them one L2 round trip at a time: 7 us at 240 rows),
-        // summed in row order: the result does not depend on timing
+        // every row load of the thread in flight at once (a rolled loop issues them one L2 round trip at a time: 7 us at 240
+        // rows; round 2's 16 per trip still needed two trips for the 240 rows of BASELINE configs[4]), summed in row order: the
+        // result does not depend on timing
         const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
         double s = 0.0;
-        for (int j0 = g; j0 < P.nblk; j0 += 128) {
-            double v[16];
+        for (int j0 = g; j0 < P.nblk; j0 += 256) {
+            double v[32];
 #pragma unroll
-            for (int u = 0; u < 16; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
+            for (int u = 0; u < 32; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
 #pragma unroll
-            for (int u = 0; u < 16; u++) s += v[u];
+            for (int u = 0; u < 32; u++) s += v[u];
         }
         sh.rows8[g][k] = s;
     }
@@ -227,20 +227,24 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
             acc[28] += 1.0;
         }
     }
-    // wave: transposed slab (two lanes per sum, 32 adds each); block: four wave rows
-    double* slab = sh.part[wave];
+    // wave: register butterfly of the 29 sums (the PnP kernel's: two permlane-swap stages, three DPP stages; lane l ends up
+    // with the total of value l >> 1) -- round 2 went through a transposed LDS slab (29 stores + 32 dependent load / adds per
+    // lane: ~1 us of every launch); block: four wave rows
+    {
+        using namespace agt_pnp;
+        double v[32];
 #pragma unroll
-    for (int k = 0; k < DN; k++) slab[k * 65 + lane] = acc[k];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    const int k = lane & 31, hh = lane >> 5;
-    double sum = 0.0;
-    if (k < DN) {
-        const double* q = slab + k * 65 + 32 * hh;
-#pragma unroll 8
-        for (int j = 0; j < 32; j++) sum += q[j];
+        for (int i = 0; i < 32; i++) v[i] = i < DN ? acc[i] : 0.0;
+#pragma unroll
+        for (int i = 0; i < 16; i++) { double b2; const double a2 = dswap32(v[i], v[i + 16], b2); v[i] = a2 + b2; }
+#pragma unroll
+        for (int i = 0; i < 8; i++) { double b2; const double a2 = dswap16(v[i], v[i + 8], b2); v[i] = a2 + b2; }
+        bfly_stage<0x140, 4>(v, (lane & 8) != 0);
+        bfly_stage<0x141, 2>(v, (lane & 4) != 0);
+        bfly_stage<0x1B, 1>(v, (lane & 2) != 0);
+        const double tot = v[0] + ddpp<0xB1>(v[0]);
+        if (!(lane & 1) && (lane >> 1) < DN) sh.wtot[wave][lane >> 1] = tot;
     }
-    sum += __shfl_xor(sum, 32);
-    if (lane < DN) sh.wtot[wave][lane] = sum;
     __syncthreads();
     if (tid < DROW) {
         const double t = tid < DN ? ((sh.wtot[0][tid] + sh.wtot[1][tid]) + (sh.wtot[2][tid] + sh.wtot[3][tid])) : 0.0;
