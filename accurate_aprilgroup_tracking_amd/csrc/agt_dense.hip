@@ -53,22 +53,28 @@ struct DenseParams {
 struct DenseShared {
     double wtot[4][DROW];
     double rows8[8][DROW];             // update prologue: partial sums of the previous iteration's rows
-    double tot[2][DROW];
-    double pose[8];                    // [0..5] linearisation point of this launch, [6] = 1: stop (converged / singular)
+    double geo[DROW];                  // ... and its corner (geometric) row
+    double totw[4][2 * DROW];          // per wave: totals of the photometric rows | the corner row
 };
 
 // The Gauss-Newton update of iteration P.iter - 1 from its block rows: called by all 256 threads of a block; on return
-// sh.pose[0..5] holds the new pose and sh.pose[6] != 0 means "stop" -- the same bits in every block.  `publish`: this
-// block also writes pose / statistics / record / done word to global memory.
-__device__ __forceinline__ void dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
-                                             double* pose_out, bool publish, int iter_done)
+// pose_new[0..5] holds the new pose in EVERY thread and the return value says "stop" -- the same bits in every thread of every
+// block.  `publish`: this block also writes pose / statistics / record / done word to global memory.
+// One global round trip: the block rows, the corner row and the previous pose are all requested up front; after the one
+// barrier every wave reduces and solves for itself (redundantly: no second barrier, no LDS hand-over of the result).
+__device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
+                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6])
 {
-    const int lane = threadIdx.x & 63;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    double param[6];
+#pragma unroll
+    for (int q = 0; q < 6; q++) param[q] = pose_in[q];
+    const double geo = (g == 0 && P.N > 0) ? rows[(long)P.nblk * DROW + k] : 0.0;
     {
         // every row load of the thread in flight at once (a rolled loop issues them one L2 round trip at a time: 7 us at 240
         // rows; round 2's 16 per trip still needed two trips for the 240 rows of BASELINE configs[4]), summed in row order: the
         // result does not depend on timing
-        const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
         double s = 0.0;
         for (int j0 = g; j0 < P.nblk; j0 += 256) {
             double v[32];
@@ -78,57 +84,52 @@ __device__ __forceinline__ void dense_update(const DenseParams& P, DenseShared& 
             for (int u = 0; u < 32; u++) s += v[u];
         }
         sh.rows8[g][k] = s;
+        if (g == 0) sh.geo[k] = geo;
     }
     __syncthreads();
-    if (threadIdx.x < AGT_WAVE) {
-        if (lane < DROW) {
-            sh.tot[0][lane] = ((sh.rows8[0][lane] + sh.rows8[1][lane]) + (sh.rows8[2][lane] + sh.rows8[3][lane])) +
-                              ((sh.rows8[4][lane] + sh.rows8[5][lane]) + (sh.rows8[6][lane] + sh.rows8[7][lane]));
-            sh.tot[1][lane] = P.N > 0 ? rows[(long)P.nblk * DROW + lane] : 0.0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        double param[6];
+    // per wave: lanes 0..31 total the eight group rows, lanes 32..63 fetch the corner row; the wave's own copy in LDS, then
+    // every lane reads what it needs (broadcast reads)
+    double* tw = sh.totw[wave];
+    if (lane < DROW)
+        tw[lane] = ((sh.rows8[0][lane] + sh.rows8[1][lane]) + (sh.rows8[2][lane] + sh.rows8[3][lane])) +
+                   ((sh.rows8[4][lane] + sh.rows8[5][lane]) + (sh.rows8[6][lane] + sh.rows8[7][lane]));
+    else tw[lane] = sh.geo[lane - DROW];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    double A[36], gv[6], dx[6];
+    int idx = 0;
 #pragma unroll
-        for (int k = 0; k < 6; k++) param[k] = pose_in[k];
-        double A[36], g[6], dx[6];
-        int idx = 0;
+    for (int q = 0; q < 6; q++)
 #pragma unroll
-        for (int q = 0; q < 6; q++)
+        for (int c = q; c < 6; c++) { const double v = tw[DROW + idx] + tw[idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
 #pragma unroll
-            for (int c = q; c < 6; c++) { const double v = sh.tot[1][idx] + sh.tot[0][idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
+    for (int q = 0; q < 6; q++) { gv[q] = tw[DROW + 21 + q] + tw[21 + q]; A[q * 7] *= 1.0 + P.mu; }
+    const bool ok = agt_solve6(A, gv, dx);
+    double dn = 0.0, pn = 0.0;
 #pragma unroll
-        for (int q = 0; q < 6; q++) { g[q] = sh.tot[1][21 + q] + sh.tot[0][21 + q]; A[q * 7] *= 1.0 + P.mu; }
-        const bool ok = agt_solve6(A, g, dx);
-        double dn = 0.0, pn = 0.0;
+    for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
+    const bool stop = !ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
 #pragma unroll
-        for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
-        const bool stop = !ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
-        if (lane == 0) {
+    for (int q = 0; q < 6; q++) pose_new[q] = ok ? param[q] - dx[q] : param[q];
+    if (publish && threadIdx.x == 0) {
+        const double ph_r2 = tw[27], ph_n = tw[28], geo_r2 = tw[DROW + 27], n_used = tw[DROW + 28];
+        double* st = P.stats + (long)b * P.stats_stride;
+        st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
+        st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
+        st[2] = ph_n; st[3] = (double)iter_done; st[4] = n_used;
+        if (!P.rec) st[5] = st[6] = st[7] = 0.0;
+        if (ok) {
 #pragma unroll
-            for (int q = 0; q < 6; q++) sh.pose[q] = ok ? param[q] - dx[q] : param[q];
-            sh.pose[6] = stop ? 1.0 : 0.0;
-            if (publish) {
-                const double ph_r2 = sh.tot[0][27], ph_n = sh.tot[0][28], geo_r2 = sh.tot[1][27], n_used = sh.tot[1][28];
-                double* st = P.stats + (long)b * P.stats_stride;
-                st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
-                st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
-                st[2] = ph_n; st[3] = (double)iter_done; st[4] = n_used;
-                if (!P.rec) st[5] = st[6] = st[7] = 0.0;
-                if (ok) {
+            for (int q = 0; q < 6; q++) { P.pose[(long)b * 6 + q] = pose_new[q]; if (pose_out) pose_out[q] = pose_new[q]; }
+            if (P.rec) {
+                double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
 #pragma unroll
-                    for (int q = 0; q < 6; q++) { P.pose[(long)b * 6 + q] = param[q] - dx[q]; if (pose_out) pose_out[q] = param[q] - dx[q]; }
-                    if (P.rec) {
-                        double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
-#pragma unroll
-                        for (int q = 0; q < 6; q++) rc[q] = param[q] - dx[q];
-                        rc[AGT_DN_REFINED] = 1.0;
-                    }
-                }
-                if (stop) P.done[b] = 1;
+                for (int q = 0; q < 6; q++) rc[q] = pose_new[q];
+                rc[AGT_DN_REFINED] = 1.0;
             }
         }
+        if (stop) P.done[b] = 1;
     }
-    __syncthreads();
+    return stop;
 }
 
 __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
@@ -148,10 +149,7 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
         // (launch 0 copies the caller's start pose there: P.pose itself is overwritten by the publishing block)
         const double* pose_prev = P.ppose + ((long)(par ^ 1) * gridDim.y + b) * 8;
         double* pose_pub = blockIdx.x == 0 ? P.ppose + ((long)par * gridDim.y + b) * 8 : nullptr;
-        dense_update(P, sh, b, rows_prev, pose_prev, pose_pub, blockIdx.x == 0, P.iter);
-        if (sh.pose[6] != 0.0) return;
-#pragma unroll
-        for (int k = 0; k < 6; k++) param[k] = sh.pose[k];
+        if (dense_update(P, sh, b, rows_prev, pose_prev, pose_pub, blockIdx.x == 0, P.iter, param)) return;
     } else {
 #pragma unroll
         for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
@@ -261,9 +259,12 @@ __global__ __launch_bounds__(256) void dense_final_kernel(const DenseParams P)
     DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
     const int b = blockIdx.x;
     const int par = (P.iter - 1) & 1;                 // P.iter = iterations launched
-    if (!P.done[b] && P.iter > 0)
+    if (!P.done[b] && P.iter > 0) {
+        double fin[6];
         dense_update(P, sh, b, P.partials + (long)par * P.pstride + (long)b * (P.nblk + 1) * DROW, P.ppose + ((long)par * gridDim.x + b) * 8,
-                     nullptr, true, P.iter);
+                     nullptr, true, P.iter, fin);
+        __syncthreads();                                  // thread 0 wrote the record the re-seed below reads
+    }
     if (!P.seed_pts || !P.rec) return;
     const double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
     if (rc[AGT_DN_REFINED] == 0.0) return;
