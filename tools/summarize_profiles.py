@@ -32,6 +32,9 @@ def full_grid(b, v):
         g = (48 * B + B + 60 * B * F) * 256
         if any(x[1] == g for x in v):
             return g
+        g = (48 * B + B) * 256          # a block of F frames: the pyramid goes out as its own launch, the chained launch carries LK | PnP only
+        if sum(1 for x in v if x[1] == g) >= 2 and F == (b or {}).get("steps"):
+            return g
     tot = defaultdict(float)
     for x in v: tot[x[1]] += x[0]
     return max(tot, key=tot.get)
@@ -113,11 +116,12 @@ def raw_entry(run, prefix, name, label, alg=None):
             traffic[name] = {"workload": label, "kernel": k, "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": e["FETCH_SIZE_KiB_mean"],
                              "WRITE_SIZE_KiB_mean": e["WRITE_SIZE_KiB_mean"],
                              "traffic_bytes_per_launch": int(round((2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024)),
-                             "algorithmic_bytes_per_launch": alg, "build": PFX, "launch_us_at_collection": us,
+                             "algorithmic_bytes_per_launch": alg, "build": PFX, "kernel_trace_mean_us": us, "launch_us_at_collection": None,
                              "note": "mean over every dispatch of the kernel in the run; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"}
             return
 raw_entry("c5", "dense_accum_kernel", "dense_accum_kernel", "c5: 61,440 samples + 240 corners, one Gauss-Newton launch (update prologue + accumulate)", 61440 * 28)
-raw_entry("c3pairs", "pyr_down_kernel", "pyr_down_kernel c3pairs", "c3pairs: pyr_down over 64 cold 720p frames, mean of the L0->L1 and L1->L2 launches", None)
+raw_entry("c3pairs", "pyr_down_kernel", "pyr_down_kernel c3pairs", "c3pairs: pyr_down over 64 cold 720p frames, mean of the L0->L1 and L1->L2 launches",
+          int((64 * (921600 + 230400) + 64 * (230400 + 57600)) / 2))
 raw_entry("c3pairs", "lk_kernel<21, 1, 3", "lk_kernel<21,1,3> c3pairs", "c3pairs: 3072 corners, one wave per corner", 64 * (48 * 3 * 1600 + 48 * 21))
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({r: {k: v for k, v in d["kernels"].items()} for r, d in durations.items()}, indent=1)[:6000])
