@@ -291,7 +291,9 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
             needJ |= (a && !((jmask >> l) & 1)) ? 1 << l : 0;
         }
         }
+        CSTAMP(7);
         CCOUNT(0, 1); CCOUNT(1, needI != 0); CCOUNT(2, needJ != 0);
+        CSTAMP(15);
         if (agt_uniform(needI | needJ)) {
             uint32_t ti[NLEV][C::JLD], tj[NLEV][C::JLD];
 #pragma unroll

@@ -24,6 +24,7 @@ for k in range(4):
     s = [st[k * 16 + i] for i in range(16)]
     f = lambda i: (s[i] - s[0]) / (GHZ * 1e3)
     it = s[14]
+    print("   geometry done %.2f, counters done %.2f" % (f(7), f(15)))
     print("frame %d (us at %.2f GHz): loads issued %.2f, tiles ready %.2f, scharr %.2f, patch+sums %.2f | L2 %.2f..%.2f (%d it) L1 %.2f..%.2f (%d it) L0 %.2f..%.2f (%d it) | published %.2f, end %.2f"
           % (k, GHZ, f(1) if s[1] > s[0] else 0.0, f(2), f(3), f(4), f(12), f(13), (it >> 16) & 255, f(10), f(11), (it >> 8) & 255, f(8), f(9), it & 255, f(5), f(6)))
     if k: print("   frame start %.2f us after the previous frame's start" % ((s[0] - prev0) / (GHZ * 1e3)))
