@@ -97,19 +97,23 @@ __device__ __forceinline__ void wave_sum2_i32(int v0, int v1, int& t0, int& t1)
     t1 = __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
 }
 
-// The two mismatch sums of one iteration over the four waves, as the floats the 2 x 2 solve needs.  Exact: every operand is
-// split v = 65536 * hi + lo (|v| < 2^26 per thread), the hi and lo parts are summed separately in int32 (|sum hi| < 2^18,
-// sum lo < 2^24 over 256 threads), and fmaf(hi, 65536, lo) rounds the exact total once -- the same float as
+// The two mismatch sums of one iteration over the four waves, as the floats the 2 x 2 solve needs.  Exact: the partial sums are
+// split x = 65536 * hi + lo before they could leave int32, the hi and lo parts are accumulated separately (|sum hi| < 2^18,
+// sum lo < 2^20 over the workgroup), and fmaf(hi, 65536, lo) rounds the exact total once -- the same float as
 // (float)(double)(int64 total) in block_sum_exact's caller.  v_permlane32_swap puts both sums in one DPP chain (value 0 in
 // the lower half-wave, value 1 in the upper one).
 __device__ __forceinline__ void iter_sum2(const int (&v)[2], float& f0, float& f1, int* slots, int& phase, int wave, int lane)
 {
-    const auto swl = __builtin_amdgcn_permlane32_swap((unsigned)(v[0] & 0xffff), (unsigned)(v[1] & 0xffff), false, false);
-    const auto swh = __builtin_amdgcn_permlane32_swap((unsigned)(v[0] >> 16), (unsigned)(v[1] >> 16), false, false);
-    int xl = (int)swl[0] + (int)swl[1], xh = (int)swh[0] + (int)swh[1];
-    xl += agt_dpp_i32<0xB1>(xl); xh += agt_dpp_i32<0xB1>(xh);
-    xl += agt_dpp_i32<0x4E>(xl); xh += agt_dpp_i32<0x4E>(xh);
-    xl += agt_dpp_i32<0x141>(xl); xh += agt_dpp_i32<0x141>(xh);
+    // |v| < 2^26 per thread: the pair sum across the half-waves (2^27) and three DPP steps (x 8: < 2^30) still fit int32, so the
+    // values travel whole that far (value 0 in the lower half-wave, value 1 in the upper one) and are split into 16-bit halves
+    // only for the last DPP step and the cross-wave accumulation (lo < 2^20, |hi| < 2^18 over the workgroup) -- 11 instructions
+    // instead of the 18 of two full half-chains
+    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v[0], (unsigned)v[1], false, false);
+    int x = (int)sw[0] + (int)sw[1];
+    x += agt_dpp_i32<0xB1>(x);
+    x += agt_dpp_i32<0x4E>(x);
+    x += agt_dpp_i32<0x141>(x);
+    int xl = x & 0xffff, xh = x >> 16;
     xl += agt_dpp_i32<0x140>(xl); xh += agt_dpp_i32<0x140>(xh);
     // After the four DPP steps every lane of a 16-lane row holds its row's sum; rows 0 / 1 belong to value 0, rows 2 / 3 to value 1
     // (the swap).  The first lane of each row adds its row sum straight into the workgroup's accumulator with an LDS atomic
