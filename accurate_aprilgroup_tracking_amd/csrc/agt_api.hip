@@ -442,6 +442,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
 {
     if (!c || !d_obj || slot < 0 || slot > 1) return AGT_ERR_ARG;
     if (n < 4 || n > c->cfg.max_points) return AGT_ERR_NPOINTS;
+    if (c->tag_gate && n % c->tag_gate) return AGT_ERR_NPOINTS;      // whole tags: corners 4t .. 4t + 3
     if (B <= 0 || B > c->cfg.max_streams) return AGT_ERR_ARG;
     if (d_corners && c->built_B[slot] < B) return AGT_ERR_STATE;
     int rc = join_pipeline(c);            // frames of an earlier run still in flight (fused pipeline or library streams)
@@ -487,6 +488,7 @@ int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_p
 int agt_tracker_tag_gate(agt_ctx* c, int corners_per_tag)
 {
     if (!c || (corners_per_tag != 0 && corners_per_tag != 4)) return AGT_ERR_ARG;
+    if (corners_per_tag && c->trk_ready && c->trk_n % corners_per_tag) return AGT_ERR_NPOINTS;
     int rc = join_pipeline(c);
     if (rc) return rc;
     c->tag_gate = corners_per_tag;

@@ -258,6 +258,12 @@ def test_track_frame_argument_and_state_errors(torch_cuda):
     trk.reset()
     with pytest.raises(H.AgtError):
         trk.step(f)                                   # reset without corners: only estimate_pose allowed
+    # the tag gate wants whole tags: a corner count that is not a multiple of four is refused
+    trk46 = StreamTracker(640, 480, obj[:46], np.array([[500.0, 0, 320], [0, 500, 240], [0, 0, 1]]), None, n_streams=1)
+    trk46.reset()
+    with pytest.raises(H.AgtError):
+        trk46.tag_gate(4)
+    trk.tag_gate(4); trk.tag_gate(0)
     # fewer than two tags' worth of corners -> guess cleared, no pose
     so = trk.new_state_buffer()
     m = torch.zeros((1, 48), dtype=torch.uint8, device="cuda"); m[0, :4] = 1
