@@ -86,6 +86,13 @@ __device__ __forceinline__ double agt_rcp(double x)
     e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, e, r);
 }
+// 1 / x with ONE Newton step on the hardware estimate (relative error ~2^-50): the pivots of the damped normal equations,
+// where six of these sit in series on the chain of every LM step
+__device__ __forceinline__ double agt_rcp1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
 __device__ __forceinline__ double agt_sqrtp(double x)
 {
     if (x == 0.0) return 0.0;
@@ -405,7 +412,7 @@ __device__ __forceinline__ bool agt_solve6(const double A[36], const double b[6]
         for (int k = 0; k < j; k++) d -= L[j][k] * L[j][k] * D[k];
         if (!(d > 0.0)) ok = false;
         D[j] = d;
-        double id = agt_rcp(d);           // (d > 0 checked above; a non-positive pivot already reports failure)
+        double id = agt_rcp1(d);          // (d > 0 checked above; a non-positive pivot already reports failure)
         iD[j] = id;
 #pragma unroll
         for (int i = j + 1; i < 6; i++) {
