@@ -39,6 +39,63 @@ def test_oracle_preproc_self_checks(oracle):
     assert roi0[2] >= 638 and roi0[3] >= 478
 
 
+def _numpy_undistort_maps(K, dist, newK, w, h):
+    """cv::initUndistortRectifyMap(K, dist, I, newK, (w, h), CV_16SC2), vectorised (written from OpenCV's documented model:
+    inverse new camera matrix -> normalised point -> Brown-Conrady + thin prism -> pixel -> 1/32-pixel fixed point)"""
+    k = np.zeros(14)
+    if dist is not None:
+        d = np.asarray(dist, np.float64).reshape(-1); k[:d.size] = d
+    ir = np.linalg.inv(np.asarray(newK, np.float64))
+    j, i = np.meshgrid(np.arange(w, dtype=np.float64), np.arange(h, dtype=np.float64))
+    _x = j * ir[0, 0] + (i * ir[0, 1] + ir[0, 2]); _y = j * ir[1, 0] + (i * ir[1, 1] + ir[1, 2]); _w = j * ir[2, 0] + (i * ir[2, 1] + ir[2, 2])
+    x, y = _x * (1.0 / _w), _y * (1.0 / _w)
+    x2, y2 = x * x, y * y
+    r2, _2xy = x2 + y2, 2 * x * y
+    kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
+    xd = x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2
+    yd = y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy + k[10] * r2 + k[11] * r2 * r2
+    iu = np.rint((K[0, 0] * xd + K[0, 2]) * 32).astype(np.int64); iv = np.rint((K[1, 1] * yd + K[1, 2]) * 32).astype(np.int64)
+    m1 = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
+    m2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
+    return m1, m2
+
+
+def _numpy_remap(src, m1, m2):
+    """cv::remap(INTER_LINEAR, BORDER_CONSTANT 0) with CV_16SC2 maps on 8-bit images: 15-bit weights from the 5-bit fractions"""
+    h, w = src.shape[:2]
+    sx, sy = m1[..., 0].astype(np.int64), m1[..., 1].astype(np.int64)
+    fx, fy = (m2 & 31).astype(np.int64), (m2 >> 5).astype(np.int64)
+    pad = np.zeros((h + 2, w + 2) + src.shape[2:], np.int64); pad[1:-1, 1:-1] = src
+
+    def tap(dy, dx):
+        yy, xx = sy + dy, sx + dx
+        ok = (yy >= 0) & (yy < h) & (xx >= 0) & (xx < w)
+        v = pad[np.clip(yy, -1, h) + 1, np.clip(xx, -1, w) + 1]
+        return np.where(ok[..., None] if src.ndim == 3 else ok, v, 0)
+    ws = [(32 - fx) * (32 - fy) * 32, fx * (32 - fy) * 32, (32 - fx) * fy * 32, fx * fy * 32]
+    if src.ndim == 3:
+        ws = [x[..., None] for x in ws]
+    acc = tap(0, 0) * ws[0] + tap(0, 1) * ws[1] + tap(1, 0) * ws[2] + tap(1, 1) * ws[3]
+    return ((acc + (1 << 14)) >> 15).astype(np.uint8)
+
+
+def test_oracle_maps_and_remap_equal_numpy_statement(oracle):
+    """the oracle's initUndistortRectifyMap and remap (cv.undistort) against a vectorised numpy statement, BIT-EXACT: maps for
+    three distortion models (incl. strong pincushion whose map leaves the source image) and the remapped BGR / gray frames"""
+    for (w, h), seed in (((333, 201), 2), ((640, 480), 3)):
+        K = syn.camera_matrix(w, h)
+        K[0, 2] += 2.3; K[1, 2] -= 1.1
+        img = _bgr(h, w, seed)
+        for dist in DISTS[:3] + [np.array([[0.4, 0.3, 0.01, -0.02, 0.1]]), np.array([[0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3]])]:
+            newK, _ = oracle.getOptimalNewCameraMatrix(K, dist, (w, h), 1, (w, h))
+            for nk in (newK, K):
+                m1, m2 = oracle.initUndistortRectifyMap(K, dist, nk, (w, h))
+                n1, n2 = _numpy_undistort_maps(K, dist, nk, w, h)
+                assert np.array_equal(m1, n1) and np.array_equal(m2, n2)
+                assert np.array_equal(oracle.undistort(img, K, dist, None, nk), _numpy_remap(img, n1, n2))
+                assert np.array_equal(oracle.undistort(img[..., 1].copy(), K, dist, None, nk), _numpy_remap(img[..., 1], n1, n2))
+
+
 @pytest.mark.parametrize("alpha", [0.0, 0.35, 1.0])
 def test_host_get_optimal_new_camera_matrix_matches_oracle(oracle, alpha):
     from accurate_aprilgroup_tracking_amd import cv_hip
