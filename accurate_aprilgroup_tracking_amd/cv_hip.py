@@ -115,11 +115,8 @@ class Context:
         H.check(self.L.agt_pyramid_level(self.h, slot, level, C.byref(p), C.byref(w), C.byref(h), C.byref(pitch), C.byref(bs)),
                 "agt_pyramid_level")
         B = self._keep[slot].shape[0]
-        self.synchronize()
-        raw = torch.empty(((B - 1) * bs.value + h.value * pitch.value,), dtype=torch.uint8, device="cuda")
-        hip = C.CDLL("libamdhip64.so")
-        assert hip.hipMemcpy(C.c_void_p(raw.data_ptr()), p, C.c_size_t(raw.numel()), 3) == 0
-        raw = raw.cpu().numpy()
+        raw = np.empty(((B - 1) * bs.value + h.value * pitch.value,), np.uint8)
+        H.check(self.L.agt_download(self.h, raw.ctypes.data_as(C.c_void_p), p, raw.size), "agt_download")     # (waits for the stream)
         return np.stack([np.lib.stride_tricks.as_strided(raw[b * bs.value:], (h.value, w.value), (pitch.value, 1)).copy() for b in range(B)])
 
     # ---- frame pre-processing (detect_pose.py:147-183, :602)
@@ -136,14 +133,11 @@ class Context:
         """(map1 [h,w,2] int16, map2 [h,w] uint16) copied to the host (tests)"""
         p1, p2, w, h = C.c_void_p(), C.c_void_p(), C.c_int(), C.c_int()
         H.check(self.L.agt_undistort_maps(self.h, C.byref(p1), C.byref(p2), C.byref(w), C.byref(h)), "agt_undistort_maps")
-        m1 = torch.empty((h.value, w.value, 2), dtype=torch.int16, device="cuda")
-        m2 = torch.empty((h.value, w.value), dtype=torch.int16, device="cuda")
-        import ctypes
-        hip = ctypes.CDLL("libamdhip64.so")
-        torch.cuda.synchronize()
-        assert hip.hipMemcpy(C.c_void_p(m1.data_ptr()), p1, m1.numel() * 2, 3) == 0
-        assert hip.hipMemcpy(C.c_void_p(m2.data_ptr()), p2, m2.numel() * 2, 3) == 0
-        return m1.cpu().numpy(), m2.cpu().numpy().view(np.uint16)
+        m1 = np.empty((h.value, w.value, 2), np.int16)
+        m2 = np.empty((h.value, w.value), np.uint16)
+        H.check(self.L.agt_download(self.h, m1.ctypes.data_as(C.c_void_p), p1, m1.nbytes), "agt_download")
+        H.check(self.L.agt_download(self.h, m2.ctypes.data_as(C.c_void_p), p2, m2.nbytes), "agt_download")
+        return m1, m2
 
     def undistort_bgr(self, frames):
         """cv.undistort on cuda uint8 [B,H,W,3] -> same shape"""

@@ -534,9 +534,8 @@ def test_lost_corner_stays_lost(torch_cuda, oracle, seq640):
         cp, sp = trk.corners()
         torch.cuda.synchronize()
         got_c = np.zeros((48, 2), np.float32); got_s = np.zeros(48, np.uint8)
-        hip = C.CDLL("libamdhip64.so")
-        assert hip.hipMemcpy(got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes, 2) == 0
-        assert hip.hipMemcpy(got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes, 2) == 0
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes), "agt_download")
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes), "agt_download")
         assert np.array_equal(got_s.astype(bool), ref_status[-1])
         assert np.array_equal(got_c.view(np.uint32), ref_pts[-1].astype(np.float32).view(np.uint32))
         ok = ref_status[-1]
@@ -597,9 +596,8 @@ def test_chained_lk_role_big_motion_and_image_border(torch_cuda, oracle, seq640)
         cp, sp = trk.corners()
         torch.cuda.synchronize()
         got_c = np.zeros((len(c0), 2), np.float32); got_s = np.zeros(len(c0), np.uint8)
-        hip = C.CDLL("libamdhip64.so")
-        assert hip.hipMemcpy(got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes, 2) == 0
-        assert hip.hipMemcpy(got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes, 2) == 0
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, got_c.ctypes.data_as(C.c_void_p), C.c_void_p(cp), got_c.nbytes), "agt_download")
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, got_s.ctypes.data_as(C.c_void_p), C.c_void_p(sp), got_s.nbytes), "agt_download")
         assert np.array_equal(got_s.astype(bool), alive), "depth %d" % depth
         assert np.array_equal(got_c.view(np.uint32), pts.view(np.uint32)), "depth %d" % depth
         assert not (outs[-1][:, :, H.ST_FLAGS].astype(int) & H.TRK_CHAIN_TIMEOUT).any()
