@@ -1308,14 +1308,12 @@ int agt_profile_end(agt_ctx* c, float* ms_out, int* n_frames)
                 e = hipEventElapsedTime(&ms_out[f * AGT_PROF_SPANS + k], ev[k], ev[k + 1]);
                 if (e != hipSuccess) { rc = hip_fail(c, e); break; }
             }
-            // dense stage: ev[3] = its start, ev[4 + 2 i] after accumulate launch i, ev[5 + 2 i] after update launch i
+            // dense stage: ev[3] = its start, ev[4] after the last Gauss-Newton launch, ev[5] after the final launch
             float acc = 0.f, upd = 0.f;
-            for (int i = 0; i < c->prof_dense[f] && rc == AGT_OK; i++) {
-                float a = 0.f, u = 0.f;
-                e = hipEventElapsedTime(&a, ev[3 + 2 * i], ev[4 + 2 * i]);
-                if (e == hipSuccess) e = hipEventElapsedTime(&u, ev[4 + 2 * i], ev[5 + 2 * i]);
+            if (c->prof_dense[f] > 0 && rc == AGT_OK) {
+                e = hipEventElapsedTime(&acc, ev[3], ev[4]);
+                if (e == hipSuccess) e = hipEventElapsedTime(&upd, ev[4], ev[5]);
                 if (e != hipSuccess) { rc = hip_fail(c, e); break; }
-                acc += a; upd += u;
             }
             ms_out[f * AGT_PROF_SPANS + 3] = acc; ms_out[f * AGT_PROF_SPANS + 4] = upd;
         }

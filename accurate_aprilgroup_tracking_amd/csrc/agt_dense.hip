@@ -24,6 +24,18 @@
 #undef AGT_PNP_STAMPS
 #include "agt_pnp_body.h"
 
+// In-kernel cycle stamps of one accumulate launch (diagnostic builds only: make dbg): block 1 of stream 0, iteration >= 1
+#ifdef AGT_DENSE_STAMPS
+__device__ unsigned long long agt_dense_stamps[16];
+#define DSTAMP(i) do { if (blockIdx.x == 1 && blockIdx.y == 0 && threadIdx.x == 0 && P.iter == 2) agt_dense_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int agt_debug_dense_stamps(unsigned long long* host16)
+{
+    return (int)hipMemcpyFromSymbol(host16, HIP_SYMBOL(agt_dense_stamps), sizeof(agt_dense_stamps));
+}
+#else
+#define DSTAMP(i)
+#endif
+
 #pragma clang fp contract(fast)      // FP64 pose code only, see agt_device.h
 
 namespace {
@@ -62,11 +74,14 @@ struct DenseShared {
 // block.  `publish`: this block also writes pose / statistics / record / done word to global memory.
 // One global round trip: the block rows, the corner row and the previous pose are all requested up front; after the one
 // barrier every wave reduces and solves for itself (redundantly: no second barrier, no LDS hand-over of the result).
+// done_word != null: the stream's done word is tested here, AFTER the loads have been requested (its round trip runs beside
+// theirs instead of in front); a set word returns "stop" before anything is written.
 __device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
-                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6])
+                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6], const int* done_word = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int done_v = done_word ? *done_word : 0;
     double param[6];
 #pragma unroll
     for (int q = 0; q < 6; q++) param[q] = pose_in[q];
@@ -80,13 +95,16 @@ __device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& 
             double v[32];
 #pragma unroll
             for (int u = 0; u < 32; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
+            if (done_v) return true;
 #pragma unroll
             for (int u = 0; u < 32; u++) s += v[u];
         }
+        DSTAMP(8);
         sh.rows8[g][k] = s;
         if (g == 0) sh.geo[k] = geo;
     }
     __syncthreads();
+    DSTAMP(9);
     // per wave: lanes 0..31 total the eight group rows, lanes 32..63 fetch the corner row; the wave's own copy in LDS, then
     // every lane reads what it needs (broadcast reads)
     double* tw = sh.totw[wave];
@@ -103,7 +121,9 @@ __device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& 
         for (int c = q; c < 6; c++) { const double v = tw[DROW + idx] + tw[idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
 #pragma unroll
     for (int q = 0; q < 6; q++) { gv[q] = tw[DROW + 21 + q] + tw[21 + q]; A[q * 7] *= 1.0 + P.mu; }
+    DSTAMP(10);
     const bool ok = agt_solve6(A, gv, dx);
+    DSTAMP(11);
     double dn = 0.0, pn = 0.0;
 #pragma unroll
     for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
@@ -137,11 +157,27 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
     const int b = blockIdx.y;
-    if (P.done[b]) return;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool geo = (int)blockIdx.x == P.nblk;        // the last block of a stream evaluates the corner (geometric) rows
     const int par = P.iter & 1;
+    // this thread's sample (or corner): requested before anything else, it does not depend on the pose -- the round trip runs
+    // beside those of the update prologue (done word, block rows) instead of behind its solve
+    DSTAMP(0);
+    const int smp = blockIdx.x * 256 + tid;
+    // (branch-free: behind a branch the compiler waits for the loads at the join.  Indices are clamped, pointers selected per block,
+    // a block without a mask reads a byte it ignores.)
+    const int si = smp < P.M ? smp : P.M - 1, ci = tid < P.N ? tid : (P.N > 0 ? P.N - 1 : 0);
+    const float* p3 = geo ? P.obj + ci * 3 : P.mxyz + (long)si * 3;
+    const float* p2 = geo ? P.ipts + ((long)b * P.N + ci) * 2 : P.mt + si;
+    const bool masked = geo && P.mask != nullptr;
+    const uint8_t* pm = masked ? P.mask + (long)b * P.N + ci : reinterpret_cast<const uint8_t*>(P.mt);
+    float sX = p3[0], sY = p3[1], sZ = p3[2];
+    const float f0 = p2[0], f1 = p2[geo ? 1 : 0];
+    const uint8_t mb = *pm;
+    float sT = f0, cu = f0, cv = f1;
+    bool c_on = geo && tid < P.N && (!masked || mb != 0);
     double param[6];
+    if (P.iter == 0 && P.done[b]) return;
     if (P.iter > 0) {
         // the update of iteration iter - 1, re-derived by every block (same rows, same order: same bits everywhere)
         const double* rows_prev = P.partials + (long)(par ^ 1) * P.pstride + (long)b * (P.nblk + 1) * DROW;
@@ -149,12 +185,13 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
         // (launch 0 copies the caller's start pose there: P.pose itself is overwritten by the publishing block)
         const double* pose_prev = P.ppose + ((long)(par ^ 1) * gridDim.y + b) * 8;
         double* pose_pub = blockIdx.x == 0 ? P.ppose + ((long)par * gridDim.y + b) * 8 : nullptr;
-        if (dense_update(P, sh, b, rows_prev, pose_prev, pose_pub, blockIdx.x == 0, P.iter, param)) return;
+        if (dense_update(P, sh, b, rows_prev, pose_prev, pose_pub, blockIdx.x == 0, P.iter, param, P.done + b)) return;
     } else {
 #pragma unroll
         for (int k = 0; k < 6; k++) param[k] = P.pose[(long)b * 6 + k];
         if (blockIdx.x == 0 && tid < 6) P.ppose[((long)par * gridDim.y + b) * 8 + tid] = param[tid];
     }
+    DSTAMP(1);
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
     bool has_dist = false;
@@ -162,18 +199,19 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     for (int k = 0; k < 12; k++) has_dist |= cam.k[k] != 0.0;
     double R[9], G[9];
     agt_rodrigues<true>(param, R, G);
+    DSTAMP(2);
     const double tvec[3] = { param[3], param[4], param[5] };      // (param + 3 as an argument kept three doubles in scratch: 1.5 MB of writes per launch)
 
     double acc[DN];
 #pragma unroll
     for (int k = 0; k < DN; k++) acc[k] = 0.0;
     if (!geo) {
-        const int i = blockIdx.x * 256 + tid;
-        if (i < P.M) {
-            const double X = (double)P.mxyz[(long)i * 3], Y = (double)P.mxyz[(long)i * 3 + 1], Z = (double)P.mxyz[(long)i * 3 + 2];
+        if (smp < P.M) {
+            const double X = (double)sX, Y = (double)sY, Z = (double)sZ;
             double u, v, jr[6], jt[6];
             if (has_dist) agt_project<true, true>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
             else agt_project<true, false>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
+            DSTAMP(3);
             const double fx0 = floor(u), fy0 = floor(v);
             if (fx0 >= 1.0 && fx0 <= (double)(P.w - 3) && fy0 >= 1.0 && fy0 <= (double)(P.h - 3)) {
                 const int x0 = (int)fx0, y0 = (int)fy0;
@@ -188,7 +226,8 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
                 const double I = w00 * p00 + w01 * p10 + w10 * p01 + w11 * p11;
                 const double gx = w00 * (p10 - pm0) * 0.5 + w01 * (p20 - p00) * 0.5 + w10 * (p11 - pm1) * 0.5 + w11 * (p21 - p01) * 0.5;
                 const double gy = w00 * (p01 - p0m) * 0.5 + w01 * (p11 - p1m) * 0.5 + w10 * (p02 - p00) * 0.5 + w11 * (p12 - p10) * 0.5;
-                const double r = I - (double)P.mt[i];
+                DSTAMP(4);
+                const double r = I - (double)sT;
                 const double J[6] = { gx * jr[0] + gy * jr[3], gx * jr[1] + gy * jr[4], gx * jr[2] + gy * jr[5],
                                       gx * jt[0] + gy * jt[3], gx * jt[1] + gy * jt[4], gx * jt[2] + gy * jt[5] };
                 int idx = 0;
@@ -206,12 +245,17 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
         // geometric rows, one corner per thread per trip (N <= 256: one trip); same row layout, unweighted,
         // [27] = sum of squared residuals, [28] = corners used
         for (int i = tid; i < P.N; i += 256) {
-            if (P.mask && !P.mask[(long)b * P.N + i]) continue;
+            if (i >= 256) {             // (second and later trips: N > 256)
+                c_on = !P.mask || P.mask[(long)b * P.N + i];
+                sX = P.obj[i * 3]; sY = P.obj[i * 3 + 1]; sZ = P.obj[i * 3 + 2];
+                cu = P.ipts[((long)b * P.N + i) * 2]; cv = P.ipts[((long)b * P.N + i) * 2 + 1];
+            }
+            if (!c_on) continue;
             double u, v, jr[6], jt[6];
-            const double X = (double)P.obj[i * 3], Y = (double)P.obj[i * 3 + 1], Z = (double)P.obj[i * 3 + 2];
+            const double X = (double)sX, Y = (double)sY, Z = (double)sZ;
             if (has_dist) agt_project<true, true>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
             else agt_project<true, false>(cam, R, G, tvec, X, Y, Z, u, v, jr, jt);
-            const double ex = u - (double)P.ipts[((long)b * P.N + i) * 2], ey = v - (double)P.ipts[((long)b * P.N + i) * 2 + 1];
+            const double ex = u - (double)cu, ey = v - (double)cv;
             const double Jx[6] = { jr[0], jr[1], jr[2], jt[0], jt[1], jt[2] };
             const double Jy[6] = { jr[3], jr[4], jr[5], jt[3], jt[4], jt[5] };
             int idx = 0;
@@ -228,6 +272,7 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     // wave: register butterfly of the 29 sums (the PnP kernel's: two permlane-swap stages, three DPP stages; lane l ends up
     // with the total of value l >> 1) -- round 2 went through a transposed LDS slab (29 stores + 32 dependent load / adds per
     // lane: ~1 us of every launch); block: four wave rows
+    DSTAMP(5);
     {
         using namespace agt_pnp;
         double v[32];
@@ -243,7 +288,9 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
         const double tot = v[0] + ddpp<0xB1>(v[0]);
         if (!(lane & 1) && (lane >> 1) < DN) sh.wtot[wave][lane >> 1] = tot;
     }
+    DSTAMP(6);
     __syncthreads();
+    DSTAMP(7);
     if (tid < DROW) {
         const double t = tid < DN ? ((sh.wtot[0][tid] + sh.wtot[1][tid]) + (sh.wtot[2][tid] + sh.wtot[3][tid])) : 0.0;
         P.partials[(long)par * P.pstride + ((long)b * (P.nblk + 1) + blockIdx.x) * DROW + tid] = t;
@@ -308,15 +355,14 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
         hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk + (N > 0 ? 1 : 0), B), dim3(256), sizeof(DenseShared), stream, P);
-        // profiling only: span "accumulate" i = launch i (which carries the update of iteration i - 1), span "update" = the final launch
-        if (ev && 2 * it < n_ev) (void)hipEventRecord(ev[2 * it], stream);
-        if (ev && 2 * it + 1 < n_ev && it + 1 < iters) (void)hipEventRecord(ev[2 * it + 1], stream);
+        // profiling only: ev[0] closes the Gauss-Newton launches (launch i carries the update of iteration i - 1), ev[1] the final launch
+        if (ev && n_ev >= 2 && it == iters - 1) (void)hipEventRecord(ev[0], stream);
         e = hipGetLastError();
     }
     if (e == hipSuccess) {
         P.iter = iters;
         hipLaunchKernelGGL(dense_final_kernel, dim3(B), dim3(256), sizeof(DenseShared), stream, P);
-        if (ev && iters > 0 && 2 * (iters - 1) + 1 < n_ev) (void)hipEventRecord(ev[2 * (iters - 1) + 1], stream);
+        if (ev && n_ev >= 2 && iters > 0) (void)hipEventRecord(ev[1], stream);
         e = hipGetLastError();
     }
     return e;

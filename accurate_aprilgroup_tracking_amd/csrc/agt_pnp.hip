@@ -13,6 +13,19 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
     agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh, P.img, P.mask, P.state_out);
 }
 
+// n > 64: four waves.  A solve that starts from a guess is shared by all of them (agt_pnp_body.h, COOP); one without (first
+// frame of a tracker, after a gate rejection, cv2-shaped calls without useExtrinsicGuess) is wave 0's, four points per lane.
+constexpr int COOP_WAVES = agt_pnp::MAX_PPL;
+template <typename T>
+__global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const AgtPnpParams P)
+{
+    __shared__ agt_pnp::PnpShared sh;
+    const int b = blockIdx.x;
+    const bool guess = P.track ? (agt_uniform(P.track[b].has_guess) && P.enhance_ape) : P.use_guess != 0;
+    if (guess) agt_pnp::pnp_body<T, 1, agt_pnp::PnpNoHook, false, COOP_WAVES>(P, b, sh, P.img, P.mask, P.state_out);
+    else if (threadIdx.x < AGT_WAVE) agt_pnp::pnp_body<T, agt_pnp::MAX_PPL>(P, b, sh, P.img, P.mask, P.state_out);
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
 {
@@ -46,7 +59,7 @@ hipError_t launch_pnp_t(hipStream_t stream, const AgtPnpParams& p, int B)
 {
     dim3 grid(B), block(AGT_WAVE);
     if (p.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_kernel<T, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((pnp_kernel<T, agt_pnp::MAX_PPL>), grid, block, 0, stream, p);
+    else hipLaunchKernelGGL((pnp_coop_kernel<T>), grid, dim3(AGT_WAVE * COOP_WAVES), 0, stream, p);
     return hipGetLastError();
 }
 

@@ -143,9 +143,9 @@ __device__ __forceinline__ double wave_sum_f64(double v)
     return c + o;
 }
 
-// vals[K] (K <= 32) summed over the wave; totals to sh.tot[0..K).  Ends with a barrier.
+// vals[K] (K <= 32) summed over the wave; totals to tot[0..K) (LDS).  Ends with a barrier.
 template <int K>
-__device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpShared& sh, int lane)
+__device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], double* tot, int lane)
 {
     static_assert(K <= 32, "one pass handles at most 32 sums");
     double v[32];
@@ -158,9 +158,9 @@ __device__ __forceinline__ void wave_reduce_bfly(const double (&vals)[K], PnpSha
     bfly_stage<0x140, 4>(v, (lane & 8) != 0);      // row_mirror        l <-> l ^ 15
     bfly_stage<0x141, 2>(v, (lane & 4) != 0);      // row_half_mirror   l <-> l ^ 7
     bfly_stage<0x1B, 1>(v, (lane & 2) != 0);       // quad_perm [3,2,1,0]  l <-> l ^ 3
-    const double tot = v[0] + ddpp<0xB1>(v[0]);    // quad_perm [1,0,3,2]  l <-> l ^ 1
-    pnp_sync();                               // earlier readers of sh.tot are done
-    if (!(lane & 1) && (lane >> 1) < K) sh.tot[lane >> 1] = tot;
+    const double t = v[0] + ddpp<0xB1>(v[0]);      // quad_perm [1,0,3,2]  l <-> l ^ 1
+    pnp_sync();                               // earlier readers of tot[] are done
+    if (!(lane & 1) && (lane >> 1) < K) tot[lane >> 1] = t;
     pnp_sync();
 }
 
@@ -478,13 +478,40 @@ struct PnpNoHook { __device__ __forceinline__ void operator()() const {} };
 // is read (the fused step's alternating PnP waves wait there for the previous frame's state update: the loads of frame k+1
 // run under the tail of frame k)
 // LDS_STATE: the tracker state of stream b is sh.ts (the caller loaded it and writes it back), not P.track[b]
-template <typename T, int PPL, typename Hook = PnpNoHook, bool LDS_STATE = false>
+// COOP > 1 (n > 64, solves that start from a guess): the COOP waves of the workgroup share ONE solve.  Wave w owns correspondences
+// 64 w .. 64 w + 63 (one per lane), every evaluation's per-wave totals meet in LDS behind one workgroup barrier (two
+// alternating slabs, summed in wave order by every wave: all waves hold bit-identical totals and walk the CvLevMarq state
+// machine redundantly, no decision is communicated), wave 0 alone writes results and runs the state update.  Against one
+// wave with four points per lane: a quarter of the FP64 chain per evaluation for one barrier + 4 x 28 LDS reads
+// (240 corners: 21.3 -> ~11 us).  Every wave of the workgroup must call, with identical arguments; the caller guarantees a
+// guess (the DLT initialisation is one-wave code: COOP callers route guess-less solves to the PPL = 4 body on wave 0).
+template <typename T, int PPL, typename Hook = PnpNoHook, bool LDS_STATE = false, int COOP = 1>
 __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
                                          double* so_p, int extra_flags = 0, Hook before_state = Hook())
 {
     using TS = typename std::conditional<LDS_STATE, AgtTrackStateLds, AgtTrackState>::type;
+    static_assert(COOP == 1 || (PPL == 1 && COOP * 32 * 3 <= NACC * SLAB), "cooperating waves hold one point per lane; slabs live in sh.part");
     const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
+    const int wave = COOP > 1 ? (int)(threadIdx.x >> 6) : 0;
+    const bool master = wave == 0;
+    const bool writer = lane == 0 && master;
     const int n = P.n;
+    // cross-wave meeting point (COOP > 1): sh.part = [2 alternating slabs][COOP][32] per-wave totals, then [COOP][32] private totals
+    int slab_sel = 0;
+    double* const tot = COOP > 1 ? &sh.part[2 * COOP * 32 + wave * 32] : sh.tot;
+    auto coop_sum = [&](double v) -> double {          // v: this wave's total (uniform) -> the workgroup's, in every lane
+        if constexpr (COOP == 1) return v;
+        else {
+            double* slot = &sh.part[slab_sel * COOP * 32];
+            if (lane == 0) slot[wave * 32] = v;
+            __syncthreads();
+            double s_ = slot[0];
+#pragma unroll
+            for (int w = 1; w < COOP; w++) s_ += slot[w * 32];
+            slab_sel ^= 1;
+            return s_;
+        }
+    };
     PSTAMP(0);
     AgtCamera cam;
     load_cam<T>(P.cam, cam);
@@ -498,7 +525,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     int cnt = 0;
 #pragma unroll
     for (int q = 0; q < PPL; q++) {
-        const int i = lane + q * AGT_WAVE;
+        const int i = lane + (q * COOP + wave) * AGT_WAVE;
         use[q] = i < n && (!mask || mask[i] != 0);
         X[q] = Y[q] = Z[q] = mu_[q] = mv_[q] = 0.0;
         if (use[q]) {
@@ -510,7 +537,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     if (P.seed_pts) {
         // detector-fed frame of the tracker: the supplied table is the corner set LK of the NEXT frame starts from
         // (detect_pose.py:400-437 -> the north-star LK step), a corner the detector did not deliver is not trackable
-        for (int i = lane; i < n; i += AGT_WAVE) {
+        for (int i = lane + wave * AGT_WAVE; i < n; i += AGT_WAVE * COOP) {
             P.seed_pts[((long)b * n + i) * 2] = (float)img[i * 2]; P.seed_pts[((long)b * n + i) * 2 + 1] = (float)img[i * 2 + 1];
             P.seed_status[(long)b * n + i] = (!mask || mask[i] != 0) ? 1 : 0;
         }
@@ -529,7 +556,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             cnt += u;
         }
     }
-    const int n_used = (int)agt_wave_sum_i64(cnt);
+    const int n_used = (int)coop_sum((double)agt_wave_sum_i64(cnt));
     before_state();
     int flags = extra_flags;          // AGT_TRK_CHAIN_TIMEOUT from the chained launch, reported with the frame's record
     double param[6];
@@ -540,7 +567,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         // Fail-stop: the chained wait for this stream's corners gave up, now or in an earlier frame.  Nothing is
         // solved on a possibly stale ring entry and the motion-model state is not touched: the record is invalid and flagged,
         // and so is every later one of the stream until agt_tracker_reset.
-        if (lane == 0) {
+        if (writer) {
             ts->chain_fault = 1; ts->frame++;
             if (P.fault) __hip_atomic_store(P.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
             if (P.dense_pose) {
@@ -567,9 +594,9 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         // velocities and prev_R for the motion model: requested now, read from LDS after the solve
         static_assert(offsetof(AgtTrackState, tran_vel) - offsetof(AgtTrackState, rot_vel) == 18 * sizeof(double) &&
                       offsetof(AgtTrackState, prev_R) - offsetof(AgtTrackState, rot_vel) == 24 * sizeof(double), "state layout");
-        if (had_guess && P.enhance_ape && lane < 33) sh.vec[lane] = (&ts->rot_vel[0][0])[lane];
+        if (had_guess && P.enhance_ape && lane < 33 && master) sh.vec[lane] = (&ts->rot_vel[0][0])[lane];
         if (n_used < P.min_points) {          // detect_pose.py:573-574: fewer than two tags
-            if (lane == 0) {
+            if (writer) {
                 ts->has_guess = 0; ts->frame++;
                 if (P.dense_pose) {
                     for (int i = 0; i < AGT_DENSE_STRIDE; i++) P.dense_rec[(long)b * AGT_DENSE_STRIDE + i] = 0.0;
@@ -590,16 +617,17 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
 
     const bool enough = use_guess ? n_used >= 3 : n_used >= 4;      // the DLT branch re-checks for >= 6
     if (!enough) {
-        if (lane == 0 && P.info) {
+        if (writer && P.info) {
             P.info[b * 4 + AGT_INFO_OK] = 0; P.info[b * 4 + AGT_INFO_ITERS] = 0;
             P.info[b * 4 + AGT_INFO_NUSED] = n_used; P.info[b * 4 + AGT_INFO_FLAGS] = AGT_PNP_TOO_FEW;
         }
-        if (lane == 0 && P.err) P.err[b] = 0.0;
+        if (writer && P.err) P.err[b] = 0.0;
         return;
     }
 
-    // ---- initialisation without a guess: cvFindExtrinsicCameraParams2, DLT branch
-    if (!use_guess) {
+    // ---- initialisation without a guess: cvFindExtrinsicCameraParams2, DLT branch (one-wave code, see COOP above)
+    if constexpr (COOP > 1) { if (!use_guess) return; }
+    if constexpr (COOP == 1) if (!use_guess) {
         double c4[4] = { 0, 0, 0, 0 };
 #pragma unroll
         for (int q = 0; q < PPL; q++) if (use[q]) { c4[0] += X[q]; c4[1] += Y[q]; c4[2] += Z[q]; }
@@ -1018,16 +1046,29 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 acc[27] += ex * ex + ey * ey;
             }
             if (mode == 2) PSTAMP(50);
-            wave_reduce_bfly<NACC>(acc, sh, lane);
+            if constexpr (COOP == 1) wave_reduce_bfly<NACC>(acc, tot, lane);
+            else {
+                double* slot = &sh.part[slab_sel * COOP * 32];
+                wave_reduce_bfly<NACC>(acc, slot + wave * 32, lane);
+                __syncthreads();
+                if (lane < NACC) {
+                    double s_ = slot[lane];
+#pragma unroll
+                    for (int w = 1; w < COOP; w++) s_ += slot[w * 32 + lane];
+                    tot[lane] = s_;
+                }
+                pnp_sync();
+                slab_sel ^= 1;
+            }
             if (mode == 2) {
                 PSTAMP(51);
-                return sh.tot[27];
+                return tot[27];
             }
 #pragma unroll
-            for (int i = 0; i < 21; i++) JtJ[i] = sh.tot[i];
+            for (int i = 0; i < 21; i++) JtJ[i] = tot[i];
 #pragma unroll
-            for (int i = 0; i < 6; i++) JtErr[i] = sh.tot[21 + i];
-            return sh.tot[27];
+            for (int i = 0; i < 6; i++) JtErr[i] = tot[21 + i];
+            return tot[27];
         }
         double e2 = 0.0;
 #pragma unroll
@@ -1039,16 +1080,16 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
             rex[q] = ex; rey[q] = ey;
             e2 += ex * ex + ey * ey;
         }
-        return wave_sum_f64(e2);
+        return coop_sum(wave_sum_f64(e2));
     };
     auto evaluate = [&](int mode) -> double {
         return has_dist ? evaluate_t(mode, std::true_type{}) : evaluate_t(mode, std::false_type{});
     };
     auto commit_candidate = [&]() {
 #pragma unroll
-        for (int i = 0; i < 21; i++) JtJ[i] = sh.tot[i];
+        for (int i = 0; i < 21; i++) JtJ[i] = tot[i];
 #pragma unroll
-        for (int i = 0; i < 6; i++) JtErr[i] = sh.tot[21 + i];
+        for (int i = 0; i < 6; i++) JtErr[i] = tot[21 + i];
     };
     // residuals at `param` re-using the rotation of the last evaluation (only tvec changed)
     auto residuals_same_rotation = [&](auto DIST) {
@@ -1132,19 +1173,20 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         if (tvec_f32) { if (has_dist) residuals_same_rotation(std::true_type{}); else residuals_same_rotation(std::false_type{}); }
 #pragma unroll
         for (int q = 0; q < PPL; q++) if (use[q]) esum += sqrt(rex[q] * rex[q] + rey[q] * rey[q]);
-        esum = wave_sum_f64(esum) / n_used;
+        esum = coop_sum(wave_sum_f64(esum)) / n_used;
     }
     PSTAMP(4);
+    if (!master) return;             // (COOP > 1: results, state update and corner refresh are wave 0's)
     if (ts) {
         // ---- PoseDetector._estimate_pose state update, detect_pose.py:528-574
         const bool accepted = esum < P.gate_px;
         int tflags = flags;
-        if (lane == 0 && use_guess) {           // in-place result: the guess arrays now hold the pose
+        if (writer && use_guess) {           // in-place result: the guess arrays now hold the pose
             for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
         }
         if (accepted && had_guess && P.enhance_ape)
             tflags |= motion_model_update(ts, lane, param, tvec_f32, unchanged_prev, prev_f32 != 0, Rlast, sh.vec);
-        if (lane == 0) {
+        if (writer) {
             if (accepted) {
                 if (!had_guess || !P.enhance_ape) {
                     for (int i = 0; i < 6; i++) ts->guess[i] = param[i];
@@ -1190,7 +1232,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         }
         return;
     }
-    if (lane == 0) {
+    if (writer) {
 #pragma unroll
         for (int i = 0; i < 6; i++) P.pose[(long)b * 6 + i] = param[i];
         if (P.info) {

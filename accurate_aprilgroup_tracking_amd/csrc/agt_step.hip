@@ -288,6 +288,60 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
     }
 }
 
+// ---- PnP role for n > 64 (split launches only): the workgroup's four waves share each frame's solve (agt_pnp_body.h, COOP).
+// Frames are taken in order by the whole workgroup; the tracker state lives in LDS as above, wave 0 updates it, a barrier at
+// the head of each frame hands it to the others.  A frame without a guess (first frame, after a gate rejection) is solved by
+// wave 0 alone with four points per lane -- the DLT initialisation is one-wave code.  A chained wait (not used by the split
+// launches of today, kept so the tables mean the same everywhere) is polled by one lane and its outcome shared through LDS.
+constexpr int PNP_COOP = agt_pnp::MAX_PPL;
+// (a real call: inlined next to the cooperative body the two solvers were register-allocated as one function and spilled)
+__device__ __noinline__ void pnp_one_wave_lds(const AgtPnpParams& P, int blk, agt_pnp::PnpShared& sh, const void* img, const uint8_t* mask,
+                                              double* so, int xf)
+{
+    agt_pnp::pnp_body<float, agt_pnp::MAX_PPL, agt_pnp::PnpNoHook, true>(P, blk, sh, img, mask, so, xf);
+}
+__device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
+{
+    const int tid = (int)threadIdx.x, wave = tid >> 6;
+    if (S.pnp_nf > 1)
+        for (unsigned i = tid; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE * PNP_COOP)
+            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+    if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(&sh.ts)[tid] = reinterpret_cast<const double*>(S.pnp.track + blk)[tid];
+    int late = 0;
+    for (int k = 0; k < S.pnp_nf; k++) {
+        __syncthreads();            // tables and state are in LDS / wave 0 has finished frame k - 1's state update
+        const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
+        const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
+        if (k) {
+            img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
+            wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
+        }
+        if (wait) {
+            if (!late) {
+                if (tid == 0) {
+                    const int* fault = &S.pnp.track[blk].chain_fault;
+                    unsigned polls = 0;
+                    int timed_out = 0;
+                    while ((int)(__hip_atomic_load(wait + blk, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                        __builtin_amdgcn_s_sleep(4);
+                        if (++polls > AGT_CHAIN_POLLS || ((polls & 15) == 1 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { timed_out = 1; break; }
+                    }
+                    *(volatile int*)&sh.late = timed_out;
+                }
+                __syncthreads();
+                late = agt_uniform(*(volatile int*)&sh.late);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+        const bool guess = agt_uniform(*(volatile int*)&sh.ts.has_guess) != 0 && S.pnp.enhance_ape;
+        const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
+        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, true, PNP_COOP>(S.pnp, blk, sh, img, mask, so, xf);
+        else if (wave == 0) pnp_one_wave_lds(S.pnp, blk, sh, img, mask, so, xf);
+    }
+    __syncthreads();
+    if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(S.pnp.track + blk)[tid] = reinterpret_cast<const double*>(&sh.ts)[tid];
+}
+
 // One heterogeneous launch: block ranges [LK | PnP | pyr stage 0 | stage 1 | ..].
 // OCC: waves per SIMD the register allocation must leave room for (1 = unconstrained).
 template <int WIN, int NW, int NLEV, bool PNP, int OCC>
@@ -354,6 +408,12 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams
     pnp_role<PPL>(S, T, kernarg_tables(), blockIdx.x, sh);
 }
 
+__global__ __launch_bounds__(AGT_WAVE * PNP_COOP) void pnp_group_coop_kernel(const AgtStepParams S, const AgtStepTables T)
+{
+    __shared__ agt_pnp::PnpShared sh;
+    pnp_role_coop(S, T, kernarg_tables(), blockIdx.x, sh);
+}
+
 // roles: AGT_STEP_ALL = one fused launch; AGT_STEP_PYR / AGT_STEP_LK = that role alone, from the kernel compiled without
 // the FP64 PnP role (the one-wave-per-corner LK keeps its four waves per SIMD; each launch sizes its own LDS);
 // AGT_STEP_PNP = the PnP role alone
@@ -365,7 +425,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     if (roles == AGT_STEP_PNP) {
         if (P.n_pnp <= 0) return hipSuccess;
         if (P.pnp.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
-        else hipLaunchKernelGGL((pnp_group_kernel<agt_pnp::MAX_PPL>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
+        else hipLaunchKernelGGL(pnp_group_coop_kernel, dim3(P.n_pnp), dim3(AGT_WAVE * PNP_COOP), 0, stream, P, T);
         return hipGetLastError();
     }
     if (!(roles & AGT_STEP_PNP)) { P.n_pnp = 0; P.pnp_nf = 0; }

@@ -299,11 +299,12 @@ int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, s
  * frames recorded, and releases the events.  With the fused software-pipelined step the frame is
  * ONE launch: spans 0 and 1 are ~0 and span 2 is the step_kernel launch.  Recording perturbs
  * timing: never leave it on in a throughput measurement. */
-#define AGT_PROF_DENSE_MAX 16      /* dense GN iterations timed individually per frame (agt_track_frame_dense) */
+#define AGT_PROF_DENSE_MAX 16      /* (kept for the event-slot layout: the dense stage uses two of its 2 x 16 slots) */
 #define AGT_PROF_EVENTS (4 + 2 * AGT_PROF_DENSE_MAX)
 #define AGT_PROF_SPANS  5          /* 0: pyramid (all pyrDown launches), 1: LK, 2: PnP+state machine,
-                                      3: sum of the dense Gauss-Newton launches of the frame (launch i: update of iteration i - 1, then the
-                                         accumulate of iteration i), 4: its final launch (last update + corner re-seed); 0 without the stage */
+                                      3: the dense Gauss-Newton launches of the frame, one span over all of them (launch i: update of
+                                         iteration i - 1, then the accumulate of iteration i), 4: its final launch (last update + corner
+                                         re-seed); 0 without the stage */
 int agt_profile_begin(agt_ctx* ctx, int max_frames);
 int agt_profile_end(agt_ctx* ctx, float* ms_out, int* n_frames);
 

@@ -231,6 +231,47 @@ def test_stream_backend_frame_buffer_and_errors(tmp_path, seq10):
         Det(LOG, s.K, None, True, backend="cv").frame_buffer((4, 4))
 
 
+def test_track_host_frame_record_paths(seq10):
+    """agt_track_host_frame (include/agt_hip.h) called through the C ABI with a pinned and with a pageable h_state returns the
+    16 doubles that agt_track_frame + agt_tracker_join + agt_download return"""
+    import ctypes as C
+    import torch
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq10
+    W, Hh = s.width, s.height
+
+    def run(kind):
+        trk = StreamTracker(W, Hh, s.obj, s.K, None, n_streams=1)
+        trk.pipeline(1)
+        trk.reset(torch.from_numpy(s.frame(0)[None]).cuda().contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+        L, h = trk.ctx.L, trk.ctx.h
+        gray = [torch.zeros((1, Hh, W), dtype=torch.uint8, device="cuda") for _ in range(2)]
+        rec_d = torch.full((1, H.STATE_STRIDE), -7.0, dtype=torch.float64, device="cuda")
+        pin = torch.zeros((Hh, W), dtype=torch.uint8).pin_memory()
+        rec_h = torch.zeros(H.STATE_STRIDE, dtype=torch.float64)
+        if kind == "pinned":
+            rec_h = rec_h.pin_memory()
+        out = []
+        for k in range(1, 6):
+            g = gray[k & 1]
+            if kind == "separate":
+                g[0].copy_(torch.from_numpy(s.frame(k)))
+                torch.cuda.synchronize()
+                H.check(L.agt_track_frame(h, C.c_void_p(g.data_ptr()), W, W * Hh, 1, C.c_void_p(rec_d.data_ptr())), "track")
+                H.check(L.agt_tracker_join(h), "join")
+                H.check(L.agt_download(h, C.c_void_p(rec_h.data_ptr()), C.c_void_p(rec_d.data_ptr()), H.STATE_STRIDE * 8), "down")
+            else:
+                np.copyto(pin.numpy(), s.frame(k))
+                H.check(L.agt_track_host_frame(h, C.c_void_p(pin.data_ptr()), 1, W, Hh, None, 0, 0, 0, C.c_void_p(g.data_ptr()), W,
+                                               C.c_void_p(rec_d.data_ptr()), C.c_void_p(rec_h.data_ptr())), "host_frame")
+            out.append(rec_h.numpy().copy())
+        return np.stack(out)
+    sep, pinned, pageable = run("separate"), run("pinned"), run("pageable")
+    assert sep[:, H.ST_OK].all()
+    assert np.array_equal(sep, pinned) and np.array_equal(sep, pageable)
+
+
 def test_hip_tracker_vs_opencv_float_accumulation_on_c2_stream(tmp_path, oracle, seq720_long):
     """DESIGN.md section 2, deviation 1, bounded where north_star bounds it: the c2 stream (1280x720, 60 frames, raw LK
     chaining, no refresh) on the HIP tracker -- exact integer window sums -- against the oracle chain run in OpenCV's

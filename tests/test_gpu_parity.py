@@ -317,6 +317,27 @@ def test_solve_pnp_large_n(cvh, oracle):
     assert np.abs(r_o - r_g).max() < POSE_TOL and np.abs(t_o - t_g).max() < POSE_TOL
 
 
+def test_solve_pnp_cooperating_waves_sizes(cvh, oracle):
+    """64 < N <= 256 with a guess: the four waves of a workgroup share the solve (agt_pnp_body.h, COOP).  Sizes around the
+    wave boundaries (one wave full and one point, a wave empty, all full), with and without distortion, iteration counts equal."""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    K = syn.camera_matrix(1280, 720)
+    rng = np.random.default_rng(12)
+    g = syn.make_april_group(n_tags=64, seed=5)
+    obj_all = syn.group_object_points(g)
+    r = np.array([-0.2, 0.15, 0.25]); t = np.array([-0.03, 0.02, 0.7])
+    for n in (65, 100, 128, 129, 192, 193, 255, 256):
+        for dist in (None, syn.MILD_DIST):
+            obj = obj_all[rng.permutation(256)[:n]]
+            img = syn.project(obj, r, t, K, dist) + rng.normal(0, 0.2, (n, 2))
+            r0, t0 = r + rng.normal(0, 0.03, 3), t + rng.normal(0, 0.01, 3)
+            ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, dist, r0.copy(), t0.copy(), True)
+            ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, dist, r0.copy(), t0.copy(), True)
+            assert ok_o and ok_g
+            gap = max(np.abs(r_o.ravel() - r_g.ravel()).max(), np.abs(t_o.ravel() - t_g.ravel()).max())
+            assert gap < POSE_TOL, (n, dist is not None, gap)
+
+
 def test_solve_pnp_planar_init(torch_cuda, cvh, oracle):
     """cvFindExtrinsicCameraParams2's homography branch: coplanar points, no guess"""
     from accurate_aprilgroup_tracking_amd import synthetic as syn, hiplib as H

@@ -7,7 +7,8 @@ from accurate_aprilgroup_tracking_amd import hiplib
 hiplib.LIB_PATH = os.path.join(os.path.dirname(hiplib.LIB_PATH), "libagt_hip_dbg.so")
 from accurate_aprilgroup_tracking_amd import synthetic as syn
 from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
-seq = syn.Sequence(1280, 720, n_frames=12, seed=0, supersample=1)
+NT = int(sys.argv[1]) if len(sys.argv) > 1 else 12          # tags: 12 -> 48 corners (one wave), 60 -> 240 (four cooperating waves)
+seq = syn.Sequence(1280, 720, n_tags=NT, n_frames=12, seed=0, supersample=1)
 trk = StreamTracker(1280, 720, seq.obj, seq.K, None, n_streams=1)
 trk.reset()
 L = hiplib.lib()
