@@ -923,9 +923,25 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
     if (rc) return rc;
     if (pev) (void)hipEventRecord(pev[1], M);
+    if (c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && c->l0_pitch[pslot] == (long)pitch && c->l0_bstride[pslot] == (long)batch_stride) {
+        // four waves per corner: the LK role of the step as a one-frame group (the frame-chained body; see agt_step.hip lk_role)
+        AgtStepParams S; AgtStepTables T;
+        memset(&S, 0, sizeof(S)); memset(&T, 0, sizeof(T));
+        fill_lk(c, &S.lk, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr, c->trk_n,
+                AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+        S.lk_nf = 1; S.n_lk = 1; S.lk_B = B;
+        for (int k = 0; k < 2; k++) {
+            const int q = k ? slot : pslot;
+            for (int l = 0; l <= c->eff_max_level; l++) T.lk.img[k][l] = l == 0 ? c->l0_ptr[q] : c->lmem[q][l];
+        }
+        T.lk.next[0] = c->corners[slot]; T.lk.status[0] = c->status[slot];
+        hipError_t e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
+        if (e != hipSuccess) return hip_fail(c, e);
+    } else {
     rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
+    }
     if (pev) (void)hipEventRecord(pev[2], M);
     AgtPnpParams p;
     fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);

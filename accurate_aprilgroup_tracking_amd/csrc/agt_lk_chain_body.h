@@ -17,8 +17,9 @@
 //   * the result is stored at once (device-scope stores when the PnP role of the same launch waits for it) and counted into
 //     the arrival counter one frame later, under the next frame's image-side work.
 // Measured on production code with fixed iteration counts: 5.8 us per frame + 0.62 us per iteration (profiles/r02_summary.md).
-// Only what the fused tracker uses is covered: flags == 0, no error output, launches of more than one frame (lk_role keeps
-// lk_body otherwise); the frames of a group share their geometry, the image before the group may differ in pitch.
+// Only what the tracker uses is covered: flags == 0, no error output (lk_role keeps lk_body otherwise); the frames of a group
+// share their geometry, the image before the group may differ in pitch.  A one-frame group is fine: its image-(k-1) tiles are
+// loaded on demand like the first frame's of any group.
 #pragma once
 #include "agt_lk_body.h"
 

@@ -103,10 +103,11 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         }
     }
     if constexpr (WIN == 21 && NW == 4) {
-        // one workgroup per corner: the frame-chained body (agt_lk_chain_body.h) for what the tracker asks for, when there is a
-        // chain (a single frame has nothing to hand over and pays 3 us for that body's on-demand first frame: 23.2 vs 20.0 us
-        // per one-frame launch)
-        if (S.lk.flags == 0 && S.lk.err == nullptr && S.lk_nf > 1) {
+        // one workgroup per corner: the frame-chained body (agt_lk_chain_body.h) for what the tracker asks for.  A launch of a
+        // single frame has nothing to hand over, but the body's shorter iteration (LDS-atomic exchange, early tap loads: round 3)
+        // now outweighs its on-demand first frame: one frame per launch 47.4 -> 52.4 k frames/s at 48 corners, configs[4]'s
+        // LK(240) 28.8 -> 25.5 us (round 2 had measured 23.2 vs 20.0 us against it)
+        if (S.lk.flags == 0 && S.lk.err == nullptr) {
             auto frame = [&](int k) {
                 agt_lk::LkFrameIo<NLEV> io;
                 io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = io.py = 0.f; io.pst = 1;
