@@ -6,6 +6,8 @@ numpy.linalg for the damped 6 x 6 solves (pseudo-inverse through the SVD, as DEC
 two-state loop.  It exists so that the C oracle's LM loop -- when a step is accepted or rejected, how lambda moves, when the
 iteration stops, how many iterations that takes -- has a second, structurally different implementation to be compared with
 (tests/test_oracle.py::test_pnp_lm_oracle_equals_numpy_statement): equal iteration counts, poses to 2e-9 (measured 1e-10).
+The second half states the initialisation WITHOUT a guess (Appendix B steps 1-2, non-planar DLT branch) the same way
+(test_pnp_noguess_init_oracle_equals_numpy_statement).
 """
 import numpy as np
 
@@ -133,3 +135,77 @@ def solve_pnp_guess(obj, img, K, dist, rvec, tvec, max_iter=20, epsilon=FLT_EPSI
                 return param[:3].copy(), param[3:].copy(), iters
             prev_err_norm = err_norm
             state = "CALC_J"
+
+
+# ---- initialisation WITHOUT a guess, written from that prose: numpy.linalg.svd throughout
+
+def undistort_points(img, K, dist=None, iters=5):
+    """cv::undistortPoints with R = I, no P: pixel -> normalised coordinates, `iters` fixed-point iterations of the inverse
+    Brown-Conrady map (rational + tangential + thin-prism terms)"""
+    p = np.asarray(img, np.float64).reshape(-1, 2)
+    k = np.zeros(12)
+    if dist is not None:
+        d = np.asarray(dist, np.float64).reshape(-1)
+        k[:min(d.size, 12)] = d[:12]
+    x0 = (p[:, 0] - K[0, 2]) / K[0, 0]
+    y0 = (p[:, 1] - K[1, 2]) / K[1, 1]
+    x, y = x0.copy(), y0.copy()
+    if dist is None:
+        return np.stack([x, y], 1)
+    for _ in range(iters):
+        r2 = x * x + y * y
+        icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        dx = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2
+        dy = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2
+        x = (x0 - dx) * icdist
+        y = (y0 - dy) * icdist
+    return np.stack([x, y], 1)
+
+
+def rodrigues_inv(R):
+    """rotation matrix -> rotation vector (the generic branch: the test scenes stay away from theta = 0 and pi)"""
+    U, _, Vt = np.linalg.svd(np.asarray(R, np.float64))
+    R = U @ Vt
+    c = np.clip((np.trace(R) - 1) * 0.5, -1.0, 1.0)
+    theta = np.arccos(c)
+    v = np.array([R[2, 1] - R[1, 2], R[0, 2] - R[2, 0], R[1, 0] - R[0, 1]])
+    s = np.linalg.norm(v) * 0.5
+    return v * (0.5 / s) * theta if s > 1e-12 else np.zeros(3)
+
+
+def is_planar(obj):
+    X = np.asarray(obj, np.float64).reshape(-1, 3)
+    d = X - X.mean(0)
+    w = np.linalg.svd(d.T @ d, compute_uv=False)
+    return w[2] / w[1] < 1e-3
+
+
+def dlt_init(obj, img, K, dist=None):
+    """non-planar branch: the 2N x 12 system, last right-singular vector of L^T L as [R | t], sign by det R, R orthonormalised by
+    its SVD, t rescaled by |R_new|_F / |R|_F -> (rvec, tvec)"""
+    X = np.asarray(obj, np.float64).reshape(-1, 3)
+    n = X.shape[0]
+    assert n >= 6 and not is_planar(X)
+    m = undistort_points(img, K, dist)
+    L = np.zeros((2 * n, 12))
+    L[0::2, 0:3] = X; L[0::2, 3] = 1.0
+    L[0::2, 8:11] = -m[:, 0:1] * X; L[0::2, 11] = -m[:, 0]
+    L[1::2, 4:7] = X; L[1::2, 7] = 1.0
+    L[1::2, 8:11] = -m[:, 1:2] * X; L[1::2, 11] = -m[:, 1]
+    _, _, Vt = np.linalg.svd(L.T @ L)
+    P = Vt[-1].reshape(3, 4)
+    R, t = P[:, :3].copy(), P[:, 3].copy()
+    if np.linalg.det(R) < 0:
+        R, t = -R, -t
+    sc = np.linalg.norm(R)
+    U, _, Vt2 = np.linalg.svd(R)
+    Rn = U @ Vt2
+    t = t * (np.linalg.norm(Rn) / sc)
+    return rodrigues_inv(Rn), t
+
+
+def solve_pnp_noguess(obj, img, K, dist=None):
+    """cv::solvePnP(SOLVEPNP_ITERATIVE) without a guess, non-planar object: DLT initialisation, then the LM loop above"""
+    r0, t0 = dlt_init(obj, img, K, dist)
+    r, t, it = solve_pnp_guess(obj, img, K, dist, r0, t0)
+    return r, t, it, (r0, t0)

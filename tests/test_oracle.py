@@ -351,3 +351,40 @@ def test_pnp_lm_oracle_equals_numpy_statement(oracle):
     assert worst < 2e-9, worst
     assert 1 <= n_maxed <= 4
     assert n_cases == 36 and n_reject >= 3, "the far-off guesses no longer exercise the rejection branch (%d rejections)" % n_reject
+
+
+def test_pnp_noguess_init_oracle_equals_numpy_statement(oracle):
+    """cv::solvePnP(ITERATIVE) WITHOUT a guess (SURVEY row a2, detect_pose.py:509-515): the C oracle's initialisation --
+    undistortPoints (5 fixed-point iterations), the 2N x 12 DLT, its smallest singular vector, sign, orthonormalisation and
+    rescaling -- against tests/pnp_numpy.py (written from SURVEY.md Appendix B with numpy.linalg.svd; the oracle gets the vector by
+    its own Jacobi eigen-solver of L^T L).  The initial pose to 1e-9 relative to its size (the singular vector of a 12 x 12 Gram
+    matrix whose condition number is ~1e9), the refined pose to 2e-9, equal LM iteration counts; with and without lens distortion,
+    noisy points, 6 .. 48 points."""
+    from tests import pnp_numpy as P
+    rng = np.random.default_rng(77)
+    worst_init = worst_pose = 0.0
+    n_cases = 0
+    for dist, seed in ((None, 21), (syn.MILD_DIST, 22)):
+        s = syn.Sequence(1280, 720, n_frames=3, seed=seed, dist=dist)
+        d = None if dist is None else np.asarray(dist, np.float64).reshape(-1)
+        pts = s.corners(1).astype(np.float64)
+        und_o = oracle.undistortPoints(pts, s.K, d).reshape(-1, 2)
+        assert np.abs(und_o - P.undistort_points(pts, s.K, d)).max() < 1e-14
+        for k in range(3):
+            for noise, npts in ((0.0, 48), (0.3, 48), (1.0, 24), (0.2, 8), (0.1, 6)):
+                sel = rng.choice(48, npts, replace=False)
+                obj = s.obj[sel]
+                if P.is_planar(obj):
+                    continue
+                img = s.corners(k).astype(np.float64)[sel] + rng.normal(0, noise, (npts, 2))
+                r0_o, t0_o = oracle.pnp_init(obj, img, s.K, d)
+                r_n, t_n, it_n, (r0_n, t0_n) = P.solve_pnp_noguess(obj, img, s.K, d)
+                scale = max(1.0, np.abs(r0_n).max(), np.abs(t0_n).max())
+                worst_init = max(worst_init, np.abs(r0_o.ravel() - r0_n).max() / scale, np.abs(t0_o.ravel() - t0_n).max() / scale)
+                ok, r_o, t_o, it_o = oracle.solvePnP(obj, img, s.K, d, return_iters=True)
+                assert ok and it_o == it_n, (it_o, it_n, noise, npts)
+                worst_pose = max(worst_pose, np.abs(r_o.ravel() - r_n).max(), np.abs(t_o.ravel() - t_n).max())
+                n_cases += 1
+    assert n_cases >= 24
+    assert worst_init < 1e-9, worst_init
+    assert worst_pose < 2e-9, worst_pose
