@@ -51,7 +51,28 @@ __device__ __forceinline__ void pyr_down2_body(const AgtPyrArgs& A0, const AgtPy
     const bool aligned16 = ((reinterpret_cast<uintptr_t>(img) | (uintptr_t)A0.spitch) & 15) == 0;
 
     // ---- 1. fetch: thread -> (row r0 + 14 k, chunk c), 14 rows x 18 chunks per round, 6 rounds
-    {
+    // (row-interior tiles of an aligned image: the fast path of agt_pyramid_body.h -- no reflection, no 64-bit row multiply)
+    if (aligned16 && (sw & 15) == 0 && sy0 >= 0 && sy0 + SHF <= sh && A0.spitch < (1L << 23)) {
+        typedef const __attribute__((address_space(1))) uint8_t* G8;
+        typedef uint32_t u32x4_t __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(1))) u32x4_t* G128;
+        const int r0 = tid / NCH, c = tid - r0 * NCH;
+        const int gx = sx0 + 16 * c;
+        const bool lane_on = tid < 14 * NCH && gx >= 0 && gx + 16 <= sw;
+        const G8 base = (G8)img + ((long)sy0 * A0.spitch + sx0);
+        const int p32 = (int)A0.spitch;
+        const int off = __mul24(r0, p32) + 16 * c;
+        constexpr int NR = (SHF + 13) / 14;
+        uint4 v[NR];
+#pragma unroll
+        for (int k = 0; k < NR; k++) {
+            v[k] = make_uint4(0, 0, 0, 0);
+            if (lane_on && r0 + 14 * k < SHF) { const u32x4_t t = *(G128)(base + (off + 14 * k * p32)); v[k] = make_uint4(t.x, t.y, t.z, t.w); }
+        }
+#pragma unroll
+        for (int k = 0; k < NR; k++)
+            if (tid < 14 * NCH && r0 + 14 * k < SHF) *reinterpret_cast<uint4*>(s_src + (r0 + 14 * k) * SW + 16 * c) = v[k];
+    } else {
         const int r0 = tid / NCH, c = tid - r0 * NCH;
         const int gx = sx0 + 16 * c;
         const bool lane_on = tid < 14 * NCH;
