@@ -360,9 +360,9 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
                        int n, int B, int crit_type, int crit_max_count, double crit_eps,
-                       int flags, double min_eig_threshold, int b0 = 0)
+                       int flags, double min_eig_threshold, int b0 = 0, int waves = 0)
 {
-    // b0: first stream of the launch (streams b0 .. b0 + B - 1 of the slots and of the point arrays)
+    // b0: first stream of the launch (streams b0 .. b0 + B - 1 of the slots and of the point arrays); waves: see agt_launch_lk
     if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
     if (prev_slot < 0 || prev_slot >= c->ring || next_slot < 0 || next_slot >= c->ring) return AGT_ERR_ARG;
     if (n < 0 || B <= 0 || b0 < 0) return AGT_ERR_ARG;
@@ -387,7 +387,7 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
         if (p.prev_status) p.prev_status += (size_t)b0 * n;
         if (p.err) p.err += (size_t)b0 * n;
     }
-    hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B);
+    hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B, c->cfg.win == 21 ? waves : 0);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
@@ -717,11 +717,15 @@ static int launch_group(agt_ctx* c, int B)
     if (rc) return rc;
     hipStream_t sL = c->ms_stream[1], sL2 = c->ms_stream[0], sY = c->ms_stream[2];
     hipEvent_t *evP = c->ms_ev[0], *evL = c->ms_ev[1], *evY = c->ms_ev[3], *evL2 = c->ms_ev[4];
-    // The per-frame LK launches of a group depend on each other (a corner starts where it ended) and leave ~4 us between one
-    // kernel's end and the next one's start on their stream.  A batch that is still "big" in halves (the one-wave-per-corner
-    // kernel in both) goes out as two launches per frame on two streams, streams [0, B1) and [B1, B): each half's gaps are
-    // filled by the other half's kernel.  Every wait on / record of the LK role below is done for both streams.
-    const int B1 = (!agt_lk_wide(c->trk_n, B / 2)) ? B / 2 : B;
+    // The per-frame LK launches of a group depend on each other (a corner starts where it ended), leave ~4 us between one
+    // kernel's end and the next one's start on their stream, and each lasts as long as its slowest corner.  A batch of the
+    // one-wave-per-corner kernel whose halves still hold >= 512 corners goes out as two launches per frame on two streams,
+    // streams [0, B1) and [B1, B), both with the one-wave kernel: each half's gaps and tails are filled by the other half's
+    // kernel.  Every wait on / record of the LK role below is done for both streams.  (Round 3: the halves used to be taken
+    // only from 44 streams of 48 corners on; 22 .. 43 streams gain 12-20 % -- 42 streams 43.9 -> 36.6 us per step.  Four
+    // quarters on four streams lose badly -- 64 streams 160 us, 86 with GPU_MAX_HW_QUEUES=8 against 49.7: more streams than
+    // hardware queues, and four kernels of <= 1 wave per SIMD each stretch one another.)
+    const int B1 = (!agt_lk_wide(c->trk_n, B) && (long)c->trk_n * (B / 2) >= 512) ? B / 2 : B;
     const bool two = B1 < B;
     const int slot_ev = (int)(c->split_seq % AGT_RING_MAX);
     bool p_work = false;
@@ -768,11 +772,12 @@ static int launch_group(agt_ctx* c, int B)
         // frame loop the one-wave-per-corner kernel needs 240 B of scratch per lane at its 128-register budget and runs at half speed)
         for (int k = 1; k <= S.lk_nf && !lk_group; k++) {
             const int ps = (int)((lk_f0 + k - 1) % M), sl = (int)((lk_f0 + k) % M);
+            // (waves = 1: a half is sized by the whole batch's kernel choice, not by its own corner count)
             rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B1,
-                             AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
+                             AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, 0, two ? 1 : 0);
             if (rc == AGT_OK && two)
                 rc = lk_track_on(c, sL2, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B - B1,
-                                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, B1);
+                                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, B1, 1);
             if (rc) return rc;
         }
         e = hipEventRecord(evL[slot_ev], sL);

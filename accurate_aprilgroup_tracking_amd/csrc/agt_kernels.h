@@ -150,7 +150,8 @@ hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, 
                                 uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B);
 hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
                                uint8_t* dst, long dpitch, long dbatch, int B);
-hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B);
+// waves: 0 = by batch size (agt_lk_wide), 1 / 4 = that many waves per corner (win 21 only)
+hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B, int waves = 0);
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B);
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
 hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,

@@ -55,7 +55,7 @@ bool agt_lk_wide(int n, int B)
     return (long)n * B <= cap;
 }
 
-hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, int B)
+hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, int B, int waves)
 {
     AgtLkParams p = p_in;
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_LK_RS=0 keeps every corner on the general body (flag bit 16, internal)
@@ -64,7 +64,7 @@ hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, i
     switch (win) {
     // (2 and 8 waves per corner were measured too: 2 loses to 1 on big batches -- 60 vs 42 us at 64 streams --, 8 loses
     // to 4 on small ones -- 19.5 vs 17.8 us)
-    case 21: return agt_lk_wide(p.n, B) ? launch_lk_t<21, 4>(stream, p, B) : launch_lk_t<21, 1>(stream, p, B);
+    case 21: return (waves ? waves == 4 : agt_lk_wide(p.n, B)) ? launch_lk_t<21, 4>(stream, p, B) : launch_lk_t<21, 1>(stream, p, B);
     case 15: return launch_lk_t<15, 1>(stream, p, B);
     case 31: return launch_lk_t<31, 1>(stream, p, B);
     default: return hipErrorInvalidValue;
