@@ -10,7 +10,7 @@ ring = torch.stack([fr[(i % 8) if (i // 8) % 2 == 0 else 7 - (i % 8)].unsqueeze(
 trk = StreamTracker(W, H, seq.obj, seq.K, None, n_streams=1)
 trk.pipeline(int(os.environ.get("AGT_DEPTH", "4")))
 c0 = torch.from_numpy(seq.corners(0)[None]).cuda().contiguous()
-for K in (400, 1600, 2000, 3000):
+for K in [int(x) for x in os.environ.get("AGT_KS", "400,1600,2000,3000").split(",")]:
     trk.reset(ring[0], c0)
     so = torch.zeros((K, 1, 16), dtype=torch.float64, device="cuda") if os.environ.get("WITH_SO") else None
     for k in range(40): trk.step(ring[(k + 1) % 32])
@@ -19,7 +19,7 @@ for K in (400, 1600, 2000, 3000):
     marks = []
     for k in range(K):
         trk.step(ring[(k + 41) % 32], so[k] if so is not None else None)
-        if (k + 1) % 400 == 0: marks.append(time.perf_counter() - t0)
+        if (k + 1) % max(400, K // 8) == 0: marks.append(time.perf_counter() - t0)
     t1 = time.perf_counter()
     trk.join(); torch.cuda.synchronize()
     t2 = time.perf_counter()
