@@ -762,7 +762,7 @@ static int launch_group(agt_ctx* c, int B)
         // per CU) -- instead of one ~17 us launch + ~5 us gap per frame (round 3: 16 streams 33.9 -> see profiles/r03_stream_sweep.txt).
         bool lk_group = agt_lk_wide(c->trk_n, B);
 #ifdef AGT_DEBUG_KNOBS
-        { static const int on = [] { const char* e = getenv("AGT_SPLIT_LK_GROUP"); return e ? atoi(e) : 1; }(); if (!on) lk_group = false; }
+        { static const int on = [] { const char* e = getenv("AGT_SPLIT_LK_GROUP"); return e ? atoi(e) : 1; }(); if (!on) lk_group = false; if (on == 2) lk_group = true; }   // (2: also for the one-wave kernel)
 #endif
         if (lk_group) {
             e = agt_launch_step(sL, S, T, c->cfg.win, AGT_STEP_LK);
