@@ -6,10 +6,18 @@ namespace {
 
 // OCC: waves per SIMD the register allocation leaves room for.  The one-wave-per-corner 21x21 kernel sits 3
 // registers above the 128 that allow a fourth wave; big batches are throughput-bound, so it is held to 128.
+// XCD-aware corner order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup g takes corner
+// (g % 8) * per_xcd + g / 8 of the launch's n * B -- every XCD walks a CONTIGUOUS run of corners, i.e. whole streams: the tiles of
+// a tag's four corners (and of neighbouring tags) overlap, and with consecutive corners on eight different XCDs each of those
+// L2s fetched the shared lines from HBM for itself (FETCH_SIZE 2.9x the algorithmic bytes at 64 streams).
 template <int WIN, int NW, int NLEV, int OCC>
-__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_kernel(const AgtLkParams P)
+__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_kernel(const AgtLkParams P, const int total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int cidx = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (cidx >= total) return;
+    const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
     agt_lk::LkFrameIo<NLEV> io;
     io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
     io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
@@ -17,25 +25,27 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     if constexpr (WIN == 21 && (NW == 1 || NW == 4)) {
         // one wave per corner: the row-segment body (agt_lk_rs_body.h) while the window's derivative footprint stays inside
         // the image at every level and the corner is alive; the general body otherwise (wave-uniform choice)
-        const long pidx = (long)blockIdx.y * P.n + blockIdx.x;
+        const long pidx = cidx;
         const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
         const int pst = P.prev_status ? P.prev_status[pidx] : 1;
         if (agt_uniform((int)(pst != 0 && !(P.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)))) {
-            agt_lk::lk_body_rs<NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ppx, ppy, ox, oy, ost);
+            agt_lk::lk_body_rs<NW, NLEV>(&P, bX, bY, lds, io, ppx, ppy, ox, oy, ost);
             return;
         }
     }
-    agt_lk::lk_body<WIN, NW, NLEV>(&P, blockIdx.x, blockIdx.y, lds, io, ox, oy, ost);
+    agt_lk::lk_body<WIN, NW, NLEV>(&P, bX, bY, lds, io, ox, oy, ost);
 }
 
 template <int WIN, int NW>
 hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p, int B)
 {
     const size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
-    const dim3 grid(p.n, B), block(AGT_WAVE * NW);
+    const long total = (long)p.n * B;
+    if (total <= 0 || total > (1L << 30)) return hipErrorInvalidValue;
+    const dim3 grid((unsigned)((total + 7) / 8 * 8)), block(AGT_WAVE * NW);
     constexpr int OCC = (WIN == 21 && NW == 1) ? 4 : 1;
-    if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3, OCC>), grid, block, lds, stream, p);
-    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC>), grid, block, lds, stream, p);
+    if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3, OCC>), grid, block, lds, stream, p, (int)total);
+    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC>), grid, block, lds, stream, p, (int)total);
     return hipGetLastError();
 }
 
