@@ -77,7 +77,8 @@ struct DenseShared {
 // done_word != null: the stream's done word is tested here, AFTER the loads have been requested (its round trip runs beside
 // theirs instead of in front); a set word returns "stop" before anything is written.
 __device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
-                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6], const int* done_word = nullptr)
+                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6], const int* done_word = nullptr,
+                                             bool* solved = nullptr)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
@@ -123,6 +124,7 @@ __device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& 
     for (int q = 0; q < 6; q++) { gv[q] = tw[DROW + 21 + q] + tw[21 + q]; A[q * 7] *= 1.0 + P.mu; }
     DSTAMP(10);
     const bool ok = agt_solve6(A, gv, dx);
+    if (solved) *solved = ok;
     DSTAMP(11);
     double dn = 0.0, pn = 0.0;
 #pragma unroll
@@ -306,20 +308,31 @@ __global__ __launch_bounds__(256) void dense_final_kernel(const DenseParams P)
     DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
     const int b = blockIdx.x;
     const int par = (P.iter - 1) & 1;                 // P.iter = iterations launched
+    // the record as earlier launches left it (requested before the update: its round trip runs beside the row loads)
+    double rec0[7];
+    const double* rc = P.rec ? P.rec + (long)b * AGT_DENSE_STRIDE : nullptr;
+#pragma unroll
+    for (int k = 0; k < 7; k++) rec0[k] = rc ? rc[k < 6 ? k : AGT_DN_REFINED] : 0.0;
+    double param[6];
+    bool refined = rec0[6] != 0.0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) param[k] = rec0[k];
     if (!P.done[b] && P.iter > 0) {
+        // the last update: every thread holds the new pose, the re-seed below needs no trip through the record thread 0 writes
         double fin[6];
+        bool ok = false;
         dense_update(P, sh, b, P.partials + (long)par * P.pstride + (long)b * (P.nblk + 1) * DROW, P.ppose + ((long)par * gridDim.x + b) * 8,
-                     nullptr, true, P.iter, fin);
-        __syncthreads();                                  // thread 0 wrote the record the re-seed below reads
+                     nullptr, true, P.iter, fin, nullptr, &ok);
+        if (ok) {
+            refined = true;
+#pragma unroll
+            for (int k = 0; k < 6; k++) param[k] = fin[k];
+        }
     }
-    if (!P.seed_pts || !P.rec) return;
-    const double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
-    if (rc[AGT_DN_REFINED] == 0.0) return;
+    if (!P.seed_pts || !P.rec || !refined) return;
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
-    double param[6], R[9], G[9];
-#pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = rc[k];
+    double R[9], G[9];
     agt_rodrigues<false>(param, R, G);
     for (int i = threadIdx.x; i < P.N; i += 256) {
         double u, v;
