@@ -47,6 +47,7 @@ struct agt_ctx {
     int l_ev_hist[3];                        // event slots of the three most recent LK launches (-1 = none)
     int y_ev_hist[2];                        // event slots of the two most recent PnP launches (-1 = none)
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
+    long prebuilt_t = -1;                    // serial step, clip submission: frame whose pyramid the previous frame's dense launch built (-1 = none)
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
     // chained launches (fused step): per ring entry, [max_streams] arrival counters the LK role counts corners into and
@@ -330,6 +331,7 @@ int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitc
     // launched, stage kernels on the library's streams) are enqueued / ordered in front of this build first
     int rc = join_pipeline(c);
     if (rc) return rc;
+    c->prebuilt_t = -1;
     return pyramid_build_on(c, c->stream, slot, d_frames, pitch, batch_stride, B);
 }
 
@@ -470,6 +472,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (e == hipSuccess) e = hipMemsetAsync(c->lk_done, 0, (size_t)AGT_RING_MAX * c->cfg.max_streams * sizeof(unsigned), c->stream);
     memset(c->lk_target, 0, sizeof(c->lk_target));
     if (e != hipSuccess) return hip_fail(c, e);
+    c->prebuilt_t = -1;
     c->trk_n = n; c->trk_B = B; c->trk_frame = 0; c->n_lk = c->n_pnp = 0; c->enhance_ape = enhance_ape ? 1 : 0;
     for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = 0;
     c->trk_ready = d_corners ? 2 : 1;
@@ -805,6 +808,7 @@ static int launch_group(agt_ctx* c, int B)
 // Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
 static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
 {
+    c->prebuilt_t = -1;
     // ring modulus of this mode: (L + 2) groups, plus the split mode's slack when the entries are available
     {
         const bool split = !agt_step_fits(c->trk_n, B);
@@ -916,8 +920,11 @@ static int ms_join(agt_ctx* c)
 }
 
 // pyrDown.. -> LK -> PnP (+ dense stage) as separate launches on the context's stream: pose complete in stream order
+// next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
+// stream stride -- its two-level pyramid pass rides in this frame's first dense launch (agt_dense.hip) instead of being the
+// first launch of its own chain.
 static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
-                       double* d_state_out, double* d_dense_out, hipEvent_t* pev)
+                       double* d_state_out, double* d_dense_out, hipEvent_t* pev, const uint8_t* next_frame = nullptr)
 {
     int rc = join_pipeline(c);            // a mode switch drains the pipeline first
     if (rc) return rc;
@@ -925,10 +932,32 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     const int slot = (int)(t % c->live_ring), pslot = (int)((t - 1) % c->live_ring);
     hipStream_t M = c->stream;
     if (pev) (void)hipEventRecord(pev[0], M);
-    rc = pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
+    const bool prebuilt = c->prebuilt_t == t && c->l0_ptr[slot] == d_frames && c->l0_pitch[slot] == (long)pitch &&
+                          c->l0_bstride[slot] == (long)batch_stride && c->built_B[slot] == B;
+    c->prebuilt_t = -1;
+    rc = prebuilt ? AGT_OK : pyramid_build_on(c, M, slot, d_frames, pitch, batch_stride, B);
     if (rc) return rc;
     if (pev) (void)hipEventRecord(pev[1], M);
-    if (c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && c->l0_pitch[pslot] == (long)pitch && c->l0_bstride[pslot] == (long)batch_stride) {
+    // Clip submission: the next frame's two-level pyramid pass rides in one of this frame's launches -- the PnP launch where that
+    // is the four-wave kernel (n > 64: one workgroup per stream, the chip idles beside it), else the dense stage's second launch.
+    // (Measured on configs[4], us per frame: no ride 89.0; in the PnP launch 84.0-84.5; in the dense launch 84.0-85.3; in the LK
+    // launch -- as the pyramid role of the step kernel beside the LK role -- 86.5: that kernel's LK role is the slower one.)
+    AgtPyrArgs npyr[2];
+    const int nslot = (int)((t + 1) % c->live_ring);
+    const bool lk_role_launch = c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && c->l0_pitch[pslot] == (long)pitch && c->l0_bstride[pslot] == (long)batch_stride;
+    const bool ride = next_frame && c->eff_max_level == 2 && B <= AGT_PYR2_MAX_B && nslot != slot && nslot < c->ring &&
+                      ((uintptr_t)next_frame & 3) == 0 && (agt_pnp_can_ride(c->trk_n) || (d_dense_out && c->dn_iters > 0));
+    const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n);
+    if (ride) {
+        // (what pyramid_build_on registers for a frame, for frame t + 1 in its ring entry)
+        c->l0_ptr[nslot] = next_frame; c->l0_pitch[nslot] = (long)pitch; c->l0_bstride[nslot] = (long)batch_stride;
+        const long db1 = (long)c->lh[1] * c->lpitch[1], db2 = (long)c->lh[2] * c->lpitch[2];
+        agt_pyr2_args(next_frame, c->lw[0], c->lh[0], (long)pitch, (long)batch_stride, c->lmem[nslot][1], c->lpitch[1], db1,
+                      c->lmem[nslot][2], c->lpitch[2], db2, B, &npyr[0], &npyr[1]);
+        c->built_B[nslot] = B;
+        c->prebuilt_t = t + 1;
+    }
+    if (lk_role_launch) {
         // four waves per corner: the LK role of the step as a one-frame group (the frame-chained body; see agt_step.hip lk_role)
         AgtStepParams S; AgtStepTables T;
         memset(&S, 0, sizeof(S)); memset(&T, 0, sizeof(T));
@@ -955,7 +984,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         if (rc) return rc;
         p.dense_pose = c->pose; p.dense_done = c->dense_done; p.dense_rec = d_dense_out;
     }
-    hipError_t e = agt_launch_pnp(M, p, B);
+    hipError_t e = agt_launch_pnp(M, p, B, ride_pnp ? npyr : nullptr);
     if (e != hipSuccess) return hip_fail(c, e);
     if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
     if (d_dense_out) {
@@ -963,7 +992,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         e = agt_launch_dense(M, d_frames, (long)pitch, (long)batch_stride, c->cfg.width, c->cfg.height, c->dn_xyz, c->dn_t, c->dn_M,
                              c->obj, c->corners[slot], c->status[slot], c->trk_n, c->cam, c->pose, c->dense_partials, nullptr,
                              c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, c->dn_reseed ? c->corners[slot] : nullptr,
-                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX);
+                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX, (ride && !ride_pnp) ? npyr : nullptr);
         if (pev) c->prof_dense[c->prof_n - 1] = c->dn_iters < AGT_PROF_DENSE_MAX ? c->dn_iters : AGT_PROF_DENSE_MAX;
         if (e != hipSuccess) return hip_fail(c, e);
     }
@@ -1021,6 +1050,7 @@ int agt_track_frame_detected(agt_ctx* c, const uint8_t* d_frames, size_t pitch, 
     if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
     int rc = join_pipeline(c);
     if (rc) return rc;
+    c->prebuilt_t = -1;
     const long t = c->trk_frame + 1;
     const int slot = (int)(t % c->live_ring);
     rc = pyramid_build_on(c, c->stream, slot, d_frames, pitch, batch_stride, B);
@@ -1294,6 +1324,26 @@ int agt_track_frame_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
     if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
     hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
     return step_serial(c, d_frames, pitch, batch_stride, B, d_state_out, d_dense_out, pev);
+}
+
+// `count` consecutive frames of the stream(s), frame k at d_frames + k * frame_stride: agt_track_frame_dense for each, in order.
+// Knowing the next frame, the library lets its pyramid pass ride in the current frame's first dense launch (agt_dense.hip) --
+// same records, one launch less in every frame's serial chain.
+int agt_track_frames_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
+                           double* d_state_out, double* d_dense_out)
+{
+    if (!c || !d_frames || !d_dense_out || count < 0 || (frame_stride & 3)) return AGT_ERR_ARG;
+    if (c->trk_ready != 2 || c->dn_M <= 0) return AGT_ERR_STATE;
+    if (B <= 0 || B != c->trk_B) return AGT_ERR_ARG;
+    if ((pitch & 3) || ((uintptr_t)d_frames & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width) return AGT_ERR_ARG;
+    for (int k = 0; k < count; k++) {
+        hipEvent_t* pev = (c->prof_ev && c->prof_n < c->prof_cap) ? c->prof_ev + (size_t)c->prof_n * AGT_PROF_EVENTS : nullptr;
+        int rc = step_serial(c, d_frames + (size_t)k * frame_stride, pitch, batch_stride, B,
+                             d_state_out ? d_state_out + (size_t)k * B * AGT_STATE_STRIDE : nullptr,
+                             d_dense_out + (size_t)k * B * AGT_DENSE_STRIDE, pev, k + 1 < count ? d_frames + (size_t)(k + 1) * frame_stride : nullptr);
+        if (rc) return rc;
+    }
+    return AGT_OK;
 }
 
 int agt_profile_begin(agt_ctx* c, int max_frames)

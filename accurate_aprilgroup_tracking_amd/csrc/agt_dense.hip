@@ -23,6 +23,7 @@
 // No MFMA: the contraction is 6x6.
 #undef AGT_PNP_STAMPS
 #include "agt_pnp_body.h"
+#include "agt_pyramid2_body.h"
 
 // In-kernel cycle stamps of one accumulate launch (diagnostic builds only: make dbg): block 1 of stream 0, iteration >= 1
 #ifdef AGT_DENSE_STAMPS
@@ -60,6 +61,11 @@ struct DenseParams {
     double photo_weight, mu;
     int iter;
     float* seed_pts; uint8_t* seed_status;     // tracker stage with re-seed: the frame's corner set / LK status ([B][N][2], [B][N]) or null
+    // clip submission (agt_track_frames_dense): the two-level pyramid pass of the NEXT frame rides in the first accumulate launch
+    // as extra workgroups (blockIdx.x > nblk) -- it depends on nothing this frame computes, and alone it was a 6.5 us launch
+    // in the frame's serial chain
+    AgtPyrArgs py0, py1;
+    int n_pyr;                                 // tiles per stream (0 = none)
 };
 
 struct DenseShared {
@@ -159,6 +165,16 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
     const int b = blockIdx.y;
+    if ((int)blockIdx.x > P.nblk) {
+        // next frame's pyramid tile (only in launches that carry the job; independent of the done word)
+        const int tile = (int)blockIdx.x - P.nblk - 1;
+        if (tile < P.n_pyr) {
+            const int by = tile / P.py0.gx, bx = tile - by * P.py0.gx;
+            agt_pyr2::pyr_down2_body(P.py0, P.py1, bx, by, P.py0.src + (long)b * P.py0.sbatch, P.py0.dst + (long)b * P.py0.dbatch,
+                                     P.py1.dst + (long)b * P.py1.dbatch, lds_raw);
+        }
+        return;
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const bool geo = (int)blockIdx.x == P.nblk;        // the last block of a stream evaluates the corner (geometric) rows
     const int par = P.iter & 1;
@@ -353,9 +369,11 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
                             int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
-                            hipEvent_t* ev, int n_ev)
+                            hipEvent_t* ev, int n_ev, const AgtPyrArgs* next_pyr)
 {
     DenseParams P;
+    P.n_pyr = 0;
+    P.py0 = AgtPyrArgs(); P.py1 = AgtPyrArgs();
     P.rec = rec; P.stats_stride = rec ? AGT_DENSE_STRIDE : 8;
     if (rec) stats = rec + AGT_DN_PHOTO_RMS;
     P.img = img; P.pitch = pitch; P.ibatch = ibatch; P.w = w; P.h = h;
@@ -367,7 +385,19 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
     hipError_t e = rec ? hipSuccess : hipMemsetAsync(done, 0, (size_t)B * sizeof(int), stream);
     for (int it = 0; it < iters && e == hipSuccess; it++) {
         P.iter = it;
-        hipLaunchKernelGGL(dense_accum_kernel, dim3(P.nblk + (N > 0 ? 1 : 0), B), dim3(256), sizeof(DenseShared), stream, P);
+        // (the geometric block's slot is always in the grid when a pyramid job rides along: block indices above nblk are tiles)
+        unsigned gx = (unsigned)(P.nblk + (N > 0 ? 1 : 0));
+        size_t lds = sizeof(DenseShared);
+        P.n_pyr = 0;
+        // (in the SECOND launch when there is one: the first has no update prologue and is shorter than a pyramid tile's ~6 us --
+        // riding there stretched it by 3.2 us; the later launches last ~7 us and hide the tiles completely)
+        if (it == (iters > 1 ? 1 : 0) && next_pyr) {
+            P.py0 = next_pyr[0]; P.py1 = next_pyr[1];
+            P.n_pyr = P.py0.gx * P.py0.gy;
+            gx = (unsigned)(P.nblk + 1 + P.n_pyr);
+            lds = lds > (size_t)agt_pyr2::PYR2_LDS_BYTES ? lds : (size_t)agt_pyr2::PYR2_LDS_BYTES;
+        }
+        hipLaunchKernelGGL(dense_accum_kernel, dim3(gx, B), dim3(256), lds, stream, P);
         // profiling only: ev[0] closes the Gauss-Newton launches (launch i carries the update of iteration i - 1), ev[1] the final launch
         if (ev && n_ev >= 2 && it == iters - 1) (void)hipEventRecord(ev[0], stream);
         e = hipGetLastError();

@@ -152,7 +152,10 @@ hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, i
                                uint8_t* dst, long dpitch, long dbatch, int B);
 // waves: 0 = by batch size (agt_lk_wide), 1 / 4 = that many waves per corner (win 21 only)
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B, int waves = 0);
-hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B);
+// ride != null (two argument blocks of agt_pyr2_args): the two-level pyramid pass of another frame as extra workgroups of the
+// launch; only where agt_pnp_can_ride(n) (the four-wave kernel of n > 64)
+hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B, const AgtPyrArgs* ride = nullptr);
+bool agt_pnp_can_ride(int n);
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
 hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,
                                     int w, int h, short2* map1, unsigned short* map2);
@@ -165,7 +168,10 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
                             int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
-                            hipEvent_t* ev = nullptr, int n_ev = 0);
+                            hipEvent_t* ev = nullptr, int n_ev = 0, const AgtPyrArgs* next_pyr = nullptr);
+// geometry of the two-level pyramid pass (agt_pyramid.hip) as the pair of argument blocks its body takes
+void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch, uint8_t* dst1, long dpitch1, long dbatch1,
+                   uint8_t* dst2, long dpitch2, long dbatch2, int B, AgtPyrArgs* A0, AgtPyrArgs* A1);
 int agt_dense_blocks(int M);
 size_t agt_dense_doubles(int M, int B);
 bool agt_lk_window_supported(int win);

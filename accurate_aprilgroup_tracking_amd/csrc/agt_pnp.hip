@@ -1,6 +1,7 @@
 // agt_pnp.hip -- stand-alone cv::solvePnP(SOLVEPNP_ITERATIVE) / cv::projectPoints launches
 // (solver body and design notes: agt_pnp_body.h).
 #include "agt_pnp_body.h"
+#include "agt_pyramid2_body.h"
 
 namespace {
 
@@ -16,10 +17,22 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 // n > 64: four waves.  A solve that starts from a guess is shared by all of them (agt_pnp_body.h, COOP); one without (first
 // frame of a tracker, after a gate rejection, cv2-shaped calls without useExtrinsicGuess) is wave 0's, four points per lane.
 constexpr int COOP_WAVES = agt_pnp::MAX_PPL;
+// Clip submission of the serial step (agt_api.hip step_serial): the two-level pyramid pass of the NEXT frame rides in this launch
+// as extra workgroups (blockIdx.x >= n_solve; tile t of stream s at n_solve + s * n_pyr + t) -- the solve is one workgroup per
+// stream, the rest of the chip idles beside it, and alone the pass was a 6.5 us launch at the head of the next frame's chain.
 template <typename T>
-__global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const AgtPnpParams P)
+__global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const AgtPnpParams P, const AgtPyrArgs Y0, const AgtPyrArgs Y1,
+                                                                         const int n_solve, const int n_pyr)
 {
+    extern __shared__ __attribute__((aligned(16))) uint8_t tile_lds[];       // pyramid tiles only (0 bytes without the job)
     __shared__ agt_pnp::PnpShared sh;
+    if ((int)blockIdx.x >= n_solve) {
+        const int t = (int)blockIdx.x - n_solve;
+        const int st = t / n_pyr, tile = t - st * n_pyr;
+        const int by = tile / Y0.gx, bx = tile - by * Y0.gx;
+        agt_pyr2::pyr_down2_body(Y0, Y1, bx, by, Y0.src + (long)st * Y0.sbatch, Y0.dst + (long)st * Y0.dbatch, Y1.dst + (long)st * Y1.dbatch, tile_lds);
+        return;
+    }
     const int b = blockIdx.x;
     const bool guess = P.track ? (agt_uniform(P.track[b].has_guess) && P.enhance_ape) : P.use_guess != 0;
     if (guess) agt_pnp::pnp_body<T, 1, agt_pnp::PnpNoHook, false, COOP_WAVES>(P, b, sh, P.img, P.mask, P.state_out);
@@ -55,20 +68,29 @@ __global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
 }
 
 template <typename T>
-hipError_t launch_pnp_t(hipStream_t stream, const AgtPnpParams& p, int B)
+hipError_t launch_pnp_t(hipStream_t stream, const AgtPnpParams& p, int B, const AgtPyrArgs* ride)
 {
     dim3 grid(B), block(AGT_WAVE);
-    if (p.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_kernel<T, 1>), grid, block, 0, stream, p);
-    else hipLaunchKernelGGL((pnp_coop_kernel<T>), grid, dim3(AGT_WAVE * COOP_WAVES), 0, stream, p);
+    if (p.n <= AGT_WAVE) {
+        if (ride) return hipErrorInvalidValue;                    // (one-wave workgroups cannot carry pyramid tiles: agt_pnp_can_ride)
+        hipLaunchKernelGGL((pnp_kernel<T, 1>), grid, block, 0, stream, p);
+    } else {
+        const AgtPyrArgs none = AgtPyrArgs();
+        const int n_pyr = ride ? ride[0].gx * ride[0].gy : 0;
+        hipLaunchKernelGGL((pnp_coop_kernel<T>), dim3((unsigned)(B + n_pyr * B)), dim3(AGT_WAVE * COOP_WAVES),
+                           ride ? (size_t)agt_pyr2::PYR2_LDS_BYTES : 0, stream, p, ride ? ride[0] : none, ride ? ride[1] : none, B, n_pyr > 0 ? n_pyr : 1);
+    }
     return hipGetLastError();
 }
 
 }  // namespace
 
-hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B)
+bool agt_pnp_can_ride(int n) { return n > AGT_WAVE && n <= AGT_WAVE * agt_pnp::MAX_PPL; }
+
+hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B, const AgtPyrArgs* ride)
 {
     if (p.n > AGT_WAVE * agt_pnp::MAX_PPL) return hipErrorInvalidValue;
-    return p.dtype == AGT_F64 ? launch_pnp_t<double>(stream, p, B) : launch_pnp_t<float>(stream, p, B);
+    return p.dtype == AGT_F64 ? launch_pnp_t<double>(stream, p, B, ride) : launch_pnp_t<float>(stream, p, B, ride);
 }
 
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B)

@@ -44,11 +44,10 @@ void agt_pyr2_grid(int w2, int h2, int* gx, int* gy)
 }
 int agt_pyr2_lds_bytes(void) { return agt_pyr2::PYR2_LDS_BYTES; }
 
-// src (sw x sh) -> dst1 ((sw+1)/2 x (sh+1)/2) -> dst2, both written, one launch
-hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
-                                uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B)
+void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch, uint8_t* dst1, long dpitch1, long dbatch1,
+                   uint8_t* dst2, long dpitch2, long dbatch2, int B, AgtPyrArgs* pA0, AgtPyrArgs* pA1)
 {
-    AgtPyrArgs A0, A1;
+    AgtPyrArgs& A0 = *pA0; AgtPyrArgs& A1 = *pA1;
     A0.src = src; A0.sw = sw; A0.sh = sh; A0.spitch = spitch; A0.sbatch = sbatch;
     A0.dst = dst1; A0.dw = (sw + 1) / 2; A0.dh = (sh + 1) / 2; A0.dpitch = dpitch1; A0.dbatch = dbatch1;
     A1.src = dst1; A1.sw = A0.dw; A1.sh = A0.dh; A1.spitch = dpitch1; A1.sbatch = dbatch1;
@@ -56,6 +55,14 @@ hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, 
     agt_pyr2_grid(A1.dw, A1.dh, &A0.gx, &A0.gy);              // the tile grid of the pass rides in A0
     A1.gx = A0.gx; A1.gy = A0.gy;
     A0.B = A1.B = B; A0.pad = A1.pad = 0;
+}
+
+// src (sw x sh) -> dst1 ((sw+1)/2 x (sh+1)/2) -> dst2, both written, one launch
+hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
+                                uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B)
+{
+    AgtPyrArgs A0, A1;
+    agt_pyr2_args(src, sw, sh, spitch, sbatch, dst1, dpitch1, dbatch1, dst2, dpitch2, dbatch2, B, &A0, &A1);
     const long tiles = (long)A0.gx * A0.gy * B;
     hipLaunchKernelGGL(pyr_down2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr2::PYR2_LDS_BYTES, stream, A0, A1);
     return hipGetLastError();

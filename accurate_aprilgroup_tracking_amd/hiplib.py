@@ -36,7 +36,7 @@ SYMBOLS = [
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_track_frames", "agt_tracker_buffers",
     "agt_profile_begin", "agt_profile_end", "agt_tracker_pipeline", "agt_tracker_join",
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
-    "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense", "agt_upload", "agt_download",
+    "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense", "agt_track_frames_dense", "agt_upload", "agt_download",
     "agt_tracker_tag_gate", "agt_track_frame_detected", "agt_track_host_frame",
 ]
 
@@ -110,6 +110,7 @@ def lib():
     L.agt_dense_refine.argtypes = [vp, vp, sz, sz, i32, i32, vp, vp, i32, vp, vp, vp, i32, vp, vp, i32, vp, i32, i32, f64, vp]
     L.agt_tracker_dense.argtypes = [vp, vp, vp, i32, i32, f64, i32]
     L.agt_track_frame_dense.argtypes = [vp, vp, sz, sz, i32, vp, vp]
+    L.agt_track_frames_dense.argtypes = [vp, vp, sz, sz, sz, i32, i32, vp, vp]
     L.agt_upload.argtypes = [vp, vp, vp, sz]
     L.agt_download.argtypes = [vp, vp, vp, sz]
     L.agt_profile_begin.argtypes = [vp, i32]

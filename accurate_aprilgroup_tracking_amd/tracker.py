@@ -142,6 +142,25 @@ class StreamTracker:
             del self._alive[0]
         return dense_out
 
+    def step_many_dense(self, clip, state_out=None, dense_out=None):
+        """A clip of consecutive frames with the dense stage in one call: clip cuda u8 [K,B,H,W], state_out cuda f64
+        [K,B,STATE_STRIDE] or None, dense_out cuda f64 [K,B,DENSE_STRIDE] (created when None).  Same records as K calls of
+        step_dense(); the library builds each next frame's pyramid inside the current frame's dense launch.  Enqueues only."""
+        assert clip.dtype == torch.uint8 and clip.is_cuda and clip.dim() == 4 and clip.shape[1] == self.B
+        assert tuple(clip.shape[2:]) == (self.ctx.height, self.ctx.width) and clip.stride(3) == 1, "clip frames must be H x W with unit pixel stride"
+        K = clip.shape[0]
+        if dense_out is None:
+            dense_out = torch.zeros((K, self.B, H.DENSE_STRIDE), dtype=torch.float64, device=self.dev)
+        assert dense_out.is_contiguous() and tuple(dense_out.shape) == (K, self.B, H.DENSE_STRIDE)
+        if state_out is not None:
+            assert state_out.is_contiguous() and tuple(state_out.shape) == (K, self.B, H.STATE_STRIDE)
+        H.check(self.ctx.L.agt_track_frames_dense(self.ctx.h, _ptr(clip), clip.stride(2), clip.stride(1), clip.stride(0), self.B, K,
+                                                  _ptr(state_out), _ptr(dense_out)), "agt_track_frames_dense")
+        self._alive.append(clip)
+        while len(self._alive) > self._keep_frames:
+            del self._alive[0]
+        return dense_out
+
     def join(self):
         """Enqueue the remaining pipeline stages of every supplied frame (no host synchronisation)."""
         H.check(self.ctx.L.agt_tracker_join(self.ctx.h), "agt_tracker_join")

@@ -32,9 +32,19 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
     dense = torch.zeros((max(K, Wm, 1), B, HL.DENSE_STRIDE), dtype=torch.float64, device=dev)
 
     def run(n, out):
-        for k in range(n):
-            bench.pos += 1
-            trk.step_dense(bench.ring[bench.pos % bench.ring_slots], out[k] if out is not None else None, dense[k % dense.shape[0]])
+        # consecutive ring entries go to the tracker as one clip (agt_track_frames_dense: the same n steps and records as n calls of
+        # step_dense; knowing the next frame, the library builds its pyramid inside the current frame's dense launch)
+        k = 0
+        while k < n:
+            a = (bench.pos + 1) % bench.ring_slots
+            m = min(n - k, bench.ring_slots - a, dense.shape[0] - (k % dense.shape[0])) if bench.clips else 1
+            d0 = k % dense.shape[0]
+            if m > 1:
+                trk.step_many_dense(bench.ring[a:a + m], out[k:k + m] if out is not None else None, dense[d0:d0 + m])
+            else:
+                m = 1
+                trk.step_dense(bench.ring[a], out[k] if out is not None else None, dense[d0])
+            bench.pos += m; k += m
     bench.run = run                 # no detector refresh: the re-seed from the refined pose is the drift control here
     dts, st_warm, st_first, st_last, gathered = bench.timed_blocks(D, max(1, args.blocks))
     med, p10, p90 = B_.percentiles(dts)
@@ -76,7 +86,7 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP, dense GN)",
                "data": "synthetic",
                "config": {"workload": wl["label"] % B, "streams_per_gpu": B, "dense_samples": M, "gn_iterations": ITERS, "photo_weight": PHOTO_WEIGHT,
-                          "corner_reseed": True, "launch": "stage kernels in stream order (%d launches per frame)" % (3 + ITERS + 1)},
+                          "corner_reseed": True, "launch": ("stage kernels in stream order; frames handed over as clips (agt_track_frames_dense): %d launches per frame, the next frame's pyramid pass rides in the first dense launch" % (2 + ITERS + 1)) if bench.clips else ("stage kernels in stream order, one call per frame (%d launches per frame)" % (3 + ITERS + 1))},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
                "roofline": roof, "cpu_baseline": cpu, "accepted_frac": round(accepted, 4),

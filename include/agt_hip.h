@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 300
+#define AGT_VERSION 301
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -291,6 +291,12 @@ int agt_dense_refine(agt_ctx* ctx, const uint8_t* d_img, size_t pitch, size_t ba
 int agt_tracker_dense(agt_ctx* ctx, const float* d_model_xyz, const float* d_model_t, int M, int iters, double photo_weight, int reseed);
 int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                           double* d_state_out, double* d_dense_out);
+/* A clip of `count` consecutive frames (frame k at d_frames + k * frame_stride; all with the same pitch and stream stride):
+ * agt_track_frame_dense for each, in order, d_state_out [count][B][AGT_STATE_STRIDE] (or NULL), d_dense_out
+ * [count][B][AGT_DENSE_STRIDE].  Same records as `count` single calls; knowing the next frame, the library lets its pyramid
+ * pass ride in the current frame's first dense launch (one launch less in every frame's serial chain). */
+int agt_track_frames_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
+                           double* d_state_out, double* d_dense_out);
 
 /* ---- per-kernel timing of agt_track_frame with HIP events on the context's stream ---- */
 /* After agt_profile_begin every agt_track_frame records AGT_PROF_EVENTS events around its

@@ -255,6 +255,49 @@ def test_c5_stream_matches_oracle_chain(oracle, reseed, tmp_path):
         pyr = npyr
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_tags", [60, 12])
+def test_dense_clip_submission_equals_single_calls(oracle, n_tags):
+    """agt_track_frames_dense (include/agt_hip.h): a clip of frames in one call -- the pyramid pass of frame k + 1 rides in a
+    launch of frame k: the four-wave PnP launch (240 corners) or the second dense launch (48 corners) -- leaves bitwise the
+    records of agt_track_frame_dense called frame by frame; clips cut at arbitrary places, a clip of one frame, a single call
+    between two clips."""
+    import torch
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = syn.Sequence(1280, 720, n_tags=n_tags, n_frames=6, seed=8, supersample=2)
+    mx = syn.model_samples(s.group, 32 if n_tags == 60 else 16)
+    T = _template(s, mx, 0)
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+    clip = frames[order].unsqueeze(1).contiguous()                       # [K, 1, H, W]
+    K = len(order)
+    outs = []
+    for cuts in (None, [K], [1, 4, 1, 6], [5, 0, 6]):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+        trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=4, photo_weight=0.05, reseed=True)
+        trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+        so = trk.new_state_buffer(K)
+        do = torch.zeros((K, 1, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
+        if cuts is None:
+            for k in range(K):
+                trk.step_dense(clip[k], so[k], do[k])
+        else:
+            k = 0
+            for m in cuts:
+                if m == 0:                      # a single call between two clips
+                    trk.step_dense(clip[k], so[k], do[k]); k += 1
+                else:
+                    trk.step_many_dense(clip[k:k + m], so[k:k + m], do[k:k + m]); k += m
+            assert k == K
+        torch.cuda.synchronize()
+        outs.append((so.cpu().numpy().copy(), do.cpu().numpy().copy()))
+    st0, dn0 = outs[0]
+    assert st0[:, 0, H.ST_OK].all() and (dn0[:, 0, H.DN_REFINED] == 1.0).all()
+    for st, dn in outs[1:]:
+        assert np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(dn.view(np.uint64), dn0.view(np.uint64))
+
+
 def test_synthetic_60_tag_layout():
     """the 60-tag model of configs[4]: every tag inside a 1280x720 frame along the trajectory, none overlapping another"""
     s = syn.Sequence(1280, 720, n_tags=60, n_frames=120, seed=8, supersample=1)
