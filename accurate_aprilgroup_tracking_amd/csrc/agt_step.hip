@@ -78,10 +78,13 @@ __host__ __device__ constexpr size_t lk_role_lds(int levels)
 
 // ---- LK role: workgroup `blk` of the role, THREADS threads.  NW = 4: the workgroup is one corner; NW = 1: each wave is
 // its own corner.  Consecutive frames of a corner are tracked in-kernel (position carried in registers).
-template <int WIN, int NW, int NLEV, int THREADS>
+// XCD_MAP (the role as its own launch, grid rounded up to a multiple of 8): workgroup g takes block (g mod 8) * (grid / 8) + g / 8 of
+// the role -- every XCD walks a contiguous run of corners, so the overlapping tiles of a tag's corners meet in one L2 (see agt_lk.hip).
+template <int WIN, int NW, int NLEV, int THREADS, bool XCD_MAP = false>
 __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTables& T, KParams KS, KTables KT, int blk, uint8_t* lds)
 {
     constexpr int CPB = THREADS / (AGT_WAVE * NW);
+    if constexpr (XCD_MAP) blk = (blk & 7) * ((int)gridDim.x >> 3) + (blk >> 3);
     const int wave = threadIdx.x / AGT_WAVE;
     const long corner = (long)blk * CPB + (NW == 1 ? wave : 0);
     if (corner >= (long)S.lk.n * S.lk_B) return;
@@ -392,7 +395,7 @@ template <int WIN, int NW, int NLEV, int OCC>
 __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_group_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    lk_role<WIN, NW, NLEV, AGT_WAVE * NW>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
+    lk_role<WIN, NW, NLEV, AGT_WAVE * NW, true>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
 }
 
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
@@ -462,8 +465,9 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         constexpr int OCCL = (WIN == 21 && NW == 1) ? 4 : 1;          // as the stand-alone lk_kernel
         const long corners = (long)P.lk.n * P.lk_B;
         const size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
-        if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
-        else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3((unsigned)corners), dim3(AGT_WAVE * NW), per, stream, P, T);
+        const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
+        if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
+        else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         return hipGetLastError();
     }
     if (!(roles & (AGT_STEP_LK | AGT_STEP_PNP))) return hipErrorInvalidValue;       // (LK | PnP without the pyramid role: diagnostics)
