@@ -338,6 +338,30 @@ def test_solve_pnp_cooperating_waves_sizes(cvh, oracle):
             assert gap < POSE_TOL, (n, dist is not None, gap)
 
 
+def test_solve_pnp_minimum_point_counts(cvh, oracle):
+    """the smallest inputs cv2 accepts (N >= 4, or N == 3 with a guess; the non-planar DLT needs 6): 3, 4 and 5
+    correspondences with a guess, 6 and 7 non-coplanar ones without -- pose and ok flag as the oracle's"""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    K = syn.camera_matrix(640, 480)
+    rng = np.random.default_rng(40)
+    r = np.array([0.25, -0.1, 0.15]); t = np.array([0.01, -0.02, 0.45])
+    for n, guess in ((3, True), (4, True), (5, True), (6, False), (7, False)):
+        for dist in (None, syn.MILD_DIST):
+            obj = rng.uniform(-0.04, 0.04, (n, 3))
+            img = syn.project(obj, r, t, K, dist) + rng.normal(0, 0.05, (n, 2))
+            if guess:
+                r0, t0 = r + rng.normal(0, 0.02, 3), t + rng.normal(0, 0.005, 3)
+                ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, dist, r0.copy(), t0.copy(), True)
+                ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, dist, r0.copy(), t0.copy(), True)
+            else:
+                ok_o, r_o, t_o = oracle.solvePnP(obj, img, K, dist)
+                ok_g, r_g, t_g = cvh.solvePnP(obj, img, K, dist)
+            assert ok_o and ok_g
+            # (three points leave the pose under-determined along a valley: both solvers walk the same LM path, compared loosely there)
+            tol = 1e-6 if n == 3 else 1e-8
+            assert np.abs(r_o.ravel() - r_g.ravel()).max() < tol and np.abs(t_o.ravel() - t_g.ravel()).max() < tol, (n, guess, dist is not None)
+
+
 def test_solve_pnp_planar_init(torch_cuda, cvh, oracle):
     """cvFindExtrinsicCameraParams2's homography branch: coplanar points, no guess"""
     from accurate_aprilgroup_tracking_amd import synthetic as syn, hiplib as H
