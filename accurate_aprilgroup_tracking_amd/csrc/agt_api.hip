@@ -941,7 +941,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     // Clip submission: the next frame's two-level pyramid pass rides in one of this frame's launches -- the PnP launch where that
     // is the four-wave kernel (n > 64: one workgroup per stream, the chip idles beside it), else the dense stage's second launch.
     // (Measured on configs[4], us per frame: no ride 89.0; in the PnP launch 84.0-84.5; in the dense launch 84.0-85.3; in the LK
-    // launch -- as the pyramid role of the step kernel beside the LK role -- 86.5: that kernel's LK role is the slower one.)
+    // launch 84.5-84.8 as tiles behind the LK role launch's own workgroups, 86.5 as the pyramid role of the fused step kernel.)
     AgtPyrArgs npyr[2];
     const int nslot = (int)((t + 1) % c->live_ring);
     const bool lk_role_launch = c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && c->l0_pitch[pslot] == (long)pitch && c->l0_bstride[pslot] == (long)batch_stride;
