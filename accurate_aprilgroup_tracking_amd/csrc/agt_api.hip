@@ -1098,6 +1098,24 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
     return *(volatile int*)c->fault_host ? AGT_ERR_CHAIN : AGT_OK;
 }
 
+// detect_pose.py:570-574 / the mirror's `if ids:`: a frame in which LK lost EVERY tag does not become the "previous" frame --
+// the next frame is tracked from the frame before it, with that frame's corner set and status.  The host sees the record
+// (AGT_ST_NTRACK == 0) and takes the frame back: its ring entry is re-used by the next frame, entry t - 1 (never written since)
+// is the LK source again.  The pose state machine keeps what the lost frame did to it (guess cleared), as in the reference.
+int agt_tracker_rewind(agt_ctx* c)
+{
+    if (!c) return AGT_ERR_ARG;
+    if (c->trk_ready != 2 || c->trk_frame < 1) return AGT_ERR_STATE;
+    int rc = join_pipeline(c);
+    if (rc) return rc;
+    c->prebuilt_t = -1;
+    c->trk_frame -= 1;
+    c->n_lk = c->n_pnp = c->trk_frame;
+    for (int s = 0; s < AGT_MAX_LEVELS; s++)
+        if (c->n_stage[s] > c->trk_frame) c->n_stage[s] = c->trk_frame;
+    return AGT_OK;
+}
+
 int agt_tracker_state_size(void) { return (int)sizeof(AgtTrackState); }
 
 int agt_tracker_state_read(agt_ctx* c, void* host_dst, int B)

@@ -35,6 +35,8 @@ __global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const A
     }
     const int b = blockIdx.x;
     const bool guess = P.track ? (agt_uniform(P.track[b].has_guess) && P.enhance_ape) : P.use_guess != 0;
+    // every wave has read the decision before wave 0 (alone, in the branch without a guess) may rewrite track[b].has_guess
+    __syncthreads();
     if (guess) agt_pnp::pnp_body<T, 1, agt_pnp::PnpNoHook, false, COOP_WAVES>(P, b, sh, P.img, P.mask, P.state_out);
     else if (threadIdx.x < AGT_WAVE) agt_pnp::pnp_body<T, agt_pnp::MAX_PPL>(P, b, sh, P.img, P.mask, P.state_out);
 }

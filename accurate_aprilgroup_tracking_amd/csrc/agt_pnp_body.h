@@ -59,6 +59,7 @@ struct PnpShared {
     unsigned long long tab[5 * AGT_MAX_GROUP];     // fused step: copy of AgtPnpTables (img / mask / so / wait / target per frame)
     int seq;                                       // fused step, two alternating waves: frames of this launch whose state update is complete
     int late;                                      // fused step: one of the two waves gave up a chained wait (the other stops waiting too)
+    int coop[2];                                   // four-wave role: "frame k is solved from a guess" latched by wave 0 for frame parity k & 1 (pnp_role_coop)
     AgtTrackState ts;                              // pipelined roles: the stream's tracker state while the launch runs (see pnp_role)
 };
 

@@ -311,9 +311,15 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
         for (unsigned i = tid; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE * PNP_COOP)
             reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
     if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(&sh.ts)[tid] = reinterpret_cast<const double*>(S.pnp.track + blk)[tid];
+    // Which body solves frame k (four cooperating waves from a guess / wave 0 alone without one) must be the SAME decision in
+    // every wave, and wave 0 rewrites ts.has_guess in its state update while the others may not have looked yet: wave 0
+    // latches the decision for frame k + 1 into coop[(k + 1) & 1] after its update of frame k; the slot read in frame k is not
+    // written again before the barrier at the top of frame k + 2, which every wave reaches only after its read.
+    __syncthreads();
+    if (tid == 0) *(volatile int*)&sh.coop[0] = sh.ts.has_guess;
     int late = 0;
     for (int k = 0; k < S.pnp_nf; k++) {
-        __syncthreads();            // tables and state are in LDS / wave 0 has finished frame k - 1's state update
+        __syncthreads();            // tables and state are in LDS / wave 0 has finished frame k - 1's state update and latched coop[k & 1]
         const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
         const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
         if (k) {
@@ -337,10 +343,14 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
             }
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        const bool guess = agt_uniform(*(volatile int*)&sh.ts.has_guess) != 0 && S.pnp.enhance_ape;
+        const bool guess = agt_uniform(*(volatile int*)&sh.coop[k & 1]) != 0 && S.pnp.enhance_ape;
         const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
         if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, true, PNP_COOP>(S.pnp, blk, sh, img, mask, so, xf);
         else if (wave == 0) pnp_one_wave_lds(S.pnp, blk, sh, img, mask, so, xf);
+        if (wave == 0) {            // (wave 0 ran the state update of frame k in either body: its own LDS accesses are in program order)
+            agt_pnp::pnp_sync();
+            if (tid == 0) *(volatile int*)&sh.coop[(k + 1) & 1] = *(volatile int*)&sh.ts.has_guess;
+        }
     }
     __syncthreads();
     if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(S.pnp.track + blk)[tid] = reinterpret_cast<const double*>(&sh.ts)[tid];

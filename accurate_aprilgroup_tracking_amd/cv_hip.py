@@ -332,11 +332,14 @@ def _undistort_context(w, h, K, dist, newK):
 
 
 def undistort(src, cameraMatrix, distCoeffs, dst=None, newCameraMatrix=None):
-    """cv2.undistort for 8-bit BGR frames (INTER_LINEAR, BORDER_CONSTANT): (H,W,3) u8 -> (H,W,3) u8"""
+    """cv2.undistort for 8-bit BGR or gray frames (INTER_LINEAR, BORDER_CONSTANT): (H,W,3) u8 -> (H,W,3) u8, (H,W) -> (H,W).
+    The remap acts per channel, so a gray frame goes through the 3-channel kernel as (g, g, g)."""
     _require_gpu()
     a = np.asarray(src)
+    if a.dtype == np.uint8 and a.ndim == 2:
+        return undistort(np.repeat(a[:, :, None], 3, axis=2), cameraMatrix, distCoeffs, None, newCameraMatrix)[:, :, 0].copy()
     if a.dtype != np.uint8 or a.ndim != 3 or a.shape[2] != 3:
-        raise error("undistort: an 8-bit 3-channel frame is expected")
+        raise error("undistort: an 8-bit 1- or 3-channel frame is expected")
     h, w = a.shape[:2]
     with _ctx_cache_lock:
         ctx = _undistort_context(w, h, cameraMatrix, distCoeffs, newCameraMatrix)

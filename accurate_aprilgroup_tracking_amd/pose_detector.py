@@ -340,7 +340,8 @@ class _DeviceStream:
         self.dirty = False
         self.has_prev = False
         self.shape = None
-        self._pin = {}
+        self._pin = {}                  # frame_buffer(): pinned arrays handed to the caller (the capture writes into them)
+        self._stage = {}                # pinned staging of frames that live anywhere else (never the caller's buffers)
         self.roi = None
 
     # ---- set-up at the first frame
@@ -388,12 +389,26 @@ class _DeviceStream:
         return buf.numpy()
 
     def _pinned(self, frame):
-        """-> (pinned tensor holding `frame`, was a copy needed)"""
+        """-> pinned tensor holding `frame`: the caller's own frame_buffer() when the frame IS that buffer, otherwise a
+        staging buffer of this object (a caller's capture buffer is never overwritten)"""
         t = self._pin.get(frame.shape)
+        if t is not None and frame.ctypes.data == t.data_ptr() and frame.flags.c_contiguous:
+            return t
+        t = self._stage.get(frame.shape)
         if t is None:
-            t = self._pin[frame.shape] = self.torch.zeros(frame.shape, dtype=self.torch.uint8).pin_memory()
-        if frame.ctypes.data != t.data_ptr() or not frame.flags.c_contiguous:
-            np.copyto(t.numpy(), frame)
+            t = self._stage[frame.shape] = self.torch.zeros(frame.shape, dtype=self.torch.uint8).pin_memory()
+        np.copyto(t.numpy(), frame)
+        return t
+
+    def _gray_as_bgr(self, frame):
+        """a GRAY raw frame of a camera with lens distortion (process_frame undistorts whatever it gets, detect_pose.py:611-619):
+        staged as three equal channels and sent down the BGR path -- remap acts per channel and BGR2GRAY of (g, g, g) is g
+        ((1868 + 9617 + 4899) g + 2^13 >> 14), so the result is cv.undistort(gray) cropped to the ROI, byte for byte"""
+        shape = frame.shape + (3,)
+        t = self._stage.get(shape)
+        if t is None:
+            t = self._stage[shape] = self.torch.zeros(shape, dtype=self.torch.uint8).pin_memory()
+        np.copyto(t.numpy(), frame[:, :, None])
         return t
 
     def _upload(self, dst, src_t, nbytes):
@@ -414,16 +429,18 @@ class _DeviceStream:
         ctx.use_current_stream()
         self.gi = (self.gi + 1) & 3
         g = self.gray[self.gi]
-        pin = self._pinned(frame)
-        if frame.ndim == 2:
+        if frame.ndim == 2 and not self.undistort:
+            assert frame.shape == (self.gh, self.gw)
+            pin = self._pinned(frame)
             if self.gpitch == self.gw:
                 self._upload(g, pin, frame.size)
             else:       # pitch-padded rows: 2-D copy through torch (rare: widths that are not a multiple of 16)
                 g[0, :, :self.gw].copy_(pin, non_blocking=True)
             return g[:, :, :self.gw]
+        pin = self._gray_as_bgr(frame) if frame.ndim == 2 else self._pinned(frame)
         if self.bgr is None:
-            self.bgr = torch.zeros((1,) + frame.shape, dtype=torch.uint8, device=self.trk.dev)
-        self._upload(self.bgr, pin, frame.size)
+            self.bgr = torch.zeros((1,) + tuple(pin.shape), dtype=torch.uint8, device=self.trk.dev)
+        self._upload(self.bgr, pin, pin.numel())
         ctx.preprocess_bgr(self.bgr, self.roi, undistort=self.undistort, out=g[:, :, :self.gw])
         return g[:, :, :self.gw]
 
@@ -434,7 +451,7 @@ class _DeviceStream:
         g = self._ingest(det, frame, raw)
         img_list, obj_list, ids = [], [], []
         if det.detector is not None:
-            gray_host = frame if np.ndim(frame) == 2 else g[0].cpu().numpy()
+            gray_host = frame if (np.ndim(frame) == 2 and not self.undistort) else g[0].cpu().numpy()     # the PROCESSED frame
             img_list, obj_list, ids = det._obtain_detections(gray_host)
         if len(img_list) >= det.MIN_TAGS or not self.has_prev:
             self._table(img_list, obj_list)
@@ -442,11 +459,12 @@ class _DeviceStream:
             pts = self.table_dev[:self.n * 8].view(self.torch.float32).view(1, self.n, 2)
             mask = self.table_dev[self.n * 8:].view(1, self.n)
             self.trk.step_detected(g, pts, mask, self.rec_dev)
-            self.has_prev = True
+            self.has_prev = self.has_prev or bool(ids)      # (the mirror's `if ids:`: a frame without any tag is no tracking source)
+            self._finish(det)
         else:
             self.trk.step(g, self.rec_dev)        # LK from the previous frame's corners: fills detect_pose.py:573-574
             self.trk.join()
-        self._finish(det)
+            self._finish(det, tracked=True)
 
     def _frame_tracked_one_call(self, det, frame, raw):
         """LK path without a detector: upload, pre-processing, agt_track_frame, join, record download and the wait in ONE
@@ -458,10 +476,10 @@ class _DeviceStream:
         ctx.use_current_stream()
         self.gi = (self.gi + 1) & 3
         g = self.gray[self.gi]
-        pin = self._pinned(frame)
-        color = frame.ndim == 3
+        color = frame.ndim == 3 or self.undistort          # a gray raw frame that must be undistorted travels as (g, g, g)
+        pin = self._gray_as_bgr(frame) if (color and frame.ndim == 2) else self._pinned(frame)
         if color and self.bgr is None:
-            self.bgr = self.torch.zeros((1,) + frame.shape, dtype=self.torch.uint8, device=self.trk.dev)
+            self.bgr = self.torch.zeros((1,) + tuple(pin.shape), dtype=self.torch.uint8, device=self.trk.dev)
         self.H.check(ctx.L.agt_track_host_frame(ctx.h, C.c_void_p(pin.data_ptr()), 3 if color else 1, self.src_hw[1], self.src_hw[0],
                                                 C.c_void_p(self.bgr.data_ptr()) if color else None, int(self.undistort and color),
                                                 self.roi[0] if color else 0, self.roi[1] if color else 0, C.c_void_p(g.data_ptr()), self.gpitch,
@@ -469,7 +487,7 @@ class _DeviceStream:
         self.trk._alive.append(g)
         if len(self.trk._alive) > self.trk._keep_frames:
             del self.trk._alive[0]
-        self._finish(det, downloaded=True)
+        self._finish(det, downloaded=True, tracked=True)
 
     def estimate(self, det, imgpoints_arr, objpoints_arr):
         """_estimate_pose(img_list, obj_list) with caller-supplied correspondences (no frame)"""
@@ -497,7 +515,7 @@ class _DeviceStream:
             self.pts_np[4 * t:4 * t + 4] = np.asarray(img, np.float32).reshape(4, 2)
             self.mask_np[4 * t:4 * t + 4] = 1
 
-    def _finish(self, det, downloaded=False):
+    def _finish(self, det, downloaded=False, tracked=False):
         H = self.H
         ctx = self.trk.ctx
         if not downloaded:
@@ -507,6 +525,11 @@ class _DeviceStream:
         self.dirty = True
         r = self.rec_np
         flags = int(r[H.ST_FLAGS])
+        if tracked and int(r[H.ST_NTRACK]) == 0 and not (flags & H.TRK_CHAIN_TIMEOUT):
+            # LK lost every tag: the reference (and the mirror's `if ids:`) keeps the OLDER frame as "previous" and tracks the next
+            # frame from it (detect_pose.py:570-574).  The frame is taken back; its gray buffer is the next frame's.
+            self.trk.rewind()
+            self.gi = (self.gi - 1) & 3
         if flags & H.TRK_CHAIN_TIMEOUT:
             raise RuntimeError("backend='stream': the chained launch gave up waiting for this frame's corners; call reset_stream()")
         if flags & H.PNP_TOO_FEW:

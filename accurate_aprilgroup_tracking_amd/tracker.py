@@ -85,11 +85,17 @@ class StreamTracker:
         reference's ">= 2 tags" (detect_pose.py:494-496).  0: every usable corner counts (the default of the C ABI)."""
         H.check(self.ctx.L.agt_tracker_tag_gate(self.ctx.h, int(corners_per_tag)), "agt_tracker_tag_gate")
 
+    def rewind(self):
+        """Take the newest frame back as the tracking source: the next step() tracks from the frame before it (the reference
+        keeps the older frame as "previous" when a frame yields no tag, detect_pose.py:570-574).  Joins the pipeline."""
+        H.check(self.ctx.L.agt_tracker_rewind(self.ctx.h), "agt_tracker_rewind")
+
     def step_detected(self, frames, corners, mask=None, state_out=None):
         """A detector-fed frame (detect_pose.py:576-609 with >= 2 tags found): `frames` joins the stream (the next step()
         tracks FROM it), `corners` cuda f32 [B,n,2] / `mask` cuda u8 [B,n] become its corner set and LK status and
         _estimate_pose runs on them.  Enqueues only; the record is complete in stream order."""
-        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B and frames.stride(2) == 1
+        assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
+        assert tuple(frames.shape[1:]) == (self.ctx.height, self.ctx.width) and frames.stride(2) == 1, "frames must be [B, H, W] with unit pixel stride"
         assert corners.dtype == torch.float32 and corners.is_contiguous() and corners.shape == (self.B, self.n, 2)
         if mask is not None:
             assert mask.dtype == torch.uint8 and mask.is_contiguous() and mask.shape == (self.B, self.n)
@@ -133,6 +139,7 @@ class StreamTracker:
         """One frame with the dense stage: pyramid -> LK -> solvePnP(guess) + gate + motion model -> dense refinement of the
         accepted pose (-> corner re-seed).  dense_out: cuda f64 [B, DENSE_STRIDE] (created when None).  Enqueues only."""
         assert frames.dtype == torch.uint8 and frames.is_cuda and frames.shape[0] == self.B
+        assert tuple(frames.shape[1:]) == (self.ctx.height, self.ctx.width) and frames.stride(2) == 1, "frames must be [B, H, W] with unit pixel stride"
         if dense_out is None:
             dense_out = torch.zeros((self.B, H.DENSE_STRIDE), dtype=torch.float64, device=self.dev)
         H.check(self.ctx.L.agt_track_frame_dense(self.ctx.h, _ptr(frames), frames.stride(1), frames.stride(0), self.B,

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 301
+#define AGT_VERSION 400
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -222,6 +222,13 @@ int agt_track_frame(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t 
  * agt_tracker_reset without corners.  Joins the pipeline first; pyramid pass + one PnP launch in stream order. */
 int agt_track_frame_detected(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                              const float* d_corners, const uint8_t* d_mask, double* d_state_out);
+/* Take the newest frame back as the tracking source (the reference keeps the older frame as "previous" when a frame yields no
+ * tag at all: detect_pose.py:570-574, the hole the LK step fills, and the host mirror's `if ids:`): joins the pipeline, then the
+ * next agt_track_frame tracks FROM frame t - 1 again (its pyramid, corner set and LK status; the caller's frame t - 1 must still
+ * be valid) and re-uses frame t's ring entry.  The pose state machine is not touched (the lost frame cleared the guess, as
+ * _estimate_pose does with < 2 tags).  A caller that reads every record calls this when AGT_ST_NTRACK came back 0 after an
+ * agt_track_frame; PoseDetector(backend="stream") does.  All B streams go back together (use it with B = 1). */
+int agt_tracker_rewind(agt_ctx* ctx);
 /* The body of the reference's live loop (detect_pose.py:669-681) for ONE stream whose frames live on the HOST, in one call:
  * h_frame (pinned for an asynchronous copy; channels = 1: gray W x H of the context, channels = 3: BGR src_w x src_h, uploaded
  * into d_staging and passed through agt_preprocess_bgr with the given undistort flag and ROI origin) -> d_gray (context-size

@@ -166,8 +166,9 @@ def test_estimate_pose_entry_matches_reference_fixtures(tmp_path, name, backend)
             assert np.abs(np.asarray(det.tran_velocities[i]).ravel() - fx["tran_vel"][k][i]).max() < TOL
 
 
+@pytest.mark.parametrize("color", [True, False], ids=["bgr", "gray"])
 @pytest.mark.parametrize("backend", ["cv", "stream"])
-def test_capture_loop_body_with_lens_distortion(tmp_path, oracle, backend):
+def test_capture_loop_body_with_lens_distortion(tmp_path, oracle, backend, color):
     """the loop body of detect_pose.py:669-681 -- process_frame (undistort with the optimal new camera matrix, crop to the
     ROI; :147-183, :611-619) then _detect_and_get_pose -- on raw BGR frames of a camera with lens distortion.  As in the
     reference the ORIGINAL mtx / dist keep going to solvePnP.  backend "stream": `step(raw)` = one upload, fused undistort
@@ -194,7 +195,9 @@ def test_capture_loop_body_with_lens_distortion(tmp_path, oracle, backend):
     rng = np.random.default_rng(3)
     for k in range(len(s)):
         gray = s.frame(k)
-        raw = np.ascontiguousarray(np.stack([gray, np.clip(gray.astype(int) + 3, 0, 255).astype(np.uint8), gray], axis=-1))
+        # (gray raw frames of a distorting camera -- ADVICE r3: process_frame undistorts whatever frame it gets; the stream
+        # backend used to upload the un-cropped gray frame into the ROI-sized buffer)
+        raw = np.ascontiguousarray(np.stack([gray, np.clip(gray.astype(int) + 3, 0, 255).astype(np.uint8), gray], axis=-1)) if color else gray
         ref._detect_and_get_pose(ref.process_frame(raw))
         if backend == "stream":
             hip.step(raw)
@@ -221,6 +224,10 @@ def test_stream_backend_frame_buffer_and_errors(tmp_path, seq10):
         det._detect_and_get_pose(buf)                 # the buffer itself: uploaded from where it is
         a._detect_and_get_pose(s.frame(k))            # any other array: staged first
         assert np.array_equal(_vec(det.last_pose), _vec(a.last_pose))
+    # an ordinary array of the same shape is staged in the detector's own buffer, never in the caller's capture buffer
+    snapshot = buf.copy()
+    det._detect_and_get_pose(s.frame(4)); a._detect_and_get_pose(s.frame(4))
+    assert np.array_equal(buf, snapshot) and np.array_equal(_vec(det.last_pose), _vec(a.last_pose))
     with pytest.raises(ValueError):
         det._detect_and_get_pose(np.zeros((100, 100), np.uint8))
     with pytest.raises(AttributeError):
@@ -318,3 +325,62 @@ def test_hip_tracker_vs_opencv_float_accumulation_on_c2_stream(tmp_path, oracle,
     print("pose gap HIP vs oracle: float-scalar order %.3g, exact %.3g" % (gaps[oracle.ACC_FLOAT_SCALAR], gaps[oracle.ACC_EXACT]))
     assert gaps[oracle.ACC_EXACT] < 1e-8
     assert gaps[oracle.ACC_FLOAT_SCALAR] <= 1e-5
+
+
+def _lost_frame_scene(oracle, seq):
+    """a crop of seq10 that leaves the object ~12 px of margin, and the tags whose windows a WHITE next frame pushes out of the
+    image (LK's only ways to clear a status are an out-of-image window and a flat previous patch: a frame that loses EVERY
+    tracked tag is built by tracking only tags that sit near the border and showing a white frame)"""
+    allc = np.stack([seq.corners(k) for k in range(len(seq))])
+    x0 = int(allc[..., 0].min() - 12) & ~3; y0 = int(allc[..., 1].min() - 12)
+    x1 = x0 + ((int(allc[..., 0].max() + 12) - x0 + 15) & ~15); y1 = int(allc[..., 1].max() + 12)
+    frames = [np.ascontiguousarray(seq.frame(k)[y0:y1, x0:x1]) for k in range(len(seq))]
+    K = seq.K.copy(); K[0, 2] -= x0; K[1, 2] -= y0
+    shift = np.array([x0, y0], np.float32)
+    white = np.full_like(frames[0], 255)
+    _, st, _ = oracle.calcOpticalFlowPyrLK(frames[2], white, (seq.corners(2) - shift).astype(np.float32), maxLevel=2)
+    lost = [int(t) for t in np.nonzero(~st.reshape(-1, 4).all(axis=1))[0]]
+    return frames, white, K, shift, lost
+
+
+@pytest.mark.parametrize("one_call", [False, True], ids=["detector_attached", "one_call_path"])
+def test_frame_that_loses_every_tag_is_not_the_previous_frame(tmp_path, oracle, seq10, one_call):
+    """detect_pose.py:570-574 / DESIGN.md section 2 (former deviation 8): when LK loses EVERY tag in a frame, the reference's
+    state (and the mirror's `if ids:`) keeps the OLDER frame as "previous": no pose for that frame, the guess is cleared, and
+    the next frame is tracked from the frame before the lost one.  backend "stream" takes the frame back on the device
+    (agt_tracker_rewind).  Frame 0: the detector delivers the tags near the image border only; frames 3 and 4 are white (every
+    tracked tag loses a corner through the border), frame 5 shows the scene again and is tracked FROM FRAME 2; 6-7 chain on.
+    State after EVERY frame vs the oracle-backend mirror; with a detector attached (agt_track_frame path) and without one
+    (agt_track_host_frame, one foreign call)."""
+    from oracle import cv2_shim
+    from accurate_aprilgroup_tracking_amd import formats
+    s = seq10
+    frames, white, K, shift, lost = _lost_frame_scene(oracle, s)
+    assert len(lost) >= 2, lost
+    Det = _detector_class(tmp_path, s)
+    tag_ids = [int(t) for t in s.group["tags"].keys()]
+
+    class BorderTags:
+        def __init__(self):
+            self.k = 0
+
+        def __call__(self, gray):
+            k, self.k = self.k, self.k + 1
+            if k:
+                return []
+            c = s.corners(0).reshape(-1, 4, 2) - shift
+            return [formats.make_detection(tag_ids[t], c[t], decision_margin=80.0) for t in lost]
+    ref = Det(LOG, K, None, True, cv=cv2_shim.make_cv2(), detector=BorderTags())
+    hip = Det(LOG, K, None, True, detector=BorderTags(), backend="stream")
+    got_pose, ids = [], []
+    for k in range(8):
+        frame = white if k in (3, 4) else frames[k]
+        ref._detect_and_get_pose(frame)
+        hip._detect_and_get_pose(frame)
+        _assert_same_state(hip, ref, k)
+        got_pose.append(ref.last_error is not None and ref.last_error < 2)
+        ids.append(list(ref._prev_ids))
+        if k == 0 and one_call:
+            ref.detector = None; hip.detector = None          # LK only from here on: PoseDetector's one-call path
+    assert got_pose == [True, True, True, False, False, True, True, True], got_pose
+    assert ids[4] == ids[2] and len(ids[5]) >= 2, "the scene was picked up again from frame 2"

@@ -28,7 +28,7 @@ def cvh(torch_cuda):
 
 def test_library_loaded():
     from accurate_aprilgroup_tracking_amd import hiplib
-    assert hiplib.lib().agt_version() == 301
+    assert hiplib.lib().agt_version() == 400
 
 
 @pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260), (53, 37), (9, 5), (3, 3), (64, 129), (33, 300), (200, 17)])

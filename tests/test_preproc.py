@@ -169,5 +169,8 @@ def test_cvtcolor_and_strong_distortion_borders(oracle):
     out = cv_hip.undistort(img, K, dist, None, K)
     ref = oracle.undistort(img, K, dist, None, K)
     assert (ref == 0).any() and np.array_equal(out, ref)
+    # one channel (round 4: cv2.undistort takes gray frames too; the gray raw frames of PoseDetector.process_frame)
+    g = np.ascontiguousarray(img[..., 1])
+    assert np.array_equal(cv_hip.undistort(g, K, dist, None, K), oracle.undistort(g, K, dist, None, K))
     with pytest.raises(ValueError):
-        cv_hip.undistort(img[..., 0], K, dist)
+        cv_hip.undistort(img.astype(np.float32), K, dist)
