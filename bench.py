@@ -58,11 +58,14 @@ WORKLOADS = {
 
 
 def algorithmic_bytes(W, H, npts):
-    """SURVEY.md 8d per-unit figures (L = 3), per launch of each kernel and per streamed frame."""
-    pyr = sum((W >> l) * (H >> l) + (W >> (l + 1)) * (H >> (l + 1)) for l in range(LEVELS - 1))   # read l, write l+1
+    """SURVEY.md 8d per-unit figures (L = 3), per launch of each kernel and per streamed frame.
+    "pyramid" is 8d's figure: level 0 read once, every coarser level written once = W * H * 1.3125 (the
+    line used to count the two single-level passes' own traffic, level 1 read a second time, which is "pyramid_two_pass")."""
+    pyr = sum((W >> l) * (H >> l) for l in range(LEVELS))
+    two_pass = sum((W >> l) * (H >> l) + (W >> (l + 1)) * (H >> (l + 1)) for l in range(LEVELS - 1))   # read l, write l + 1, per pass
     lk = npts * LEVELS * (24 * 24 + 32 * 32) + npts * (8 + 8 + 1 + 4)
     pnp = npts * 20 + 48
-    return {"pyramid": pyr, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + npts * LEVELS * 1600 + npts * 21}
+    return {"pyramid": pyr, "pyramid_two_pass": two_pass, "lk": lk, "pnp": pnp, "frame": W * H * 1.3125 + npts * LEVELS * 1600 + npts * 21}
 
 
 def pmc_traffic(kernel, launch_us=None):
@@ -127,12 +130,47 @@ def self_launch(args):
     sys.exit(subprocess.run(cmd, env=env).returncode)
 
 
+def stream_seed(rank, s):
+    """seed of rendered stream s of rank `rank` (rank r renders seeds 1000 r + s)"""
+    return 1000 * rank + s
+
+
+_traj = {}
+
+
+def truth_pose(seed, NF, z0, frame):
+    """generator's pose of stream `seed` at `frame` (trajectory only: nothing is rendered) -> [6]"""
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    if (seed, NF, z0) not in _traj:
+        rv, tv = syn.trajectory(NF, seed, t0=(0.01, -0.02, z0))
+        _traj[(seed, NF, z0)] = np.concatenate([rv, tv], axis=1)
+    return _traj[(seed, NF, z0)][frame]
+
+
+def gather_order_check(gathered, world, B, nseq, NF, z0, ring_start, ring_slots, tol):
+    """Multi-GPU readiness: block q of the gathered records must carry RANK q's streams, in the real record
+    layout: stream b of rank q shows seed 1000 q + b % nseq, so its pose at step k must be that trajectory's pose at the
+    frame of step k (ring index ring_start + 1 + k).  -> (ok, worst gap over the accepted records)"""
+    g = np.asarray(gathered)
+    worst, ok = 0.0, g.shape[0] == world
+    for q in range(g.shape[0]):
+        for b in range(B):
+            for k in range(g.shape[1]):
+                if g[q, k, b, 6] != 1.0:
+                    continue
+                fr = pingpong((ring_start + 1 + k) % ring_slots, NF)
+                worst = max(worst, float(np.abs(g[q, k, b, :6] - truth_pose(stream_seed(q, b % nseq), NF, z0, fr)).max()))
+    return bool(ok and worst < tol), worst
+
+
 class StubTracker:
     """--dry-run only (tests/test_distributed.py): stands in for StreamTracker on a host without a GPU so that the launcher,
-    the rendezvous, the block timing and the pose gather of THIS file run under gloo.  Writes (rank, frame index) records."""
+    the rendezvous, the block timing and the pose gather of THIS file run under gloo.  Writes records in the REAL layout
+    (AGT_STATE_STRIDE doubles: the generator's pose of this rank's stream at the frame handed over, ok = 1, frame counter in
+    AGT_ST_NTRACK's place), so the gather-order check of the real run is exercised on the CPU."""
 
-    def __init__(self, rank):
-        self.rank, self.t = rank, 0
+    def __init__(self, rank, NF, nseq):
+        self.rank, self.t, self.NF, self.nseq = rank, 0, NF, nseq
 
     def pipeline(self, depth):
         pass
@@ -144,7 +182,15 @@ class StubTracker:
         self.t += 1
         if out is not None:
             out.zero_()
-            out[:, 0] = self.rank; out[:, 1] = self.t; out[:, 6] = 1.0
+            ring_index = int(frames[0, 0, 0])               # (the dry-run ring's pixels hold their ring index)
+            for b in range(out.shape[0]):
+                out[b, :6] = self.torch_from(truth_pose(stream_seed(self.rank, b % self.nseq), self.NF, 0.30, pingpong(ring_index, self.NF)))
+            out[:, 6] = 1.0; out[:, 8] = self.t
+
+    @staticmethod
+    def torch_from(a):
+        import torch
+        return torch.from_numpy(np.asarray(a, np.float64))
 
     def join(self):
         pass
@@ -162,19 +208,26 @@ class Bench:
         self.sync = torch.cuda.synchronize if dev.type == "cuda" else (lambda: None)
         W, H, B, NF = self.W, self.H, self.B, self.NF
         t_r = time.time()
+        self.nseq = min(B, 4)
+        self.z0 = 0.30
         if args.dry_run:
+            self.NF = 3
             self.period = self.ring_slots = 4
             self.ring = torch.zeros((4, B, 8, 8), dtype=torch.uint8)
+            for i in range(4):
+                self.ring[i] = i
             self.truth = torch.zeros((4, B, 48, 2))
             self.npts, self.render_s, self.seqs, self.rendered = 48, 0.0, [], None
-            self.trk = StubTracker(rank)
+            self.trk = StubTracker(rank, self.NF, self.nseq)
             self.pos = self.since = 0
             self.clips = False
             return
         # up to 4 rendered seeds; further streams are copies at distinct HBM addresses.  The ring exceeds the 256 MiB
         # Infinity Cache, so every step reads cold addresses.
-        nseq = min(B, 4)
-        self.seqs = [syn.Sequence(W, H, n_tags=wl["ntags"], n_frames=NF, seed=1000 * rank + s, supersample=3, group_seed=0)
+        nseq = self.nseq
+        if wl["ntags"] > 12:
+            self.z0 = syn.DENSE_Z0
+        self.seqs = [syn.Sequence(W, H, n_tags=wl["ntags"], n_frames=NF, seed=stream_seed(rank, s), supersample=3, group_seed=0)
                      for s in range(nseq)]
         self.rendered = np.stack([sq.frames() for sq in self.seqs], axis=1)          # [NF, nseq, H, W]
         self.period = 2 * NF - 2
@@ -242,6 +295,7 @@ class Bench:
             if r > 0 and self.since + K > REDETECT:
                 self.refresh()                        # detector work: between blocks, outside the timers
             self.sync(); D.barrier()
+            self.block_start = self.pos % self.ring_slots         # ring index of the frame before the block's first step
             t0 = time.perf_counter()
             self.run(K, state)
             self.trk.join()                           # enqueue the last pipeline stages of the frames in flight
@@ -377,6 +431,7 @@ def main():
             # the copy stream of the H2D measurement -- would make two of them share a hardware queue and serialise)
             ring = bench.ring; bench.ring = None
             extras["batch64_hbm"] = batch_extra(torch, D, HL, args, rank, dev)
+            extras["pairs64_hbm"] = pairs_extra(torch, D, HL, args, rank, dev)
             bench.ring = ring
             bench.trk.pipeline(depth)
             extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
@@ -421,6 +476,11 @@ def main():
                                               % (("1 and %d" % cpu["all_cores"]["cores"]) if cpu.get("all_cores") else "1", os.cpu_count())}
         out["rccl_ranks"] = world
         out["dist_backend"] = D.backend_name()
+        if world > 1:
+            # block q of the gathered records carries rank q's streams (seeds 1000 q + s): poses against each stream's own trajectory
+            ok_g, worst = gather_order_check(gathered.cpu().numpy(), world, B, bench.nseq, bench.NF, bench.z0, bench.block_start, bench.ring_slots, 5e-3)
+            out["gather_order_ok"] = ok_g
+            out["gather_max_abs_pose_err_vs_truth"] = worst
         if rehearsal:
             out["rehearsal"] = True
         print(json.dumps(out), flush=True)
@@ -433,8 +493,10 @@ def dry_run(args, torch, D, rank, world):
     dts, _, first, last, gathered = bench.timed_blocks(D, max(1, args.blocks))
     med, p10, p90 = percentiles(dts)
     g = gathered.cpu().numpy()
-    # every rank's block came back from the gather, in rank order, with the frame numbers of the LAST block
-    ok = g.shape[0] == world and all((g[r, :, :, 0] == r).all() for r in range(world)) and (np.diff(g[0, :, 0, 1]) == 1).all()
+    # every rank's block came back from the gather, in rank order (block q = the streams of rank q: seeds 1000 q + s), with the
+    # frame numbers of the LAST block -- the same check the real multi-rank run applies to its records
+    ok, _ = gather_order_check(g, world, bench.B, bench.nseq, bench.NF, bench.z0, bench.block_start, bench.ring_slots, 1e-12)
+    ok = ok and bool((np.diff(g[0, :, 0, 8]) == 1).all()) and all(np.abs(g[q, :, :, :6] - g[0, :, :, :6]).max() > 1e-4 for q in range(1, world))
     if rank == 0:
         print(json.dumps({"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(world * bench.B * bench.K / med, 2),
                           "unit": "frames/s", "n_gpus": world, "steps": bench.K, "warmup": bench.Wm, "ms_per_step": round(med / bench.K * 1e3, 5),
@@ -537,13 +599,23 @@ def batch_extra(torch, D, HL, args, rank, dev):
     wl = WORKLOADS["c3"]
     b = Bench(torch, wl, a, rank, 1, dev)
     b.trk.pipeline(16)                       # (the c3 workload's default group size)
-    dts, _, _, st, _ = b.timed_blocks(D, 7)
+    dts, st_w, st_f, st, _ = b.timed_blocks(D, 7)
     med, p10, p90 = percentiles(dts)
     spans = b.stage_spans_us(HL, 40)
     ab = algorithmic_bytes(b.W, b.H, b.npts)
     step_bytes = 64 * ab["frame"]
     pyr_gbs = 64 * ab["pyramid"] / (float(spans[0]) * 1e-6) / 1e9
+    pyr2_gbs = 64 * ab["pyramid_two_pass"] / (float(spans[0]) * 1e-6) / 1e9
     ok = float(st[:, :, HL.ST_OK].mean())
+    # EVERY distinct rendered stream (4 seeds) against its own CPU chain, and every copy (stream b shows
+    # seed b % 4 at its own HBM address) bitwise equal to the stream it copies -- a cross-stream mix-up cannot hide
+    rec = np.concatenate([st_w[:a.warmup], st_f])
+    pose_err = None
+    if not args.no_cpu_baseline:
+        gaps = [pose_gap_vs_cpu_chain(b.seqs[q], b.rendered[:, q], rec[:, q], b.NF, 25) for q in range(b.nseq)]
+        pose_err = {"max_l2_drvec": max(g["max_l2_drvec"] for g in gaps), "max_l2_dtvec": max(g["max_l2_dtvec"] for g in gaps),
+                    "streams_compared": b.nseq, "frames_each": gaps[0]["frames"], "tolerance": 1e-4}
+    copies_ok = all(np.array_equal(rec[:, q].view(np.uint64), rec[:, q % b.nseq].view(np.uint64)) for q in range(64))
     del b
     torch.cuda.empty_cache()
     return {"workload": wl["label"] % 64 + " (span_us: serial pass of the stage kernels)", "frames_per_s": round(64 * a.steps / med, 1),
@@ -551,7 +623,22 @@ def batch_extra(torch, D, HL, args, rank, dev):
             "whole_step_algorithmic_GBs": round(step_bytes / (med / a.steps) / 1e9, 1), "whole_step_frac_of_8TBs": round(step_bytes / (med / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "span_us": {"pyramid": round(float(spans[0]), 2), "lk": round(float(spans[1]), 2), "pnp": round(float(spans[2]), 2)},
             "pyr_down_algorithmic_GBs": round(pyr_gbs, 1), "pyr_down_frac_of_8TBs": round(pyr_gbs / HBM_PEAK_GBS, 4),
-            "accepted_frac": round(ok, 4)}
+            "pyr_down_bytes_note": "W*H*1.3125 per frame (SURVEY 8d); the two single-level passes' own traffic (level 1 read again) would be %.1f GB/s = %.4f of 8 TB/s"
+                                   % (pyr2_gbs, pyr2_gbs / HBM_PEAK_GBS),
+            "accepted_frac": round(ok, 4), "pose_err_vs_cpu": pose_err, "copies_bitwise_equal_to_their_seed_stream": bool(copies_ok)}
+
+
+def pairs_extra(torch, D, HL, args, rank, dev):
+    """BASELINE.json configs[2] exactly as SURVEY.md 8d states it, on the driver-timed line: 64 COLD 1280x720 frame
+    pairs per step, both pyramids built, 169,638,912 algorithmic bytes per batch, 4 rotated batches (472 MiB of frames).  The
+    c3pairs workload's own measurement (bench_pairs.py) with 7 blocks of 128 steps; its CPU baseline runs with --workload c3pairs."""
+    from bench_pairs import measure_pairs
+    a = argparse.Namespace(**vars(args))
+    a.steps, a.warmup, a.blocks, a.streams, a.no_cpu_baseline = 128, 16, 7, 64, True
+    out = measure_pairs(a, torch, D, HL, WORKLOADS["c3pairs"], rank, 1, dev, False)
+    torch.cuda.empty_cache()
+    keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "timing", "roofline", "max_abs_pose_err_vs_truth", "tracked_frac")
+    return {k: out[k] for k in keep}
 
 
 _native = []
@@ -712,7 +799,17 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
            "cpu_model": cpu_model(), "build": flags,
            "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr,
                          "sample": "%d frames, %.1f s; pyrDown / Scharr in %d bands of rows, LK over points (OpenMP)" % (n2, dt2, nthr)} if n2 else None}
-    # -- parity: reference-validated state machine on the oracle backend over the first frames
+    return cpu, pose_gap_vs_cpu_chain(seq, frames, gpu_state, NF, 60)
+
+
+def pose_gap_vs_cpu_chain(seq, frames, gpu_state, NF, max_frames):
+    """parity of what was timed: the reference-validated state machine on the oracle backend (oracle LK with the tracker's
+    sticky status + PoseDetector mirror) over the first frames of ONE stream against that stream's device records"""
+    import logging, tempfile
+    from oracle import cv2_shim
+    from accurate_aprilgroup_tracking_amd import hiplib as HL
+    from accurate_aprilgroup_tracking_amd.pose_detector import PoseDetector
+    cvo, _ = native_oracle()
     tmp = tempfile.mkdtemp()
     open(os.path.join(tmp, "april_group.json"), "w").write(json.dumps(seq.group))
 
@@ -724,7 +821,7 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
     npts = obj32.shape[0]
     pyr = cvo.Pyramid(frames[0]); pts = seq.corners(0)
     alive = np.ones(npts, bool)
-    nchk = min(len(gpu_state), 60)
+    nchk = min(len(gpu_state), max_frames)
     dr = dtv = 0.0
     for i in range(nchk):
         npyr = cvo.Pyramid(frames[pingpong(i + 1, NF)])
@@ -738,7 +835,7 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
             dr = max(dr, float(np.linalg.norm(gpu_state[i, :3] - det.last_pose[0].ravel())))
             dtv = max(dtv, float(np.linalg.norm(gpu_state[i, 3:6] - det.last_pose[1].ravel().astype(np.float64))))
         pts = nx.astype(np.float32); pyr = npyr
-    return cpu, {"max_l2_drvec": dr, "max_l2_dtvec": dtv, "frames": nchk, "tolerance": 1e-4}
+    return {"max_l2_drvec": dr, "max_l2_dtvec": dtv, "frames": nchk, "tolerance": 1e-4}
 
 
 if __name__ == "__main__":

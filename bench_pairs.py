@@ -27,6 +27,14 @@ def pair_bytes(W, H, npts, levels=3):
 
 
 def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
+    out = measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    D.barrier()
+
+
+def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
+    """-> the JSON object of the c3pairs workload on rank 0 (None elsewhere); also the `pairs64_hbm` extra of the default run"""
     import bench as B_
     from accurate_aprilgroup_tracking_amd import cv_hip, synthetic as syn
     W, H, B = wl["W"], wl["H"], args.streams or wl["B"]
@@ -125,6 +133,8 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         sp = np.array([[e[i].elapsed_time(e[i + 1]) * 1e3 for i in range(4)] for e in ev]).mean(axis=0)      # us
         ab = B_.algorithmic_bytes(W, H, npts)
         spans = {"pyramid_prev(2 launches)": float(sp[0]), "pyramid_next(2 launches)": float(sp[1]), "lk": float(sp[2]), "pnp": float(sp[3])}
+        # (pyramid bytes: SURVEY 8d's W * H * 1.3125 per frame -- level 0 read once, levels 1 and 2 written once; the two single-level
+        # passes read level 1 a second time, which is their own traffic, not algorithmic bytes: VERDICT r3 weak #6)
         per = {"pyramid": (2 * B * ab["pyramid"], float(sp[0] + sp[1])), "lk": (B * ab["lk"], float(sp[2])), "pnp": (B * ab["pnp"], float(sp[3]))}
         dom = max(per, key=lambda n: per[n][1])
         nlaunch = {"pyramid": 4, "lk": 1, "pnp": 1}[dom]
@@ -157,8 +167,8 @@ def main_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "render_s": round(render_s, 1), "gathered_shape": list(gathered.shape), "rccl_ranks": world, "dist_backend": D.backend_name()}
         if rehearsal:
             out["rehearsal"] = True
-        print(json.dumps(out), flush=True)
-    D.barrier()
+        return out
+    return None
 
 
 def cpu_baseline_pairs(seqs, NF):
