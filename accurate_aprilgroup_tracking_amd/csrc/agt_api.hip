@@ -596,8 +596,8 @@ static int launch_group(agt_ctx* c, int B)
         A.sw = c->lw[s]; A.sh = c->lh[s];
         A.dw = c->lw[s + 1]; A.dh = c->lh[s + 1];
         A.dpitch = c->lpitch[s + 1]; A.dbatch = (long)c->lh[s + 1] * c->lpitch[s + 1];
-        agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
         A.B = B;
+        uintptr_t src_align = 0, dst_align = 0;
         for (long k = 0; k < cnt; k++) {
             const int slot = (int)((c->n_stage[s] + 1 + k) % M);
             if (s == 0) {
@@ -610,8 +610,10 @@ static int launch_group(agt_ctx* c, int B)
                 T.pyr_src[s][k] = c->lmem[slot][s];
             }
             T.pyr_dst[s][k] = c->lmem[slot][s + 1];
+            src_align |= (uintptr_t)T.pyr_src[s][k]; dst_align |= (uintptr_t)T.pyr_dst[s][k];
         }
         A.src = T.pyr_src[s][0]; A.dst = T.pyr_dst[s][0];
+        agt_pyr_plan(&A, src_align, dst_align, (int)cnt);          // tiled or register-rolling form (A.pad), workgroups per image in A.gx * A.gy
         if (fused && s == 0) {
             // the level 1 -> 2 geometry and buffers ride in stage 1's slots; the pass's tile grid (64 x 16 tiles of level 2) in A
             AgtPyrArgs& A1 = S.pyr[1];
@@ -619,6 +621,7 @@ static int launch_group(agt_ctx* c, int B)
             A1.spitch = c->lpitch[1]; A1.sbatch = (long)c->lh[1] * c->lpitch[1];
             A1.dpitch = c->lpitch[2]; A1.dbatch = (long)c->lh[2] * c->lpitch[2];
             agt_pyr2_grid(A1.dw, A1.dh, &A.gx, &A.gy);
+            A.pad = 0;                            // (the two-level pass has its own tile grid)
             A1.gx = A.gx; A1.gy = A.gy; A1.B = B;
             for (long k = 0; k < cnt; k++) T.pyr_dst[1][k] = c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
             c->n_stage[1] += cnt;                // (same frames: level 2 is complete when level 1 is)

@@ -1,7 +1,9 @@
 // agt_pyramid.hip -- stand-alone cv::pyrDown launch (body: agt_pyramid_body.h).
 // Replaces the pyramid build inside cv.calcOpticalFlowPyrLK (north-star step).
 // Algorithmic bytes per launch: sw*sh read + dw*dh written (per image).
+#include <cstdlib>
 #include "agt_pyramid2_body.h"
+#include "agt_pyramid3_body.h"
 
 namespace {
 
@@ -19,6 +21,16 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs 
     const int bz = t / per_img, r = t - bz * per_img;
     const int by = r / A.gx;
     agt_pyr::pyr_down_body(A, r - by * A.gx, by, A.src + (long)bz * A.sbatch, A.dst + (long)bz * A.dbatch, lds);
+}
+
+// register-rolling form (agt_pyramid3_body.h): A.gx = workgroups per image, A.pad = output rows per strip; same XCD-aware order
+__global__ __launch_bounds__(agt_pyr::NT) void pyr_roll_kernel(const AgtPyrArgs A)
+{
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= A.gx * A.B) return;
+    const int bz = t / A.gx;
+    agt_pyr3::pyr_roll_body(A, t - bz * A.gx, A.src + (long)bz * A.sbatch, A.dst + (long)bz * A.dbatch);
 }
 
 // two levels per pass (agt_pyramid2_body.h): same XCD-aware tile order, tiles of 64 x 16 L2 pixels
@@ -74,15 +86,49 @@ void agt_pyr_grid(int dw, int dh, int* gx, int* gy)
     *gy = (dh + agt_pyr::TH - 1) / agt_pyr::TH;
 }
 
+// Geometry of one pyrDown pass for A.src / A.dst (pointers, pitches, sizes and B filled in): the register-rolling form where
+// it applies (A.pad = output rows per strip, A.gx = workgroups per image, A.gy = 1), else the tiled form (A.pad = 0, tile grid).
+// `src_align` / `dst_align`: OR of every source / destination address the launch will see (frames of a group, batch strides).
+void agt_pyr_plan(AgtPyrArgs* pA, uintptr_t src_align, uintptr_t dst_align, int frames)
+{
+    AgtPyrArgs& A = *pA;
+    A.pad = 0;
+    agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
+    const bool ok = ((src_align | (uintptr_t)A.spitch | (uintptr_t)A.sbatch | (uintptr_t)A.sw) & 15) == 0 &&
+                    ((dst_align | (uintptr_t)A.dpitch | (uintptr_t)A.dbatch) & 7) == 0 &&
+                    A.sw >= 32 && A.sh >= 8 && (long)A.sh * A.spitch < (1L << 31) && (long)A.dh * A.dpitch < (1L << 31);
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_PYR3=0 keeps the tiled kernel, AGT_PYR3_OH=n forces the strip height
+    { static const int on = [] { const char* e = getenv("AGT_PYR3"); return e ? atoi(e) : 1; }(); if (!on) return; }
+#endif
+    if (!ok) return;
+    // strip height: enough units (four per wave) to put ~3 waves on each of the 1024 SIMDs -- a wave keeps 8 KB of reads in
+    // flight --, strips no longer than 16 output rows (measured on 64 x 720p, L0 -> L1: 8 rows 17.8 us, 16: 17.0, 24: 21.2,
+    // 32: 22.1, 48: 27 -- the tiled kernel: 18.6), no shorter than 4 (3 halo rows per strip are re-read through the L2)
+    const long images = (long)A.B * (frames > 0 ? frames : 1);
+    const int ncol = ((A.sw >> 4) + 15) >> 4;
+    long per_image = (12288 + images - 1) / images;
+    long strips = (per_image + ncol - 1) / ncol;
+    if (strips < 1) strips = 1;
+    int oh = (int)(A.dh / strips) & ~3;
+    oh = oh < 4 ? 4 : (oh > 16 ? 16 : oh);
+#ifdef AGT_DEBUG_KNOBS
+    { static const int f = [] { const char* e = getenv("AGT_PYR3_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = f & ~3; }
+#endif
+    A.pad = oh;
+    A.gx = agt_pyr3::roll_blocks(A.sw, A.dh, oh);
+    A.gy = 1;
+}
+
 hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
                                uint8_t* dst, long dpitch, long dbatch, int B)
 {
     AgtPyrArgs A;
     A.src = src; A.sw = sw; A.sh = sh; A.spitch = spitch; A.sbatch = sbatch;
     A.dst = dst; A.dw = (sw + 1) / 2; A.dh = (sh + 1) / 2; A.dpitch = dpitch; A.dbatch = dbatch;
-    agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
     A.B = B;
+    agt_pyr_plan(&A, (uintptr_t)src, (uintptr_t)dst, 1);
     const long tiles = (long)A.gx * A.gy * B;
-    hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
+    if (A.pad) hipLaunchKernelGGL(pyr_roll_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A);
+    else hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
     return hipGetLastError();
 }

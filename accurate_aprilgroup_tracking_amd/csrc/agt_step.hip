@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstddef>
 #include "agt_pyramid2_body.h"
+#include "agt_pyramid3_body.h"
 #include "agt_lk_rs_body.h"
 #include "agt_lk_chain_body.h"
 #include "agt_pnp_body.h"
@@ -46,6 +47,10 @@ extern "C" int agt_debug_role_stamps(unsigned long long* host) { return (int)hip
 #define SSTAMP_MAX(i)
 #define SSTAMP_MIN(i)
 #define RSTAMP(k, i)
+#endif
+
+#ifndef AGT_LKG_OCC
+#define AGT_LKG_OCC 4            // waves per SIMD the one-wave-per-corner LK group kernel is register-allocated for (4: 128 VGPRs)
 #endif
 
 namespace {
@@ -130,7 +135,7 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         }
     }
     float px = 0.f, py = 0.f; int pst = 1;
-    for (int k = 0; k < S.lk_nf; k++) {
+    auto frame_io = [&](int k) {
         agt_lk::LkFrameIo<NLEV> io;
         io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = px; io.py = py; io.pst = pst;
         if (k == 0) {
@@ -143,18 +148,28 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
             for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
             io.next_pts = tab->next[k]; io.status = tab->status[k]; io.done = tab->done[k];
         }
-        if constexpr (WIN == 21 && NW == 1) {
-            // one wave per corner: the row-segment body while the window stays inside the image and the corner is alive
-            // (with four waves per corner the general body is kept here: inside this kernel the row-segment form measured
-            // 16.7 us per frame against 15.9, although it wins by 2.5 us as the stand-alone lk_kernel)
-            const long pidx = (long)b * S.lk.n + pt;
+        return io;
+    };
+    int k = 0;
+    if constexpr (WIN == 21 && NW == 1) {
+        // one wave per corner: the row-segment body while the window stays inside the image and the corner is alive (with four
+        // waves per corner the general body is kept: inside this kernel the row-segment form measured 16.7 us per frame against
+        // 15.9, although it wins by 2.5 us as the stand-alone lk_kernel).  Two loops in sequence, NOT one loop with both bodies:
+        // side by side in one loop body the two trackers are register-allocated as one (29 VGPR spills at a 168-register budget,
+        // 79 at 128; each alone fits 137).  A corner that needs the general body once (window at the image border, status lost)
+        // finishes the group's remaining frames in the second loop -- the general body tracks every case, only slower.
+        const long pidx = (long)b * S.lk.n + pt;
+        for (; k < S.lk_nf; k++) {
             const float ppx = k ? px : S.lk.prev_pts[pidx * 2], ppy = k ? py : S.lk.prev_pts[pidx * 2 + 1];
             const int alive = k ? pst : (S.lk.prev_status ? S.lk.prev_status[pidx] : 1);
-            if (agt_uniform((int)(alive != 0 && !(S.lk.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h)))) {
-                agt_lk::lk_body_rs<NW, NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
-                continue;
-            }
+            if (!agt_uniform((int)(alive != 0 && !(S.lk.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h))))
+                break;
+            const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
+            agt_lk::lk_body_rs<NW, NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
         }
+    }
+    for (; k < S.lk_nf; k++) {
+        const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
         agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
     }
 }
@@ -172,7 +187,7 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
             A.src = nullptr; A.dst = nullptr; A.pad = 0;
             A.spitch = KS->pyr[s].spitch; A.sbatch = KS->pyr[s].sbatch; A.dpitch = KS->pyr[s].dpitch; A.dbatch = KS->pyr[s].dbatch;
             A.sw = KS->pyr[s].sw; A.sh = KS->pyr[s].sh; A.dw = KS->pyr[s].dw; A.dh = KS->pyr[s].dh;
-            A.gx = KS->pyr[s].gx; A.gy = KS->pyr[s].gy; A.B = KS->pyr[s].B;
+            A.gx = KS->pyr[s].gx; A.gy = KS->pyr[s].gy; A.B = KS->pyr[s].B; A.pad = KS->pyr[s].pad;
             // XCD-aware tile order (see agt_pyramid.hip): workgroup index % 8 is the XCD; the stage's
             // workgroups on XCD j take a contiguous run of tiles, runs laid out in XCD order.
             const int j = (blk + base) & 7;
@@ -191,6 +206,10 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
                 A1.gx = A.gx; A1.gy = A.gy; A1.B = A.B;
                 agt_pyr2::pyr_down2_body(A, A1, bx, by, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
                                          KT->pyr_dst[1][fr] + (long)st * A1.dbatch, lds);
+                return;
+            }
+            if (A.pad) {        // register-rolling form (agt_pyramid3_body.h): bx = workgroup of the image, no LDS
+                agt_pyr3::pyr_roll_body(A, bx, KT->pyr_src[s][fr] + (long)st * A.sbatch, KT->pyr_dst[s][fr] + (long)st * A.dbatch);
                 return;
             }
             agt_pyr::pyr_down_body(A, bx, by, KT->pyr_src[s][fr] + (long)st * A.sbatch, KT->pyr_dst[s][fr] + (long)st * A.dbatch, lds);
@@ -472,13 +491,25 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         return hipGetLastError();
     }
     if (roles == AGT_STEP_LK) {
-        constexpr int OCCL = (WIN == 21 && NW == 1) ? 4 : 1;          // as the stand-alone lk_kernel
+#ifndef AGT_DEBUG_KNOBS
+        // The one-wave-per-corner LK role as a group launch (in-kernel frame loop) is a measured dead end -- round 4, spill-free at
+        // last (two frame loops in sequence instead of one with both tracker bodies): 64 streams 54.2 us per step against 42.1 with
+        // per-frame launches in two half-batch chains, 24 streams 36.9 against 30.6; the corners that need 30 iterations need them
+        // in EVERY frame, so a corner's own chain over the group is as long as the chain of per-frame maxima.  Only the knobs build
+        // (AGT_SPLIT_LK_GROUP=2) still carries the instantiation.
+        if constexpr (NW == 1) return hipErrorInvalidValue;
+        else {
+#endif
+        constexpr int OCCL = (WIN == 21 && NW == 1) ? AGT_LKG_OCC : 1;
         const long corners = (long)P.lk.n * P.lk_B;
         const size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
         const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
         if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         return hipGetLastError();
+#ifndef AGT_DEBUG_KNOBS
+        }
+#endif
     }
     if (!(roles & (AGT_STEP_LK | AGT_STEP_PNP))) return hipErrorInvalidValue;       // (LK | PnP without the pyramid role: diagnostics)
     // The FP64 PnP role gets the whole register file (256 VGPR + AGPR spill space): one workgroup per CU, which is why the fused

@@ -31,7 +31,12 @@ def test_library_loaded():
     assert hiplib.lib().agt_version() == 400
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260), (53, 37), (9, 5), (3, 3), (64, 129), (33, 300), (200, 17)])
+# (round 4: widths that are multiples of 16 on aligned buffers take the register-rolling kernel, agt_pyramid3_body.h -- every level
+# of the 720p / 1080p pyramids, heights that are odd / not a multiple of the strip height / shorter than one strip, a single
+# column tile with two groups, seventeen column tiles; the other shapes keep the tiled kernel)
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (37, 52), (5, 8), (121, 260), (53, 37), (9, 5), (3, 3), (64, 129), (33, 300), (200, 17),
+                                   (1080, 1920), (360, 640), (540, 960), (270, 480), (135, 240), (180, 320), (45, 80), (8, 32), (9, 48), (11, 32),
+                                   (101, 4112), (27, 272), (7, 64)])
 def test_pyr_down_bit_exact(torch_cuda, cvh, oracle, shape):
     torch = torch_cuda
     rng = np.random.default_rng(shape[0] * 1000 + shape[1])

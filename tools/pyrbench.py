@@ -4,6 +4,9 @@
 import os, sys
 import torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from accurate_aprilgroup_tracking_amd import hiplib
+if os.environ.get("AGT_LIB"):       # e.g. the knobs build, to sweep AGT_PYR3_OH / AGT_PYR3
+    hiplib.LIB_PATH = os.path.join(os.path.dirname(hiplib.LIB_PATH), os.environ["AGT_LIB"])
 from accurate_aprilgroup_tracking_amd import cv_hip
 W, H, B, SLOTS = 1280, 720, 64, 6
 ctx = cv_hip.Context(W, H, max_level=2, max_points=48, max_streams=B)
