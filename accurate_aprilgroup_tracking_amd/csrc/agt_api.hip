@@ -6,6 +6,9 @@
 #include <string.h>
 #include <math.h>
 #include <float.h>
+#include <time.h>
+#include <stdio.h>
+#include <stdlib.h>
 
 #define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
 #define AGT_RING_MAX 224         // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
@@ -1078,6 +1081,18 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
     if (c->trk_ready != 2 || c->trk_B != 1) return AGT_ERR_STATE;
     const int W = c->cfg.width, H = c->cfg.height;
     hipError_t e;
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_HOST_FRAME_TIMES=1 prints where the host time of this call goes (us, mean) at exit
+    struct Acc { double t[6]; long n; ~Acc() { if (n) fprintf(stderr, "agt_track_host_frame host us: upload-call %.2f track-call %.2f join %.2f d2h-call %.2f sync %.2f total %.2f (n=%ld)\n",
+                                                              t[0] / n, t[1] / n, t[2] / n, t[3] / n, t[4] / n, t[5] / n, n); } };
+    static Acc acc = {};
+    static const int timing = [] { const char* v = getenv("AGT_HOST_FRAME_TIMES"); return v ? atoi(v) : 0; }();
+    auto now = [] { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3; };
+    double tq[6] = { 0, 0, 0, 0, 0, 0 };
+    if (timing) tq[0] = now();
+#define AGT_TQ(i) do { if (timing) tq[i] = now(); } while (0)
+#else
+#define AGT_TQ(i)
+#endif
     if (channels == 1) {
         if (src_w != W || src_h != H || roi_x || roi_y || undistort) return AGT_ERR_ARG;
         if (gpitch == (size_t)W) e = hipMemcpyAsync(d_gray, h_frame, (size_t)W * H, hipMemcpyHostToDevice, c->stream);
@@ -1091,13 +1106,24 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
                                     d_gray, gpitch, gpitch * (size_t)H);
         if (rc) return rc;
     }
+    AGT_TQ(1);
     int rc = agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_state);
     if (rc) return rc;
+    AGT_TQ(2);
     rc = join_pipeline(c);
     if (rc) return rc;
+    AGT_TQ(3);
+    // (Measured and dropped, round 4: the record written by the solver straight into host-mapped memory with a system-scope
+    // sequence word behind it, polled by this thread -- no copy command, no stream wait: 91.4 us per call against 84.8-91.5 this way,
+    // box to box.  The call's time is the device pipeline itself: the copy engine's 19 us of PCIe transfer plus ~16 us of
+    // submission and engine hand-over around it, then the two launches; HSA_ENABLE_SDMA=0 -- blit-kernel copies -- 107 us.)
     e = hipMemcpyAsync(h_state, d_state, AGT_STATE_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+    AGT_TQ(4);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     if (e != hipSuccess) return hip_fail(c, e);
+#ifdef AGT_DEBUG_KNOBS
+    if (timing) { const double t5 = now(); for (int i = 0; i < 4; i++) acc.t[i] += tq[i + 1] - tq[i]; acc.t[4] += t5 - tq[4]; acc.t[5] += t5 - tq[0]; acc.n++; }
+#endif
     return *(volatile int*)c->fault_host ? AGT_ERR_CHAIN : AGT_OK;
 }
 
