@@ -308,7 +308,16 @@ static int pyramid_build_on(agt_ctx* c, hipStream_t stream, int slot, const uint
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     const uint8_t* src = d_frames; long sp = (long)pitch, sb = (long)batch_stride;
     int l0 = 1;
-    if (c->eff_max_level >= 2 && B <= AGT_PYR2_MAX_B) {
+    bool two_level = c->eff_max_level >= 2 && B <= AGT_PYR2_MAX_B;
+    if (c->eff_max_level >= 2 && !two_level) {
+        // big batches: the two-level pass only in its register-rolling form (the tiled one loses to two single passes there)
+        AgtPyrArgs A0, A1;
+        agt_pyr2_args(src, c->lw[0], c->lh[0], sp, sb, c->lmem[slot][1], c->lpitch[1], (long)c->lh[1] * c->lpitch[1],
+                      c->lmem[slot][2], c->lpitch[2], (long)c->lh[2] * c->lpitch[2], B, &A0, &A1);
+        agt_pyr2_plan(&A0, &A1, (uintptr_t)src, (uintptr_t)c->lmem[slot][1] | (uintptr_t)c->lmem[slot][2], 1);
+        two_level = A0.pad != 0;
+    }
+    if (two_level) {
         // levels 1 and 2 in one pass: level 0 is read once, level 1 is never re-read from HBM
         const long db1 = (long)c->lh[1] * c->lpitch[1], db2 = (long)c->lh[2] * c->lpitch[2];
         hipError_t e = agt_launch_pyr_down2(stream, src, c->lw[0], c->lh[0], sp, sb, c->lmem[slot][1], c->lpitch[1], db1,
@@ -587,9 +596,10 @@ static int launch_group(agt_ctx* c, int B)
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_CHAIN=0 keeps the PnP role one launch behind the LK role
     { static const int on = [] { const char* e = getenv("AGT_CHAIN"); return e ? atoi(e) : 1; }(); if (!on) chain = false; }
 #endif
-    // stage 0 builds levels 1 and 2 in one pass (stage 1 then only keeps the books) while the batch is small
-    const bool fused = L >= 2 && B <= AGT_PYR2_MAX_B;
-    S.pyr_fused = fused ? 1 : 0;
+    // stage 0 builds levels 1 and 2 in one pass (stage 1 then only keeps the books): always while the batch is small (tiled or
+    // register-rolling two-level pass), for big batches where the rolling form applies to every frame of the launch (decided below,
+    // in the s = 0 trip) and stage 1 has no backlog from an earlier launch that ran the levels as two passes
+    bool fused = L >= 2 && B <= AGT_PYR2_MAX_B;
     for (int s = 0; s < L; s++) {
         if (fused && s == 1) continue;
         long cnt = done_before[s] - c->n_stage[s];
@@ -617,23 +627,30 @@ static int launch_group(agt_ctx* c, int B)
         }
         A.src = T.pyr_src[s][0]; A.dst = T.pyr_dst[s][0];
         agt_pyr_plan(&A, src_align, dst_align, (int)cnt);          // tiled or register-rolling form (A.pad), workgroups per image in A.gx * A.gy
-        if (fused && s == 0) {
-            // the level 1 -> 2 geometry and buffers ride in stage 1's slots; the pass's tile grid (64 x 16 tiles of level 2) in A
-            AgtPyrArgs& A1 = S.pyr[1];
+        if (s == 0 && L >= 2) {
+            // the level 1 -> 2 geometry and buffers ride in stage 1's slots; the pass's grid in A: 64 x 16 tiles of level 2 (tiled
+            // form) or workgroups per image with the strip height in A.pad (register-rolling form, agt_pyramid4_body.h)
+            AgtPyrArgs A0 = A, A1 = S.pyr[1];
             A1.sw = c->lw[1]; A1.sh = c->lh[1]; A1.dw = c->lw[2]; A1.dh = c->lh[2];
             A1.spitch = c->lpitch[1]; A1.sbatch = (long)c->lh[1] * c->lpitch[1];
             A1.dpitch = c->lpitch[2]; A1.dbatch = (long)c->lh[2] * c->lpitch[2];
-            agt_pyr2_grid(A1.dw, A1.dh, &A.gx, &A.gy);
-            A.pad = 0;                            // (the two-level pass has its own tile grid)
-            A1.gx = A.gx; A1.gy = A.gy; A1.B = B;
-            for (long k = 0; k < cnt; k++) T.pyr_dst[1][k] = c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
-            c->n_stage[1] += cnt;                // (same frames: level 2 is complete when level 1 is)
+            A1.B = B; A1.src = nullptr; A1.dst = nullptr;
+            uintptr_t d2_align = 0;
+            for (long k = 0; k < cnt; k++) d2_align |= (uintptr_t)c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
+            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (int)cnt);
+            if (!fused && A0.pad != 0 && c->n_stage[1] == c->n_stage[0]) fused = true;       // big batch, rolling form, no backlog
+            if (fused) {
+                A = A0; S.pyr[1] = A1;
+                for (long k = 0; k < cnt; k++) T.pyr_dst[1][k] = c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
+                c->n_stage[1] += cnt;            // (same frames: level 2 is complete when level 1 is)
+            }
         }
         S.pyr_nf[s] = (int)cnt;
         S.n_pyr[s] = A.gx * A.gy * B * (int)cnt;
         c->n_stage[s] += cnt;
         any = true;
     }
+    S.pyr_fused = fused ? 1 : 0;
     if (c->n_lk < done_before[L]) {
         long cnt = done_before[L] - c->n_lk;
         if (cnt > F) cnt = F;

@@ -4,6 +4,9 @@
 #include <cstdlib>
 #include "agt_pyramid2_body.h"
 #include "agt_pyramid3_body.h"
+#ifdef AGT_DEBUG_KNOBS
+#include "agt_pyramid4_body.h"
+#endif
 
 namespace {
 
@@ -47,6 +50,18 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down2_kernel(const AgtPyrArgs
                              A1.dst + (long)bz * A1.dbatch, lds);
 }
 
+#ifdef AGT_DEBUG_KNOBS
+// two levels per pass, register-rolling form (agt_pyramid4_body.h): A0.gx = workgroups per image, A0.pad = level-2 rows per strip
+__global__ __launch_bounds__(agt_pyr::NT) void pyr_roll2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1)
+{
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= A0.gx * A0.B) return;
+    const int bz = t / A0.gx;
+    agt_pyr4::pyr_roll2_body(A0, A1, t - bz * A0.gx, A0.src + (long)bz * A0.sbatch, A0.dst + (long)bz * A0.dbatch, A1.dst + (long)bz * A1.dbatch);
+}
+#endif
+
 }  // namespace
 
 void agt_pyr2_grid(int w2, int h2, int* gx, int* gy)
@@ -69,13 +84,57 @@ void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch,
     A0.B = A1.B = B; A0.pad = A1.pad = 0;
 }
 
+// The register-rolling form of the two-level pass where it applies: A0.pad = level-2 rows per strip, A0.gx = workgroups per image,
+// A0.gy = 1 (A1 likewise); else the tiled form is left as agt_pyr2_args set it up (A0.pad = 0).  src_align / dst_align: OR of every
+// source / destination address of the launch (both destination levels); frames: images per stream in the launch.
+void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintptr_t dst_align, int frames)
+{
+    AgtPyrArgs& A0 = *pA0; AgtPyrArgs& A1 = *pA1;
+    A0.pad = A1.pad = 0;
+    agt_pyr2_grid(A1.dw, A1.dh, &A0.gx, &A0.gy);
+    A1.gx = A0.gx; A1.gy = A0.gy;
+    const bool ok = ((src_align | (uintptr_t)A0.spitch | (uintptr_t)A0.sbatch | (uintptr_t)A0.sw) & 15) == 0 &&
+                    ((dst_align | (uintptr_t)A0.dpitch | (uintptr_t)A0.dbatch) & 7) == 0 && ((dst_align | (uintptr_t)A1.dpitch | (uintptr_t)A1.dbatch) & 3) == 0 &&
+                    A0.sw >= 32 && A0.sh >= 32 && (long)A0.sh * A0.spitch < (1L << 31) && (long)A0.dh * A0.dpitch < (1L << 31);
+    // MEASURED AND NOT SHIPPED (round 4): the rolling two-level pass is bit-exact (tests/test_gpu_parity.py ran it on every shape of
+    // test_pyramid_build_all_levels_bit_exact) but a strip of oh2 level-2 rows is a serial chain of 4 oh2 + 9 level-0 rows per lane with
+    // 8 in flight, and short strips re-read (4 oh2 + 9) / (4 oh2) of the image through the L2: 64 x 720p 24.0-25.5 us per pass
+    // (oh2 = 4 .. 8) against 24.9 for two single-level rolling passes; one frame 5.9-8.5 us against 6.5-7.3 for the tiled pass.
+    // Only the knobs build takes it (AGT_PYR4=1, AGT_PYR4_OH=n).
+#ifndef AGT_DEBUG_KNOBS
+    (void)ok; (void)frames;
+    return;
+#else
+    { static const int on = [] { const char* e = getenv("AGT_PYR4"); return e ? atoi(e) : 0; }(); if (!on) return; }
+    if (!ok) return;
+    // strip height (level-2 rows, even): ~3 waves on each SIMD where the launch has that many units, strips of at most 16 rows
+    // (73 level-0 rows: 14 % of them the halo), at least 2 (17 rows)
+    const long images = (long)A0.B * (frames > 0 ? frames : 1);
+    const int ncol = ((A0.sw >> 4) + agt_pyr4::TILE_GROUPS - 1) / agt_pyr4::TILE_GROUPS;
+    long per_image = (12288 + images - 1) / images;
+    long strips = (per_image + ncol - 1) / ncol;
+    if (strips < 1) strips = 1;
+    int oh = (int)(A1.dh / strips) & ~1;
+    oh = oh < 2 ? 2 : (oh > 16 ? 16 : oh);
+    { static const int f = [] { const char* e = getenv("AGT_PYR4_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = f & ~1; }
+    A0.pad = A1.pad = oh;
+    A0.gx = A1.gx = agt_pyr4::roll2_blocks(A0.sw, A1.dh, oh);
+    A0.gy = A1.gy = 1;
+#endif
+}
+
 // src (sw x sh) -> dst1 ((sw+1)/2 x (sh+1)/2) -> dst2, both written, one launch
 hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,
                                 uint8_t* dst1, long dpitch1, long dbatch1, uint8_t* dst2, long dpitch2, long dbatch2, int B)
 {
     AgtPyrArgs A0, A1;
     agt_pyr2_args(src, sw, sh, spitch, sbatch, dst1, dpitch1, dbatch1, dst2, dpitch2, dbatch2, B, &A0, &A1);
+    agt_pyr2_plan(&A0, &A1, (uintptr_t)src, (uintptr_t)dst1 | (uintptr_t)dst2, 1);
     const long tiles = (long)A0.gx * A0.gy * B;
+#ifdef AGT_DEBUG_KNOBS
+    if (A0.pad) hipLaunchKernelGGL(pyr_roll2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A0, A1);
+    else
+#endif
     hipLaunchKernelGGL(pyr_down2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr2::PYR2_LDS_BYTES, stream, A0, A1);
     return hipGetLastError();
 }

@@ -1,0 +1,184 @@
+// agt_pyramid4_body.h -- TWO pyrDown levels in one pass, register-rolling form: L0 -> L1 -> L2 with level 0 read once, levels 1
+// and 2 written once (the W * H * 1.3125 bytes of SURVEY.md section 8d), no LDS, no barriers.  Bit-identical to cv::pyrDown
+// applied twice (oracle: oracle/cv_lk.c cvo_pyr_down_u8); same arithmetic as agt_pyramid_body.h / agt_pyramid3_body.h.
+//
+// A 16-lane DPP row is one UNIT = (strip of `oh2` level-2 rows, column tile of 14 groups): lane q owns level-0 group
+// g = 14 c - 1 + q (16 source bytes per row) -- lanes 1..14 are the tile's interior, lanes 0 and 15 a one-group halo on either side
+// (every group is interior in exactly one tile).  Per lane and level-0 row: one 16-byte buffer load; horizontal sums (8 x u16) by
+// v_dot4_u32_u8 with the neighbours' bytes through DPP row shifts; a five-row rolling window -> one level-1 row (8 pixels) per two
+// level-0 rows, stored by the interior lanes AND fed (again through DPP: two level-1 pixels from the left neighbour, one from the
+// right -- which is all the halo lanes are for; their own missing neighbours never reach a value that is used) into a second
+// horizontal pass (4 x u16) and a second five-row window -> one level-2 row (4 pixels per lane) per two level-1 rows.
+// Per level-2 row a lane reads 64 bytes and spends ~200 VALU for 16 + 4 output pixels.
+// Redundancy: the halo lanes (16 / 14) and per strip 9 extra level-0 rows (level-1 rows 2 y2 - 2 .. 2 y2 + 2 of the strip's first and
+// last level-2 row need level-0 rows 4 y2 - 6 .. 4 y2 + 6): re-read through the XCD's L2, not from HBM.
+// Reflection: level-0 rows and the image's left / right edge as in agt_pyramid3_body.h; level-1 rows / columns outside the image
+// are reflections OF LEVEL 1 (pyrDown(L1) reflects L1, which differs from filtering reflected level-0 pixels): columns by the same
+// in-register trick on the level-1 bytes, rows by picking the reflected entry of the level-1 window (all of them are in it).
+// Both exist only in the EDGE form of the row loop (wave-uniform choice).
+#pragma once
+#include "agt_pyramid3_body.h"
+
+namespace agt_pyr4 {
+
+using namespace agt_pyr;
+using agt_pyr3::RING;
+using agt_pyr3::UNITS_PER_BLOCK;
+using agt_pyr3::u32x4;
+using agt_pyr3::v4u;
+using agt_pyr3::roll_reflect_row;
+
+constexpr int TILE_GROUPS = 14;     // interior groups per column tile
+
+// four horizontal [1 4 6 4 1] sums (u16) from the lane's 8 level-1 bytes (lo: pixels 0..3, hi: 4..7), the dword before (pm: its two
+// top bytes are pixels -2, -1) and the byte after (nx & 0xff: pixel 8) -> two registers
+__device__ __forceinline__ uint2 hgroup4(uint32_t lo, uint32_t hi, uint32_t pm, uint32_t nx)
+{
+    const uint32_t W4 = 0x04060401u;
+    const uint32_t e0 = __builtin_amdgcn_alignbyte(lo, pm, 2), e2 = __builtin_amdgcn_alignbyte(hi, lo, 2);
+    const uint32_t h0 = __builtin_amdgcn_udot4(e0, W4, (lo >> 16) & 0xff, false);      // centre pixel 0, fifth tap: pixel 2
+    const uint32_t h1 = __builtin_amdgcn_udot4(lo, W4, hi & 0xff, false);              // centre 2, fifth tap 4
+    const uint32_t h2 = __builtin_amdgcn_udot4(e2, W4, (hi >> 16) & 0xff, false);      // centre 4, fifth tap 6
+    const uint32_t h3 = __builtin_amdgcn_udot4(hi, W4, nx & 0xff, false);              // centre 6, fifth tap 8
+    return make_uint2(h0 | (h1 << 16), h2 | (h3 << 16));
+}
+
+// four vertical sums + (v + 128) >> 8 from five rows of four u16 -> four bytes
+__device__ __forceinline__ uint32_t vgroup4(uint2 r0, uint2 r1, uint2 r2, uint2 r3, uint2 r4)
+{
+    const uint32_t K4 = 0x00040004u, K6 = 0x00060006u, K128 = 0x00800080u;
+    auto col = [&](uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4) -> uint32_t {
+        uint32_t v = pk_mad(pk_add(a1, a3), K4, pk_add(a0, a4));
+        v = pk_mad(a2, K6, v);
+        return pk_shr8(pk_add(v, K128));
+    };
+    const uint32_t p0 = col(r0.x, r1.x, r2.x, r3.x, r4.x), p1 = col(r0.y, r1.y, r2.y, r3.y, r4.y);
+    return __builtin_amdgcn_perm(p1, p0, 0x06040200u);
+}
+
+// level-0 horizontal sums of one row (no edge dword: the halo lanes stand in for the tile's neighbours)
+__device__ __forceinline__ uint4 roll2_hrow(u32x4 d, bool left_edge, bool right_edge)
+{
+    // (the image's first group sits on lane 1 of tile 0, behind an idle halo lane: selected AFTER the shift, unlike agt_pyramid3_body.h)
+    uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d.w, 0x111, 0xf, 0xf, false);                     // row_shr:1
+    uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d.x, 0x101, 0xf, 0xf, false);                     // row_shl:1
+    pm = left_edge ? __builtin_amdgcn_perm(d.x, d.x, 0x01020000u) : pm;
+    nx = right_edge ? (d.w >> 16) : nx;
+    return hgroup8(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
+}
+
+template <bool EDGE, typename RS>
+__device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPyrArgs& A1, const RS rs, const RS r1, const RS r2,
+                                               int oy2, int g, int q, int G, bool lane_on)
+{
+    const int sh = A0.sh, h1 = A0.dh, h2 = A1.dh, oh2 = A0.pad;
+    const int pitch = (int)A0.spitch, pitch1 = (int)A0.dpitch, pitch2 = (int)A1.dpitch;
+    const int NR = 4 * oh2 + 9;                                  // level-0 rows of the strip
+    const int y1a = 2 * oy2 - 2;                                 // first level-1 row the strip computes (two halo rows above its own)
+    const int y0 = 2 * y1a - 2;                                  // first level-0 row
+    const bool left_edge = g == 0, right_edge = g == G - 1;
+    const bool writer = lane_on && q >= 1 && q <= TILE_GROUPS;   // interior lane: stores its level-1 and level-2 pixels
+    const int xoff = g * 16;
+    const int vbase = EDGE ? xoff : y0 * pitch + xoff;
+    u32x4 d[RING];
+#pragma unroll
+    for (int k = 0; k < RING; k++) d[k] = (u32x4)(0u);
+    auto issue = [&](int slot, int r) {
+        int vo = vbase, so = 0;
+        if constexpr (EDGE) vo = vbase + roll_reflect_row(y0 + r, sh) * pitch;
+        else so = r * pitch;
+        if (lane_on) { const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t); }
+    };
+    auto take = [&](int slot, int r) {                           // horizontal sums of strip row r (in `slot`), then refill the slot
+        const uint4 h = roll2_hrow(d[slot], left_edge, right_edge);
+        if (r + RING < NR) issue(slot, r + RING);
+        return h;
+    };
+    // level-1 row `i` of the strip (image row y1a + i) from the level-0 window: the pixels (two dwords), stored by the interior
+    // lanes if the row is the strip's own, and their horizontal sums for level 2
+    const int o1base = 2 * oy2 * pitch1 + g * 8;                   // (level-1 row i = 2: the strip's first own row; offsets stay non-negative)
+    auto level1 = [&](const uint4& a0, const uint4& a1, const uint4& a2, const uint4& a3, const uint4& a4, int i) {
+        const uint2 px = vgroup8(a0, a1, a2, a3, a4);
+        const int y1 = y1a + i;
+        if (writer && i >= 2 && i < 2 * oh2 + 2 && y1 < h1)
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, o1base, (i - 2) * pitch1, 0);
+        // neighbours' level-1 pixels: -2, -1 from the lane on the left, 8 from the lane on the right; the image's own edges
+        // reflect level 1 (pixel -2 = 2, -1 = 1; pixel w1 = w1 - 2)
+        uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)px.y, 0x111, 0xf, 0xf, false);
+        uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)px.x, 0x101, 0xf, 0xf, false);
+        pm = left_edge ? __builtin_amdgcn_perm(px.x, px.x, 0x01020000u) : pm;
+        nx = right_edge ? (px.y >> 16) : nx;
+        return hgroup4(px.x, px.y, pm, nx);
+    };
+#pragma unroll
+    for (int k = 0; k < RING; k++) issue(k, k);
+    // prologue: level-0 rows 0..8 -> level-1 rows 0, 1, 2
+    uint4 H0 = take(0, 0), H1 = take(1, 1), H2 = take(2, 2);
+    uint2 K0, K1, K2;
+    {
+        uint4 H3 = take(3, 3), H4 = take(4, 4);
+        K0 = level1(H0, H1, H2, H3, H4, 0); H0 = H2; H1 = H3; H2 = H4;
+        H3 = take(5, 5); H4 = take(6, 6);
+        K1 = level1(H0, H1, H2, H3, H4, 1); H0 = H2; H1 = H3; H2 = H4;
+        H3 = take(7, 7); H4 = take(0, 8);
+        K2 = level1(H0, H1, H2, H3, H4, 2); H0 = H2; H1 = H3; H2 = H4;
+    }
+    const int o2base = oy2 * pitch2 + g * 4;
+    for (int T = 0; T < oh2 / 2; T++) {
+#pragma unroll
+        for (int u = 0; u < 2; u++) {
+            const int j = 2 * T + u;                             // level-2 row of the strip
+            const int r = 9 + 4 * j;                             // its four new level-0 rows r .. r + 3: slots (1 + 4 u + k) % 8
+            uint4 H3 = take((1 + 4 * u) % RING, r), H4 = take((2 + 4 * u) % RING, r + 1);
+            const uint2 K3 = level1(H0, H1, H2, H3, H4, 3 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
+            H3 = take((3 + 4 * u) % RING, r + 2); H4 = take((4 + 4 * u) % RING, r + 3);
+            const uint2 K4 = level1(H0, H1, H2, H3, H4, 4 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
+            uint2 E0 = K0, E1 = K1, E3 = K3, E4 = K4;
+            if constexpr (EDGE) {
+                // level-1 rows outside the image: their reflections are in the window (centre row yc = 2 (oy2 + j))
+                const int yc = 2 * (oy2 + j);
+                const bool top = yc == 0, b1 = yc + 2 == h1, b2 = yc + 1 == h1;
+                E0.x = top ? K4.x : K0.x; E0.y = top ? K4.y : K0.y;
+                E1.x = top ? K3.x : K1.x; E1.y = top ? K3.y : K1.y;
+                E3.x = b2 ? K1.x : K3.x; E3.y = b2 ? K1.y : K3.y;
+                E4.x = b1 ? K2.x : (b2 ? K0.x : K4.x); E4.y = b1 ? K2.y : (b2 ? K0.y : K4.y);
+            }
+            const uint32_t o = vgroup4(E0, E1, K2, E3, E4);
+            if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, 0);
+            K0 = K2; K1 = K3; K2 = K4;
+        }
+    }
+}
+
+// One 256-thread workgroup = 16 units of the image at `img`.  A0: level 0 -> 1 geometry (A0.pad = level-2 rows per strip, even),
+// A1: level 1 -> 2 geometry.
+__device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPyrArgs& A1, int blk, const uint8_t* __restrict__ img,
+                                               uint8_t* __restrict__ out1, uint8_t* __restrict__ out2)
+{
+    const int tid = threadIdx.x, q = tid & 15;
+    const int G = A0.sw >> 4, ncol = (G + TILE_GROUPS - 1) / TILE_GROUPS, oh2 = A0.pad;
+    const int nstrip = (A1.dh + oh2 - 1) / oh2, units = nstrip * ncol;
+    const int u = blk * UNITS_PER_BLOCK + (tid >> 4);
+    const bool uvalid = u < units;
+    const int s = uvalid ? u / ncol : 0, c = uvalid ? u - s * ncol : 0;
+    const int g = c * TILE_GROUPS - 1 + q;
+    const bool lane_on = uvalid && g >= 0 && g < G;
+    const int oy2 = s * oh2;
+    const int y0 = 4 * oy2 - 6;
+    // EDGE: some level-0 row of the strip is outside the image, or some level-1 row its level-2 rows use is
+    const bool edge = uvalid && (y0 < 0 || y0 + 4 * oh2 + 8 > A0.sh - 1 || 2 * (oy2 + oh2 - 1) + 2 > A0.dh - 1);
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, A0.sh * (int)A0.spitch, 0x00020000);
+    const auto r1 = __builtin_amdgcn_make_buffer_rsrc(out1, 0, A0.dh * (int)A0.dpitch, 0x00020000);
+    const auto r2 = __builtin_amdgcn_make_buffer_rsrc(out2, 0, A1.dh * (int)A1.dpitch, 0x00020000);
+    if (__builtin_amdgcn_ballot_w64(uvalid) == 0) return;
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true>(A0, A1, rs, r1, r2, oy2, g, q, G, lane_on);
+    else pyr_roll2_rows<false>(A0, A1, rs, r1, r2, oy2, g, q, G, lane_on);
+}
+
+__host__ __device__ inline int roll2_blocks(int sw, int h2, int oh2)
+{
+    const int G = sw >> 4, ncol = (G + TILE_GROUPS - 1) / TILE_GROUPS, nstrip = (h2 + oh2 - 1) / oh2;
+    return (nstrip * ncol + UNITS_PER_BLOCK - 1) / UNITS_PER_BLOCK;
+}
+
+}  // namespace agt_pyr4

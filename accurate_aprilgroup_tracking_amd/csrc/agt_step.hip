@@ -16,6 +16,9 @@
 #include <cstddef>
 #include "agt_pyramid2_body.h"
 #include "agt_pyramid3_body.h"
+#ifdef AGT_DEBUG_KNOBS
+#include "agt_pyramid4_body.h"
+#endif
 #include "agt_lk_rs_body.h"
 #include "agt_lk_chain_body.h"
 #include "agt_pnp_body.h"
@@ -204,6 +207,13 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
                 A1.spitch = KS->pyr[1].spitch; A1.sbatch = KS->pyr[1].sbatch; A1.dpitch = KS->pyr[1].dpitch; A1.dbatch = KS->pyr[1].dbatch;
                 A1.sw = KS->pyr[1].sw; A1.sh = KS->pyr[1].sh; A1.dw = KS->pyr[1].dw; A1.dh = KS->pyr[1].dh;
                 A1.gx = A.gx; A1.gy = A.gy; A1.B = A.B;
+#ifdef AGT_DEBUG_KNOBS      // (the register-rolling two-level pass is not shipped: agt_pyramid.hip agt_pyr2_plan)
+                if (A.pad) {      // bx = workgroup of the image, no LDS
+                    agt_pyr4::pyr_roll2_body(A, A1, bx, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
+                                             KT->pyr_dst[1][fr] + (long)st * A1.dbatch);
+                    return;
+                }
+#endif
                 agt_pyr2::pyr_down2_body(A, A1, bx, by, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
                                          KT->pyr_dst[1][fr] + (long)st * A1.dbatch, lds);
                 return;
@@ -473,8 +483,16 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 #endif
     size_t lds = 0;
     int blocks = 0;
-    const size_t pyr_lds = P.pyr_fused ? (size_t)agt_pyr2::PYR2_LDS_BYTES : (size_t)agt_pyr::PYR_LDS_BYTES;
-    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) if (P.n_pyr[s] > 0) { blocks += P.n_pyr[s]; lds = lds > pyr_lds ? lds : pyr_lds; }
+    // (the register-rolling forms of the pyramid passes, pyr[s].pad != 0, use no LDS: a launch of them alone must not be held to
+    // the tiled kernels' occupancy)
+    size_t pyr_lds = 0;
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++)
+        if (P.n_pyr[s] > 0) {
+            blocks += P.n_pyr[s];
+            const size_t need = P.pyr[s].pad ? 0 : ((P.pyr_fused && s == 0) ? (size_t)agt_pyr2::PYR2_LDS_BYTES : (size_t)agt_pyr::PYR_LDS_BYTES);
+            pyr_lds = pyr_lds > need ? pyr_lds : need;
+        }
+    lds = pyr_lds;
     if (P.n_lk > 0) {
         const long corners = (long)P.lk.n * P.lk_B;
         P.n_lk = (int)((corners + CPB - 1) / CPB);

@@ -66,7 +66,11 @@ def _assert_lk_equal(o, g):
     assert np.array_equal(o[2].view(np.uint32), g[2].view(np.uint32)), "err not bit-identical"
 
 
-@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (1080, 1920), (97, 131), (200, 260), (150, 516), (257, 95), (131, 1030)])
+# (round 4: widths that are multiples of 16 on aligned pitches take the register-rolling two-level pass, agt_pyramid4_body.h: heights
+# whose level 1 / level 2 are odd, not a multiple of the strip height, one strip only; one column tile, a last tile of one group, a
+# last group on the halo lane of its tile (15 + 14 k groups); the padded pitch of the same shapes keeps the tiled pass)
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (1080, 1920), (97, 131), (200, 260), (150, 516), (257, 95), (131, 1030),
+                                   (270, 480), (101, 240), (99, 464), (96, 96), (135, 96), (100, 4112), (301, 1360), (89, 112)])
 def test_pyramid_build_all_levels_bit_exact(torch_cuda, cvh, oracle, shape):
     """agt_pyramid_build: levels 1 and 2 come from the two-level pass (L0 read once, L1 never re-read), deeper levels from
     single passes; every level of every stream must equal pyrDown applied level by level -- tile seams, image edges at
