@@ -209,3 +209,153 @@ def solve_pnp_noguess(obj, img, K, dist=None):
     r0, t0 = dlt_init(obj, img, K, dist)
     r, t, it = solve_pnp_guess(obj, img, K, dist, r0, t0)
     return r, t, it, (r0, t0)
+
+
+# ---- initialisation WITHOUT a guess, PLANAR object (first branch) and cv::findHomography (method 0) with its
+# LMSolver polish -- written in round 4 from the prose of Appendix B and from OpenCV 4.x's published fundam.cpp / levmarq.cpp as
+# recalled, NOT from oracle/cv_pnp.c: numpy.linalg.eigh for the 9 x 9 null vector, numpy.linalg.solve / pinv for the damped
+# systems, the LMSolver loop spelled out.  (test_oracle.py::test_pnp_planar_init_oracle_equals_numpy_statement)
+
+def homography_dlt(src, dst):
+    """HomographyEstimatorCallback::runKernel on float32 points: centroids, scale = 1 / mean absolute deviation per axis,
+    the symmetric 9 x 9 L^T L, its eigenvector of the smallest eigenvalue, de-normalised, divided by H[2, 2]"""
+    M = np.asarray(src, np.float32).astype(np.float64).reshape(-1, 2)
+    m = np.asarray(dst, np.float32).astype(np.float64).reshape(-1, 2)
+    n = M.shape[0]
+    cM, cm = M.mean(0), m.mean(0)
+    sM, sm = np.abs(M - cM).mean(0), np.abs(m - cm).mean(0)
+    if (np.concatenate([sM, sm]) < DBL_EPSILON).any():
+        return None
+    sM, sm = 1.0 / sM, 1.0 / sm
+    invHnorm = np.array([[1.0 / sm[0], 0, cm[0]], [0, 1.0 / sm[1], cm[1]], [0, 0, 1]])
+    Hnorm2 = np.array([[sM[0], 0, -cM[0] * sM[0]], [0, sM[1], -cM[1] * sM[1]], [0, 0, 1]])
+    LtL = np.zeros((9, 9))
+    for i in range(n):
+        x, y = (m[i] - cm) * sm
+        X, Y = (M[i] - cM) * sM
+        Lx = np.array([X, Y, 1, 0, 0, 0, -x * X, -x * Y, -x])
+        Ly = np.array([0, 0, 0, X, Y, 1, -y * X, -y * Y, -y])
+        LtL += np.outer(Lx, Lx) + np.outer(Ly, Ly)
+    w, V = np.linalg.eigh(LtL)
+    H0 = V[:, 0].reshape(3, 3)
+    H = invHnorm @ H0 @ Hnorm2
+    return H / H[2, 2]
+
+
+def _homography_residuals(h, M, m, jacobian):
+    """HomographyRefineCallback::compute: 2N residuals (projected - measured) and the 2N x 8 Jacobian w.r.t. h[0..7] (h[8] = 1)"""
+    Mx, My = M[:, 0], M[:, 1]
+    ww = 1.0 / (h[6] * Mx + h[7] * My + 1.0)
+    xi = (h[0] * Mx + h[1] * My + h[2]) * ww
+    yi = (h[3] * Mx + h[4] * My + h[5]) * ww
+    r = np.empty(2 * len(Mx))
+    r[0::2] = xi - m[:, 0]; r[1::2] = yi - m[:, 1]
+    if not jacobian:
+        return r, None
+    J = np.zeros((2 * len(Mx), 8))
+    J[0::2, 0] = Mx * ww; J[0::2, 1] = My * ww; J[0::2, 2] = ww
+    J[0::2, 6] = -Mx * ww * xi; J[0::2, 7] = -My * ww * xi
+    J[1::2, 3] = Mx * ww; J[1::2, 4] = My * ww; J[1::2, 5] = ww
+    J[1::2, 6] = -Mx * ww * yi; J[1::2, 7] = -My * ww * yi
+    return r, J
+
+
+def lm_solver(x, compute, max_iters, eps=FLT_EPSILON):
+    """cv::LMSolver::run (levmarq.cpp): Levenberg-Marquardt with the gain-ratio update of lambda (Rlo = 0.25, Rhi = 0.75),
+    damping lambda * diag(J^T J), steps accepted when the squared error falls; stops after max_iters, or when the step's
+    or the residual's largest component falls under eps"""
+    x = np.array(x, np.float64)
+    r, J = compute(x, True)
+    S = float(r @ r)
+    A = J.T @ J
+    v = J.T @ r
+    D = np.diag(A).copy()
+    Rlo, Rhi = 0.25, 0.75
+    lam, lc = 1.0, 0.75
+    it = 0
+    while True:
+        Ap = A + np.diag(lam * D)
+        d = np.linalg.pinv(Ap) @ v                      # solve(Ap, v, d, DECOMP_EIG): positive definite here
+        xd = x - d
+        rd, _ = compute(xd, False)
+        Sd = float(rd @ rd)
+        dS = float(d @ (2.0 * v - A @ d))
+        R = (S - Sd) / (dS if abs(dS) > DBL_EPSILON else 1.0)
+        if R > Rhi:
+            lam *= 0.5
+            if lam < lc:
+                lam = 0.0
+        elif R < Rlo:
+            t = float(d @ v)
+            nu = (Sd - S) / (t if abs(t) > DBL_EPSILON else 1.0) + 2.0
+            nu = min(max(nu, 2.0), 10.0)
+            if lam == 0.0:
+                Ai = np.linalg.pinv(A)
+                lam = lc = 1.0 / max(DBL_EPSILON, float(np.abs(np.diag(Ai)).max()))
+                nu *= 0.5
+            lam *= nu
+        if Sd < S:
+            S = Sd
+            x = xd
+            r, J = compute(x, True)
+            A = J.T @ J
+            v = J.T @ r
+        it += 1
+        if not (it < max_iters and np.abs(d).max() >= eps and np.abs(r).max() >= eps):
+            return x, it
+
+
+def find_homography(src, dst, refine=True):
+    """cv::findHomography(src, dst, 0): float32 points, normalised DLT, for more than four points the LMSolver polish (10
+    iterations) of the eight free entries, H[2, 2] = 1"""
+    H = homography_dlt(src, dst)
+    M = np.asarray(src, np.float32).astype(np.float64).reshape(-1, 2)
+    m = np.asarray(dst, np.float32).astype(np.float64).reshape(-1, 2)
+    if H is None or not refine or M.shape[0] <= 4:
+        return H
+    h, _ = lm_solver(H.reshape(9)[:8], lambda hh, jac: _homography_residuals(np.append(hh, 1.0), M, m, jac), 10)
+    return np.append(h, 1.0).reshape(3, 3)
+
+
+def rodrigues_matrix(R):
+    """cv::Rodrigues(matrix) through rodrigues_inv, then back: the orthonormalising round trip of the planar branch"""
+    r = rodrigues_inv(R)
+    return rodrigues(r)[0]
+
+
+def planar_init(obj, img, K, dist=None):
+    """Appendix B step 2, planar branch: rotate the object points into their plane (rows of V^T of the scatter's SVD, det forced
+    positive; identity when the plane is already z = const), homography plane -> normalised image, rotation from its first
+    two columns (normalised; third = their cross product; orthonormalised by a Rodrigues round trip), translation from the
+    third column scaled by 2 / (|h1| + |h2|) -> (rvec, tvec)"""
+    X = np.asarray(obj, np.float64).reshape(-1, 3)
+    Mc = X.mean(0)
+    d = X - Mc
+    _, w, Vt = np.linalg.svd(d.T @ d)
+    assert w[2] / w[1] < 1e-3
+    Rt = Vt.copy()
+    # numpy's singular vectors carry arbitrary signs; OpenCV's own choice does not matter downstream EXCEPT through det < 0 -> -V^T:
+    # a sign flip of a ROW pair leaves the final pose unchanged (the homography absorbs it), which the test asserts by value
+    if Rt[0, 2] ** 2 + Rt[1, 2] ** 2 < 1e-10:
+        Rt = np.eye(3)
+    if np.linalg.det(Rt) < 0:
+        Rt = -Rt
+    Tt = -Rt @ Mc
+    Mxy = (X @ Rt.T + Tt)[:, :2]
+    mn = undistort_points(img, K, dist)
+    H = find_homography(Mxy, mn)
+    h1n, h2n = np.linalg.norm(H[:, 0]), np.linalg.norm(H[:, 1])
+    h1 = H[:, 0] / max(h1n, DBL_EPSILON)
+    h2 = H[:, 1] / max(h2n, DBL_EPSILON)
+    t = H[:, 2] * (2.0 / max(h1n + h2n, DBL_EPSILON))
+    Rh = np.stack([h1, h2, np.cross(h1, h2)], axis=1)
+    Rh = rodrigues_matrix(Rh)
+    t = Rh @ Tt + t
+    R = Rh @ Rt
+    return rodrigues_inv(R), t
+
+
+def solve_pnp_noguess_planar(obj, img, K, dist=None):
+    r0, t0 = planar_init(obj, img, K, dist)
+    r, t, it = solve_pnp_guess(obj, img, K, dist, r0, t0)
+    return r, t, it, (r0, t0)
