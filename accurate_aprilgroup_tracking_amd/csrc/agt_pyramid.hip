@@ -100,6 +100,8 @@ void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintpt
     // test_pyramid_build_all_levels_bit_exact) but a strip of oh2 level-2 rows is a serial chain of 4 oh2 + 9 level-0 rows per lane with
     // 8 in flight, and short strips re-read (4 oh2 + 9) / (4 oh2) of the image through the L2: 64 x 720p 24.0-25.5 us per pass
     // (oh2 = 4 .. 8) against 24.9 for two single-level rolling passes; one frame 5.9-8.5 us against 6.5-7.3 for the tiled pass.
+    // A 16-row ring changes nothing: one frame takes 0.24 us per strip row at every ring depth (7.8 / 11.5 / 15.5 / 19.3 us at
+    // oh2 = 4 / 8 / 12 / 16) -- a wave's ~100 instructions per level-0 row are the chain, not the memory round trips.
     // Only the knobs build takes it (AGT_PYR4=1, AGT_PYR4_OH=n).
 #ifndef AGT_DEBUG_KNOBS
     (void)ok; (void)frames;
@@ -114,9 +116,10 @@ void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintpt
     long per_image = (12288 + images - 1) / images;
     long strips = (per_image + ncol - 1) / ncol;
     if (strips < 1) strips = 1;
-    int oh = (int)(A1.dh / strips) & ~1;
-    oh = oh < 2 ? 2 : (oh > 16 ? 16 : oh);
-    { static const int f = [] { const char* e = getenv("AGT_PYR4_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = f & ~1; }
+    constexpr int Q = agt_pyr4::L2_PER_TRIP;
+    int oh = (int)(A1.dh / strips) / Q * Q;
+    oh = oh < Q ? Q : (oh > 16 ? 16 : oh);
+    { static const int f = [] { const char* e = getenv("AGT_PYR4_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = (f + Q - 1) / Q * Q; }
     A0.pad = A1.pad = oh;
     A0.gx = A1.gx = agt_pyr4::roll2_blocks(A0.sw, A1.dh, oh);
     A0.gy = A1.gy = 1;

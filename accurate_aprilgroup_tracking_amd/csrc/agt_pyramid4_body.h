@@ -22,13 +22,19 @@
 namespace agt_pyr4 {
 
 using namespace agt_pyr;
-using agt_pyr3::RING;
 using agt_pyr3::UNITS_PER_BLOCK;
 using agt_pyr3::u32x4;
 using agt_pyr3::v4u;
 using agt_pyr3::roll_reflect_row;
 
 constexpr int TILE_GROUPS = 14;     // interior groups per column tile
+#ifndef AGT_PYR4_RING
+#define AGT_PYR4_RING 8
+#endif
+constexpr int RING = AGT_PYR4_RING; // level-0 rows in flight per lane (a strip is a serial chain of 4 oh2 + 9 rows per lane: the deeper
+                                    // the ring, the fewer memory round trips it takes); a loop trip consumes RING rows = RING / 4 level-2 rows
+constexpr int L2_PER_TRIP = RING / 4;
+static_assert(RING == 8 || RING == 16, "slot arithmetic below: the prologue consumes rows 0..8");
 
 // four horizontal [1 4 6 4 1] sums (u16) from the lane's 8 level-1 bytes (lo: pixels 0..3, hi: 4..7), the dword before (pm: its two
 // top bytes are pixels -2, -1) and the byte after (nx & 0xff: pixel 8) -> two registers
@@ -112,7 +118,7 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
     };
 #pragma unroll
     for (int k = 0; k < RING; k++) issue(k, k);
-    // prologue: level-0 rows 0..8 -> level-1 rows 0, 1, 2
+    // prologue: level-0 rows 0..8 -> level-1 rows 0, 1, 2 (row r lives in slot r % RING)
     uint4 H0 = take(0, 0), H1 = take(1, 1), H2 = take(2, 2);
     uint2 K0, K1, K2;
     {
@@ -120,18 +126,18 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         K0 = level1(H0, H1, H2, H3, H4, 0); H0 = H2; H1 = H3; H2 = H4;
         H3 = take(5, 5); H4 = take(6, 6);
         K1 = level1(H0, H1, H2, H3, H4, 1); H0 = H2; H1 = H3; H2 = H4;
-        H3 = take(7, 7); H4 = take(0, 8);
+        H3 = take(7, 7); H4 = take(8 % RING, 8);
         K2 = level1(H0, H1, H2, H3, H4, 2); H0 = H2; H1 = H3; H2 = H4;
     }
     const int o2base = oy2 * pitch2 + g * 4;
-    for (int T = 0; T < oh2 / 2; T++) {
+    for (int T = 0; T < oh2 / L2_PER_TRIP; T++) {
 #pragma unroll
-        for (int u = 0; u < 2; u++) {
-            const int j = 2 * T + u;                             // level-2 row of the strip
-            const int r = 9 + 4 * j;                             // its four new level-0 rows r .. r + 3: slots (1 + 4 u + k) % 8
-            uint4 H3 = take((1 + 4 * u) % RING, r), H4 = take((2 + 4 * u) % RING, r + 1);
+        for (int u = 0; u < L2_PER_TRIP; u++) {
+            const int j = L2_PER_TRIP * T + u;                   // level-2 row of the strip
+            const int r = 9 + 4 * j;                             // its four new level-0 rows r .. r + 3: slots (9 + 4 u + k) % RING
+            uint4 H3 = take((9 + 4 * u) % RING, r), H4 = take((10 + 4 * u) % RING, r + 1);
             const uint2 K3 = level1(H0, H1, H2, H3, H4, 3 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
-            H3 = take((3 + 4 * u) % RING, r + 2); H4 = take((4 + 4 * u) % RING, r + 3);
+            H3 = take((11 + 4 * u) % RING, r + 2); H4 = take((12 + 4 * u) % RING, r + 3);
             const uint2 K4 = level1(H0, H1, H2, H3, H4, 4 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
             uint2 E0 = K0, E1 = K1, E3 = K3, E4 = K4;
             if constexpr (EDGE) {

@@ -7,6 +7,13 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 
+# development aid: AGT_TEST_LIB=libagt_hip_knobs.so runs the suite on the knobs build (whose environment knobs select experimental
+# kernels, e.g. AGT_PYR4=1); the product library is the default and what the driver tests
+if os.environ.get("AGT_TEST_LIB"):
+    from accurate_aprilgroup_tracking_amd import hiplib as _hiplib
+    _hiplib.LIB_PATH = os.path.join(os.path.dirname(_hiplib.LIB_PATH), os.environ["AGT_TEST_LIB"])
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
 
