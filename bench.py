@@ -431,7 +431,7 @@ def main():
             # the copy stream of the H2D measurement -- would make two of them share a hardware queue and serialise)
             ring = bench.ring; bench.ring = None
             extras["batch64_hbm"] = batch_extra(torch, D, HL, args, rank, dev)
-            extras["pairs64_hbm"] = pairs_extra(torch, D, HL, args, rank, dev)
+            extras["pairs64_hbm"] = pairs_extra(args)
             bench.ring = ring
             bench.trk.pipeline(depth)
             extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
@@ -628,17 +628,29 @@ def batch_extra(torch, D, HL, args, rank, dev):
             "accepted_frac": round(ok, 4), "pose_err_vs_cpu": pose_err, "copies_bitwise_equal_to_their_seed_stream": bool(copies_ok)}
 
 
-def pairs_extra(torch, D, HL, args, rank, dev):
+def pairs_extra(args):
     """BASELINE.json configs[2] exactly as SURVEY.md 8d states it, on the driver-timed line: 64 COLD 1280x720 frame
-    pairs per step, both pyramids built, 169,638,912 algorithmic bytes per batch, 4 rotated batches (472 MiB of frames).  The
-    c3pairs workload's own measurement (bench_pairs.py) with 7 blocks of 128 steps; its CPU baseline runs with --workload c3pairs."""
-    from bench_pairs import measure_pairs
-    a = argparse.Namespace(**vars(args))
-    a.steps, a.warmup, a.blocks, a.streams, a.no_cpu_baseline = 128, 16, 7, 64, True
-    out = measure_pairs(a, torch, D, HL, WORKLOADS["c3pairs"], rank, 1, dev, False)
-    torch.cuda.empty_cache()
+    pairs per step, both pyramids built, 169,638,912 algorithmic bytes per batch, 4 rotated batches (450 MiB of frames) -- the
+    c3pairs workload's own measurement (bench_pairs.py), 7 blocks of 128 steps, run as a CHILD PROCESS of this command: it
+    pipelines its batches over four HIP streams and wants the process's four hardware queues to itself; in this process, whose
+    64-stream extra has created three library streams by now (or would create them afterwards), either measurement slowed the
+    other by 1.5-1.8x (82 instead of 56 us per step; 87-91 instead of 48 the other way round).  Its CPU baseline runs with
+    --workload c3pairs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AGT_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c3pairs", "--steps", "128", "--warmup", "16", "--blocks", "7",
+           "--render-frames", str(args.render_frames), "--no-cpu-baseline"]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode or not line:
+            return {"error": "child exited %d: %s" % (p.returncode, p.stderr[-300:])}
+        out = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
     keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "timing", "roofline", "max_abs_pose_err_vs_truth", "tracked_frac")
-    return {k: out[k] for k in keep}
+    res = {k: out[k] for k in keep}
+    res["note"] = "child process of this command (python bench.py --workload c3pairs --steps 128 --warmup 16 --blocks 7 --no-cpu-baseline)"
+    return res
 
 
 _native = []
