@@ -513,8 +513,10 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         // The one-wave-per-corner LK role as a group launch (in-kernel frame loop) is a measured dead end -- round 4, spill-free at
         // last (two frame loops in sequence instead of one with both tracker bodies): 64 streams 54.2 us per step against 42.1 with
         // per-frame launches in two half-batch chains, 24 streams 36.9 against 30.6; the corners that need 30 iterations need them
-        // in EVERY frame, so a corner's own chain over the group is as long as the chain of per-frame maxima.  Only the knobs build
-        // (AGT_SPLIT_LK_GROUP=2) still carries the instantiation.
+        // in EVERY frame, so a corner's own chain over the group is as long as the chain of per-frame maxima.  Sub-groups of 2 / 4 / 8
+        // frames per launch (to save the ~4 us launch boundary and ~2 us kernel start per frame) lose as well: 64 streams 55.3 / 52.4 /
+        // 51.5 us, 24 streams 39.9 / 37.5 / 35.9 against 30.7 -- inside the frame loop a frame costs the one-wave kernel ~10 us more
+        // than as a launch of its own.  Only the knobs build (AGT_SPLIT_LK_GROUP=2) still carries the instantiation.
         if constexpr (NW == 1) return hipErrorInvalidValue;
         else {
 #endif

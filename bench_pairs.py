@@ -142,10 +142,10 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         achieved = per[dom][0] / nlaunch / (kernel_us * 1e-6) / 1e9
         batch_bytes = B * pair_bytes(W, H, npts)
         whole = batch_bytes / (med / K) / 1e9
-        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down kernels (L0->L1, L1->L2 of both frames: 4 launches per step)", "lk": "lk_kernel<21,1,3> (one wave per corner)",
+        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_roll_kernel (pyrDown, register-rolling: L0->L1, L1->L2 of both frames: 4 launches per step)", "lk": "lk_kernel<21,1,3> (one wave per corner)",
                                            "pnp": "pnp_kernel<float,1>"}[dom],
                 "achieved": round(achieved, 3), "peak": B_.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / B_.HBM_PEAK_GBS, 6),
-                "traffic": B_.pmc_traffic({"pyramid": "pyr_down_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us),
+                "traffic": B_.pmc_traffic({"pyramid": "pyr_roll_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us),
                 "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(per[dom][0] / nlaunch),
                 "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / B_.HBM_PEAK_GBS, 4), "bytes_per_step": int(batch_bytes),
                                "frac_of_measured_copy_6290GBs": round(whole / 6290.0, 4)},

@@ -7,7 +7,7 @@ OUT=gpurun_out/${1:-r2prof}
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 mkdir -p "$OUT"
 run() { name=$1; shift; echo "== $name"; timeout -k 10 400 rocprofv3 "$@" > "$OUT/$name.stdout" 2> "$OUT/$name.stderr"; echo "rc=$?"; }
-run c2_stats  --kernel-trace --stats --output-format csv -d "$OUT/c2_stats"  -- python3 bench.py --no-cpu-baseline
+run c2_stats  --kernel-trace --stats --output-format csv -d "$OUT/c2_stats"  -- python3 bench.py --no-cpu-baseline --no-extras
 run c2k20_stats --kernel-trace --stats --output-format csv -d "$OUT/c2k20_stats" -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-extras
 run c3_stats  --kernel-trace --stats --output-format csv -d "$OUT/c3_stats"  -- python3 bench.py --workload c3 --steps 64 --warmup 16 --render-frames 8 --no-cpu-baseline --no-extras
 run c3pairs_stats --kernel-trace --stats --output-format csv -d "$OUT/c3pairs_stats" -- python3 bench.py --workload c3pairs --steps 100 --warmup 12 --no-cpu-baseline
