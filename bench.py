@@ -418,7 +418,7 @@ def main():
             kernel_us = float(stage_us[dom]) / launches
             achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
             whole = B * ab["frame"] / (med / K) / 1e9
-            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_down kernels", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
+            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_roll_kernel (register-rolling pyrDown: L0->L1 and L1->L2 launches)", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": None, "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(B * ab[names[dom]] / launches),
                     "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 4),

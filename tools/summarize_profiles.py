@@ -29,11 +29,11 @@ def full_grid(b, v):
     F = (b or {}).get("roofline", {}).get("frames_per_launch")
     B = (b or {}).get("config", {}).get("streams_per_gpu", 1)
     if F and (b or {}).get("config", {}).get("workload", "").startswith("c2"):
-        g = (48 * B + B + 60 * B * F) * 256
-        if any(x[1] == g for x in v):
-            return g
         g = (48 * B + B) * 256          # a block of F frames: the pyramid goes out as its own launch, the chained launch carries LK | PnP only
         if sum(1 for x in v if x[1] == g) >= 2 and F == (b or {}).get("steps"):
+            return g                    # (checked FIRST: such a run also holds one launch with the pyramid role riding -- rounds 2 / 3 sampled that one)
+        g = (48 * B + B + 60 * B * F) * 256
+        if any(x[1] == g for x in v):
             return g
     tot = defaultdict(float)
     for x in v: tot[x[1]] += x[0]
@@ -100,10 +100,20 @@ for run, ks in pmc.items():
     for k, e in ks.items():
         if not k.startswith("step_kernel<21, 4, 3") or "FETCH_SIZE_KiB_mean" not in e or "WRITE_SIZE_KiB_mean" not in e or not F:
             continue
+        fetch, write, parts, label = e["FETCH_SIZE_KiB_mean"], e["WRITE_SIZE_KiB_mean"], None, "%d frames per chained launch (full launches only)" % F
+        b_run = bench_line(run + "_fetch")
+        if b_run and b_run.get("steps") == F and "pyr_group_kernel" in ks:
+            # driver-style blocks of F frames: per block ONE pyramid launch (pyr_group_kernel) + ONE chained LK | PnP launch; the block's
+            # traffic is the sum of the two
+            pg = ks["pyr_group_kernel"]
+            parts = {"pyr_group_kernel": {"FETCH": pg["FETCH_SIZE_KiB_mean"], "WRITE": pg["WRITE_SIZE_KiB_mean"]},
+                     "step_kernel (LK | PnP)": {"FETCH": fetch, "WRITE": write}}
+            fetch += pg["FETCH_SIZE_KiB_mean"]; write += pg["WRITE_SIZE_KiB_mean"]
+            label = "blocks of %d frames (driver style): per block ONE pyramid launch (pyr_group_kernel) + ONE chained LK | PnP launch (step_kernel, 49 workgroups); the figures are the sum of the two" % F
         traffic["step_kernel<21,4,3> depth %d" % F] = {
-            "workload": "c2: 1 x 1280x720 stream, %d frames per chained launch (full launches only)" % F,
-            "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": e["FETCH_SIZE_KiB_mean"], "WRITE_SIZE_KiB_mean": e["WRITE_SIZE_KiB_mean"],
-            "traffic_bytes_per_launch": int(round((2 * e["FETCH_SIZE_KiB_mean"] + e["WRITE_SIZE_KiB_mean"]) * 1024)),
+            "workload": "c2: 1 x 1280x720 stream, " + label, "parts_KiB": parts,
+            "dispatches": e["dispatches_fetch"], "FETCH_SIZE_KiB_mean": round(fetch, 1), "WRITE_SIZE_KiB_mean": round(write, 1),
+            "traffic_bytes_per_launch": int(round((2 * fetch + write) * 1024)),
             "algorithmic_bytes_per_launch": 1441008 * F, "build": PFX + " final (chained launch, frame-chained LK role)",
             # launch period bench.py measured (HIP events) in the run the counters were taken in: bench.py withholds the figure
             # when its own launch period has moved away from this by more than 15 %
