@@ -944,7 +944,7 @@ static int ms_join(agt_ctx* c)
 
 // pyrDown.. -> LK -> PnP (+ dense stage) as separate launches on the context's stream: pose complete in stream order
 // next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
-// stream stride -- its two-level pyramid pass rides in this frame's first dense launch (agt_dense.hip) instead of being the
+// stream stride -- its two-level pyramid pass rides in this frame's PnP launch (more than 64 corners) or second dense launch (agt_dense.hip) instead of being the
 // first launch of its own chain.
 static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                        double* d_state_out, double* d_dense_out, hipEvent_t* pev, const uint8_t* next_frame = nullptr)
@@ -1391,7 +1391,7 @@ int agt_track_frame_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
 }
 
 // `count` consecutive frames of the stream(s), frame k at d_frames + k * frame_stride: agt_track_frame_dense for each, in order.
-// Knowing the next frame, the library lets its pyramid pass ride in the current frame's first dense launch (agt_dense.hip) --
+// Knowing the next frame, the library lets its pyramid pass ride in the current frame's four-wave PnP launch or second dense launch (step_serial) --
 // same records, one launch less in every frame's serial chain.
 int agt_track_frames_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
                            double* d_state_out, double* d_dense_out)

@@ -86,7 +86,7 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP, dense GN)",
                "data": "synthetic",
                "config": {"workload": wl["label"] % B, "streams_per_gpu": B, "dense_samples": M, "gn_iterations": ITERS, "photo_weight": PHOTO_WEIGHT,
-                          "corner_reseed": True, "launch": ("stage kernels in stream order; frames handed over as clips (agt_track_frames_dense): %d launches per frame, the next frame's pyramid pass rides in the first dense launch" % (2 + ITERS + 1)) if bench.clips else ("stage kernels in stream order, one call per frame (%d launches per frame)" % (3 + ITERS + 1))},
+                          "corner_reseed": True, "launch": ("stage kernels in stream order; frames handed over as clips (agt_track_frames_dense): %d launches per frame, the next frame's pyramid pass rides in the four-wave PnP launch" % (2 + ITERS + 1)) if bench.clips else ("stage kernels in stream order, one call per frame (%d launches per frame)" % (3 + ITERS + 1))},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
                "roofline": roof, "cpu_baseline": cpu, "accepted_frac": round(accepted, 4),

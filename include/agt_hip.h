@@ -301,7 +301,8 @@ int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, s
 /* A clip of `count` consecutive frames (frame k at d_frames + k * frame_stride; all with the same pitch and stream stride):
  * agt_track_frame_dense for each, in order, d_state_out [count][B][AGT_STATE_STRIDE] (or NULL), d_dense_out
  * [count][B][AGT_DENSE_STRIDE].  Same records as `count` single calls; knowing the next frame, the library lets its pyramid
- * pass ride in the current frame's first dense launch (one launch less in every frame's serial chain). */
+ * pass ride in one of the current frame's launches -- the four-wave PnP launch when there are more than 64 corners, else the SECOND
+ * dense launch (one launch less in every frame's serial chain). */
 int agt_track_frames_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
                            double* d_state_out, double* d_dense_out);
 
