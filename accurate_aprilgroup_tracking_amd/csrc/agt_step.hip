@@ -10,7 +10,13 @@
 // buffers the serial order would give it (rings of 4 in the context).
 //
 // Bodies: agt_pyramid_body.h, agt_lk_body.h, agt_pnp_body.h (shared with the stand-alone kernels).
+#ifdef AGT_STEP_LK_STAMPS       // experiment builds only: the LK role's in-kernel stamps under their own symbol (tools/_exp)
+#define AGT_LK_STAMPS
+#define agt_lk_stamps agt_lk_stamps_step
+#define agt_debug_lk_stamps agt_debug_lk_stamps_step
+#else
 #undef AGT_LK_STAMPS
+#endif
 #undef AGT_PNP_STAMPS
 #include <cstdlib>
 #include <cstddef>
@@ -167,13 +173,26 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
             const int alive = k ? pst : (S.lk.prev_status ? S.lk.prev_status[pidx] : 1);
             if (!agt_uniform((int)(alive != 0 && !(S.lk.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, S.lk.max_level, S.lk.prev[0].w, S.lk.prev[0].h))))
                 break;
+#ifdef AGT_STEP_LK_STAMPS
+            const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
+#endif
             const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
             agt_lk::lk_body_rs<NW, NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
+#ifdef AGT_STEP_LK_STAMPS
+            if ((threadIdx.x & 63) == 0) {       // experiment: slowest / summed per-frame time over all corners, frames in the row-segment loop
+                const unsigned long long dt = __builtin_amdgcn_s_memtime() - tq0;
+                atomicMax(&agt_lk_stamps[40 + (k < 15 ? k : 15)], dt);
+                atomicAdd(&agt_lk_stamps[56], dt); atomicAdd(&agt_lk_stamps[57], 1ull);
+            }
+#endif
         }
     }
     for (; k < S.lk_nf; k++) {
         const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
         agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
+#ifdef AGT_STEP_LK_STAMPS
+        if ((threadIdx.x & 63) == 0) atomicAdd(&agt_lk_stamps[58], 1ull);
+#endif
     }
 }
 
