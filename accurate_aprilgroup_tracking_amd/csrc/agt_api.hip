@@ -828,8 +828,8 @@ static int launch_group(agt_ctx* c, int B)
     return AGT_OK;
 }
 
-// Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
-static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+// The part of registering frame T+1 that comes before the registration itself: ring modulus of the mode, a free ring entry.
+static int pipelined_entry(agt_ctx* c, int B)
 {
     c->prebuilt_t = -1;
     // ring modulus of this mode: (L + 2) groups, plus the split mode's slack when the entries are available
@@ -860,6 +860,15 @@ static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
             if (c->n_pnp + c->n_lk + c->n_stage[0] == before) return AGT_ERR_STATE;      // (cannot happen: work was pending)
         }
     }
+    return AGT_OK;
+}
+
+// Register frame T+1 of the fused pipeline; a launch goes out once `group` frames wait for their first stage.
+static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B, double* d_state_out)
+{
+    int rc = pipelined_entry(c, B);
+    if (rc) return rc;
+    const long t = c->trk_frame + 1;
     const int slot = (int)(t % c->live_ring);
     c->l0_ptr[slot] = d_frames; c->l0_pitch[slot] = (long)pitch; c->l0_bstride[slot] = (long)batch_stride;
     c->built_B[slot] = B;
@@ -868,6 +877,31 @@ static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
     const long first_done = c->eff_max_level > 0 ? c->n_stage[0] : c->n_lk;
     if (t - first_done < c->group) return AGT_OK;
     return launch_group(c, B);
+}
+
+// Frame T+1 of ONE stream arrives in pinned HOST memory (h_dev: its device address): upload and pyramid in one launch -- the
+// two-level register-rolling pass reads the frame over PCIe, stores its level 0 to d_gray and levels 1 / 2 to the frame's ring
+// entry (agt_pyramid.hip agt_launch_pyr_upload2) -- and the frame is registered with its pyramid stages done; the LK | PnP launch
+// follows at the join as ever.  Returns 1 when the form does not apply (geometry, pyramid work of earlier frames still pending):
+// nothing has been enqueued for the frame then and the caller copies and calls agt_track_frame.
+static int step_pipelined_uploaded(agt_ctx* c, const uint8_t* h_dev, uint8_t* d_gray, size_t gpitch, double* d_state_out)
+{
+    if (c->eff_max_level != 2 || c->trk_B != 1) return 1;
+    int rc = pipelined_entry(c, 1);
+    if (rc) return rc;
+    const long t = c->trk_frame + 1;
+    if (c->n_stage[0] != t - 1 || c->n_stage[1] != t - 1) return 1;
+    const int slot = (int)(t % c->live_ring);
+    const int W = c->cfg.width, H = c->cfg.height;
+    hipError_t e = agt_launch_pyr_upload2(c->stream, h_dev, W, H, (long)W, d_gray, (long)gpitch, c->lmem[slot][1], c->lpitch[1], c->lmem[slot][2], c->lpitch[2]);
+    if (e == hipErrorInvalidValue) { (void)hipGetLastError(); return 1; }
+    if (e != hipSuccess) return hip_fail(c, e);
+    c->l0_ptr[slot] = d_gray; c->l0_pitch[slot] = (long)gpitch; c->l0_bstride[slot] = (long)gpitch * H;
+    c->built_B[slot] = 1;
+    c->so_ring[slot] = d_state_out;
+    c->trk_frame = t;
+    c->n_stage[0] = c->n_stage[1] = t;
+    return AGT_OK;
 }
 
 // Drain the software pipeline: enqueue the remaining stages of every frame supplied so far.
@@ -1110,11 +1144,30 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
 #else
 #define AGT_TQ(i)
 #endif
+    bool registered = false;
     if (channels == 1) {
         if (src_w != W || src_h != H || roi_x || roi_y || undistort) return AGT_ERR_ARG;
-        if (gpitch == (size_t)W) e = hipMemcpyAsync(d_gray, h_frame, (size_t)W * H, hipMemcpyHostToDevice, c->stream);
-        else e = hipMemcpy2DAsync(d_gray, gpitch, h_frame, (size_t)W, (size_t)W, (size_t)H, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) return hip_fail(c, e);
+        // Round 4: a gray frame in PINNED host memory is not copied first: the two-level pyramid pass reads it over PCIe and writes its
+        // level 0 to d_gray on the way (step_pipelined_uploaded) -- one launch instead of a copy-engine transfer (19 us + ~8 us of
+        // submission and hand-over) and a pyramid launch (6 us).  Pageable memory, frame sizes the rolling pass does not take, the
+        // stage-by-stage mode and pending pyramid work of earlier frames keep the copy.
+        if (c->pipeline && !c->reproject && agt_step_fits(c->trk_n, 1) && !(c->prof_ev && c->prof_n < c->prof_cap)) {
+            // (the device address of the caller's buffer, asked for on EVERY call: a cached answer would outlive the buffer)
+            hipPointerAttribute_t at;
+            const uint8_t* h_dev = nullptr;
+            if (hipPointerGetAttributes(&at, h_frame) == hipSuccess && at.type == hipMemoryTypeHost) h_dev = (const uint8_t*)at.devicePointer;
+            else (void)hipGetLastError();
+            if (h_dev) {
+                int rcu = step_pipelined_uploaded(c, h_dev, d_gray, gpitch, d_state);
+                if (rcu < 0) return rcu;
+                registered = rcu == AGT_OK;
+            }
+        }
+        if (!registered) {
+            if (gpitch == (size_t)W) e = hipMemcpyAsync(d_gray, h_frame, (size_t)W * H, hipMemcpyHostToDevice, c->stream);
+            else e = hipMemcpy2DAsync(d_gray, gpitch, h_frame, (size_t)W, (size_t)W, (size_t)H, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) return hip_fail(c, e);
+        }
     } else {
         if (!d_staging) return AGT_ERR_ARG;
         e = hipMemcpyAsync(d_staging, h_frame, (size_t)src_w * src_h * 3, hipMemcpyHostToDevice, c->stream);
@@ -1124,7 +1177,7 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
         if (rc) return rc;
     }
     AGT_TQ(1);
-    int rc = agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_state);
+    int rc = registered ? AGT_OK : agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_state);
     if (rc) return rc;
     AGT_TQ(2);
     rc = join_pipeline(c);

@@ -145,6 +145,8 @@ struct AgtProjParams {
 
 void agt_pyr_grid(int dw, int dh, int* gx, int* gy);
 void agt_pyr_plan(AgtPyrArgs* A, uintptr_t src_align, uintptr_t dst_align, int frames);
+hipError_t agt_launch_pyr_upload2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, uint8_t* copy, long cpitch,
+                                  uint8_t* dst1, long dpitch1, uint8_t* dst2, long dpitch2);     // fused upload + two-level pyramid of one frame (agt_pyramid.hip)
 void agt_pyr2_plan(AgtPyrArgs* A0, AgtPyrArgs* A1, uintptr_t src_align, uintptr_t dst_align, int frames);     // the same for the two-level pass      // tiled or register-rolling form of one pyrDown pass (agt_pyramid.hip)
 void agt_pyr2_grid(int w2, int h2, int* gx, int* gy);           // tile grid of the two-level pass (64 x 16 tiles of L2)
 int agt_pyr2_lds_bytes(void);

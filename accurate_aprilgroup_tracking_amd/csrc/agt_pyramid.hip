@@ -4,9 +4,7 @@
 #include <cstdlib>
 #include "agt_pyramid2_body.h"
 #include "agt_pyramid3_body.h"
-#ifdef AGT_DEBUG_KNOBS
 #include "agt_pyramid4_body.h"
-#endif
 
 namespace {
 
@@ -48,6 +46,16 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down2_kernel(const AgtPyrArgs
     const int by = r / A0.gx;
     agt_pyr2::pyr_down2_body(A0, A1, r - by * A0.gx, by, A0.src + (long)bz * A0.sbatch, A0.dst + (long)bz * A0.dbatch,
                              A1.dst + (long)bz * A1.dbatch, lds);
+}
+
+// Fused upload (agt_track_host_frame): ONE gray frame read from pinned host memory (A0.src: its device address), level 0 copied to
+// HBM (`copy`), levels 1 and 2 written -- the two-level register-rolling pass with COPY (agt_pyramid4_body.h)
+__global__ __launch_bounds__(agt_pyr::NT) void pyr_upload2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1, uint8_t* copy, const int cpitch)
+{
+    const int per_xcd = (int)gridDim.x >> 3;
+    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    if (t >= A0.gx) return;
+    agt_pyr4::pyr_roll2_body<true>(A0, A1, t, A0.src, A0.dst, A1.dst, copy, cpitch);
 }
 
 #ifdef AGT_DEBUG_KNOBS
@@ -124,6 +132,27 @@ void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintpt
     A0.gx = A1.gx = agt_pyr4::roll2_blocks(A0.sw, A1.dh, oh);
     A0.gy = A1.gy = 1;
 #endif
+}
+
+// Fused upload + two-level pyramid of ONE frame: src = device address of the caller's gray frame in pinned host memory; copy = the
+// frame's level 0 in HBM.  hipErrorInvalidValue when the geometry does not fit the rolling form (the caller then copies and builds).
+hipError_t agt_launch_pyr_upload2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, uint8_t* copy, long cpitch,
+                                  uint8_t* dst1, long dpitch1, uint8_t* dst2, long dpitch2)
+{
+    AgtPyrArgs A0, A1;
+    agt_pyr2_args(src, sw, sh, spitch, 0, dst1, dpitch1, 0, dst2, dpitch2, 0, 1, &A0, &A1);
+    const bool ok = (((uintptr_t)src | (uintptr_t)spitch | (uintptr_t)sw | (uintptr_t)copy | (uintptr_t)cpitch) & 15) == 0 &&
+                    (((uintptr_t)dst1 | (uintptr_t)dpitch1) & 7) == 0 && (((uintptr_t)dst2 | (uintptr_t)dpitch2) & 3) == 0 &&
+                    sw >= 32 && sh >= 32 && (long)sh * spitch < (1L << 31) && (long)sh * cpitch < (1L << 31) && (long)A0.dh * dpitch1 < (1L << 31);
+    if (!ok) return hipErrorInvalidValue;
+    // two level-2 rows per strip (17 level-0 rows a lane): the most units one frame gives, measured 22.9 us from pinned host memory
+    // (4: 24.7, 8: 26.2); the rows a strip reads twice come out of the L2, not over PCIe again
+    const int oh = agt_pyr4::L2_PER_TRIP;
+    A0.pad = A1.pad = oh;
+    A0.gx = A1.gx = agt_pyr4::roll2_blocks(sw, A1.dh, oh);
+    A0.gy = A1.gy = 1;
+    hipLaunchKernelGGL(pyr_upload2_kernel, dim3((unsigned)((A0.gx + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A0, A1, copy, (int)cpitch);
+    return hipGetLastError();
 }
 
 // src (sw x sh) -> dst1 ((sw+1)/2 x (sh+1)/2) -> dst2, both written, one launch

@@ -16,6 +16,10 @@
 // are reflections OF LEVEL 1 (pyrDown(L1) reflects L1, which differs from filtering reflected level-0 pixels): columns by the same
 // in-register trick on the level-1 bytes, rows by picking the reflected entry of the level-1 window (all of them are in it).
 // Both exist only in the EDGE form of the row loop (wave-uniform choice).
+// Shipped use (round 4): the FUSED UPLOAD of agt_track_host_frame -- the pass reads a gray frame straight from pinned host memory
+// (one frame: 22.9 us for both levels, PCIe-bound, against a 19 us copy-engine transfer + ~8 us of its submission + a 6 us pyramid
+// launch) and stores the frame's level 0 to HBM on the way (COPY).  As a plain HBM -> HBM pass it is not faster than what it would
+// replace (agt_pyramid.hip agt_pyr2_plan) and stays a knobs-build experiment there.
 #pragma once
 #include "agt_pyramid3_body.h"
 
@@ -73,8 +77,11 @@ __device__ __forceinline__ uint4 roll2_hrow(u32x4 d, bool left_edge, bool right_
     return hgroup8(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
 }
 
-template <bool EDGE, typename RS>
-__device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPyrArgs& A1, const RS rs, const RS r1, const RS r2,
+// COPY: the level-0 rows the strip owns (4 oy2 .. 4 oy2 + 4 oh2 - 1; interior lanes) are also stored to `rc` (pitch cpitch): the
+// source then is the caller's frame in pinned HOST memory, read over PCIe exactly once per byte that matters, and the copy is the
+// frame's level 0 in HBM -- upload and pyramid in one pass (agt_track_host_frame).
+template <bool EDGE, bool COPY, typename RS>
+__device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPyrArgs& A1, const RS rs, const RS r1, const RS r2, const RS rc, int cpitch,
                                                int oy2, int g, int q, int G, bool lane_on)
 {
     const int sh = A0.sh, h1 = A0.dh, h2 = A1.dh, oh2 = A0.pad;
@@ -96,6 +103,11 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         if (lane_on) { const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t); }
     };
     auto take = [&](int slot, int r) {                           // horizontal sums of strip row r (in `slot`), then refill the slot
+        if constexpr (COPY) {
+            const int y = y0 + r;
+            if (writer && r >= 6 && r < 4 * oh2 + 6 && y < sh)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, d[slot]), rc, y * cpitch + xoff, 0, 0);
+        }
         const uint4 h = roll2_hrow(d[slot], left_edge, right_edge);
         if (r + RING < NR) issue(slot, r + RING);
         return h;
@@ -158,8 +170,9 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
 
 // One 256-thread workgroup = 16 units of the image at `img`.  A0: level 0 -> 1 geometry (A0.pad = level-2 rows per strip, even),
 // A1: level 1 -> 2 geometry.
+template <bool COPY = false>
 __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPyrArgs& A1, int blk, const uint8_t* __restrict__ img,
-                                               uint8_t* __restrict__ out1, uint8_t* __restrict__ out2)
+                                               uint8_t* __restrict__ out1, uint8_t* __restrict__ out2, uint8_t* copy = nullptr, int cpitch = 0)
 {
     const int tid = threadIdx.x, q = tid & 15;
     const int G = A0.sw >> 4, ncol = (G + TILE_GROUPS - 1) / TILE_GROUPS, oh2 = A0.pad;
@@ -176,9 +189,10 @@ __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPy
     const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(img), 0, A0.sh * (int)A0.spitch, 0x00020000);
     const auto r1 = __builtin_amdgcn_make_buffer_rsrc(out1, 0, A0.dh * (int)A0.dpitch, 0x00020000);
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc(out2, 0, A1.dh * (int)A1.dpitch, 0x00020000);
+    const auto rc = __builtin_amdgcn_make_buffer_rsrc(COPY ? copy : out2, 0, COPY ? A0.sh * cpitch : 0, 0x00020000);
     if (__builtin_amdgcn_ballot_w64(uvalid) == 0) return;
-    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true>(A0, A1, rs, r1, r2, oy2, g, q, G, lane_on);
-    else pyr_roll2_rows<false>(A0, A1, rs, r1, r2, oy2, g, q, G, lane_on);
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true, COPY>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on);
+    else pyr_roll2_rows<false, COPY>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on);
 }
 
 __host__ __device__ inline int roll2_blocks(int sw, int h2, int oh2)
