@@ -67,6 +67,10 @@ struct agt_ctx {
     int reproject, min_points, tag_gate;
     double gate_px;
     int* fault_host; int* fault_dev;         // host-mapped word a chained launch sets when a wait gave up (agt_synchronize reports it)
+    // agt_track_host_frame: the frame's record and a sequence word in host-mapped memory (same allocation as the fault word: +64 the
+    // record, +192 the word); seq(frame t) = hseq_off + t, monotonic across resets and rewinds
+    double* hrec_host; double* hrec_dev; unsigned long long* hseq_host; unsigned long long* hseq_dev;
+    unsigned long long hseq_off, hseq_last; int host_seq_on;
     // LK parameters of the fused step (COUNT+EPS (30, 0.01), minEig 1e-4, flags 0)
     int lk_max_count; double lk_eps; double lk_min_eig;
     // undistortion maps of the pre-processing stage (built once per camera)
@@ -208,8 +212,12 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     ok = ok && hipMalloc((void**)&c->tstate, B * sizeof(AgtTrackState)) == hipSuccess;
     ok = ok && hipMalloc((void**)&c->lk_done, (size_t)AGT_RING_MAX * B * sizeof(unsigned)) == hipSuccess;
     ok = ok && hipMemset(c->lk_done, 0, (size_t)AGT_RING_MAX * B * sizeof(unsigned)) == hipSuccess;
-    ok = ok && hipHostMalloc((void**)&c->fault_host, 64, hipHostMallocMapped) == hipSuccess;
-    if (ok) { *c->fault_host = 0; ok = hipHostGetDevicePointer((void**)&c->fault_dev, c->fault_host, 0) == hipSuccess; }
+    ok = ok && hipHostMalloc((void**)&c->fault_host, 256, hipHostMallocMapped) == hipSuccess;
+    if (ok) { memset(c->fault_host, 0, 256); ok = hipHostGetDevicePointer((void**)&c->fault_dev, c->fault_host, 0) == hipSuccess; }
+    if (ok) {
+        c->hrec_host = (double*)((char*)c->fault_host + 64); c->hrec_dev = (double*)((char*)c->fault_dev + 64);
+        c->hseq_host = (unsigned long long*)((char*)c->fault_host + 192); c->hseq_dev = (unsigned long long*)((char*)c->fault_dev + 192);
+    }
     if (!ok) { hip_fail(nullptr, hipGetLastError()); agt_destroy(c); return AGT_ERR_ALLOC; }
     c->last_p_ev = -1; c->l_ev_hist[0] = c->l_ev_hist[1] = c->l_ev_hist[2] = -1; c->y_ev_hist[0] = c->y_ev_hist[1] = -1;
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
@@ -485,6 +493,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     memset(c->lk_target, 0, sizeof(c->lk_target));
     if (e != hipSuccess) return hip_fail(c, e);
     c->prebuilt_t = -1;
+    c->hseq_off = c->hseq_last + 1;          // (sequence numbers of agt_track_host_frame stay monotonic across runs)
     c->trk_n = n; c->trk_B = B; c->trk_frame = 0; c->n_lk = c->n_pnp = 0; c->enhance_ape = enhance_ape ? 1 : 0;
     for (int s = 0; s < AGT_MAX_LEVELS; s++) c->n_stage[s] = 0;
     c->trk_ready = d_corners ? 2 : 1;
@@ -554,6 +563,14 @@ static void fill_estimate(const agt_ctx* c, AgtPnpParams* p, const float* d_img,
     p->track = c->tstate; p->state_out = d_state_out; p->corners_rw = corners_rw; p->status_rw = status_rw;
     p->enhance_ape = c->enhance_ape; p->reproject = c->reproject; p->min_points = c->min_points; p->gate_px = c->gate_px;
     p->tag_gate = c->tag_gate; p->fault = c->fault_dev;
+}
+
+// the solver of the launch's first frame `frame` (tracker frame index) reports to the polling host thread (agt_track_host_frame)
+static void arm_host_seq(agt_ctx* c, AgtPnpParams* p, long frame)
+{
+    if (!c->host_seq_on) return;
+    p->host_seq = c->hseq_dev;
+    p->host_seq_base = c->hseq_off + (unsigned long long)frame;
 }
 
 static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slot, const float* d_prev, const uint8_t* d_prev_status, float* d_next,
@@ -687,6 +704,7 @@ static int launch_group(agt_ctx* c, int B)
         if (cnt > F) cnt = F;
         const int slot = (int)((c->n_pnp + 1) % M);
         fill_estimate(c, &S.pnp, c->corners[slot], c->status[slot], c->so_ring[slot], nullptr);
+        arm_host_seq(c, &S.pnp, c->n_pnp + 1);
         for (long k = 0; k < cnt; k++) {
             const long f = c->n_pnp + 1 + k;
             const int q = (int)(f % M);
@@ -1036,6 +1054,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     if (pev) (void)hipEventRecord(pev[2], M);
     AgtPnpParams p;
     fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
+    arm_host_seq(c, &p, t);
     if (d_dense_out) {
         rc = dense_scratch(c, agt_dense_doubles(c->dn_M, B), B);
         if (rc) return rc;
@@ -1128,7 +1147,7 @@ int agt_track_frame_detected(agt_ctx* c, const uint8_t* d_frames, size_t pitch, 
 int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int src_w, int src_h, uint8_t* d_staging,
                          int undistort, int roi_x, int roi_y, uint8_t* d_gray, size_t gpitch, double* d_state, double* h_state)
 {
-    if (!c || !h_frame || !d_gray || !d_state || !h_state || (channels != 1 && channels != 3)) return AGT_ERR_ARG;
+    if (!c || !h_frame || !d_gray || !h_state || (channels != 1 && channels != 3)) return AGT_ERR_ARG;
     if (c->trk_ready != 2 || c->trk_B != 1) return AGT_ERR_STATE;
     const int W = c->cfg.width, H = c->cfg.height;
     hipError_t e;
@@ -1144,7 +1163,22 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
 #else
 #define AGT_TQ(i)
 #endif
+    // Polled record: the frame's record goes straight to host-mapped memory of the context and the solver stores a sequence word behind
+    // it (system scope); this thread polls the word -- no 128-byte copy (a blit KERNEL of ~4.5 us behind the step's launch,
+    // rocprofv3), no completion signal, no stream wait.  (With profiling spans armed the call waits for the stream as before.)
+    bool polled = !(c->prof_ev && c->prof_n < c->prof_cap);
+#ifdef AGT_DEBUG_KNOBS
+    { static const int on = [] { const char* v = getenv("AGT_HOST_POLL"); return v ? atoi(v) : 1; }(); if (!on) polled = false; }
+#endif
+    double* const d_rec = (polled || !d_state) ? c->hrec_dev : d_state;       // where the pose solver writes the frame's record
     bool registered = false;
+    // (the device address of the caller's buffer when it is pinned host memory, asked for on EVERY call: a cached answer would outlive the buffer)
+    const uint8_t* h_dev = nullptr;
+    {
+        hipPointerAttribute_t at;
+        if (hipPointerGetAttributes(&at, h_frame) == hipSuccess && at.type == hipMemoryTypeHost) h_dev = (const uint8_t*)at.devicePointer;
+        else (void)hipGetLastError();
+    }
     if (channels == 1) {
         if (src_w != W || src_h != H || roi_x || roi_y || undistort) return AGT_ERR_ARG;
         // Round 4: a gray frame in PINNED host memory is not copied first: the two-level pyramid pass reads it over PCIe and writes its
@@ -1152,13 +1186,8 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
         // submission and hand-over) and a pyramid launch (6 us).  Pageable memory, frame sizes the rolling pass does not take, the
         // stage-by-stage mode and pending pyramid work of earlier frames keep the copy.
         if (c->pipeline && !c->reproject && agt_step_fits(c->trk_n, 1) && !(c->prof_ev && c->prof_n < c->prof_cap)) {
-            // (the device address of the caller's buffer, asked for on EVERY call: a cached answer would outlive the buffer)
-            hipPointerAttribute_t at;
-            const uint8_t* h_dev = nullptr;
-            if (hipPointerGetAttributes(&at, h_frame) == hipSuccess && at.type == hipMemoryTypeHost) h_dev = (const uint8_t*)at.devicePointer;
-            else (void)hipGetLastError();
             if (h_dev) {
-                int rcu = step_pipelined_uploaded(c, h_dev, d_gray, gpitch, d_state);
+                int rcu = step_pipelined_uploaded(c, h_dev, d_gray, gpitch, d_rec);
                 if (rcu < 0) return rcu;
                 registered = rcu == AGT_OK;
             }
@@ -1169,28 +1198,69 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
             if (e != hipSuccess) return hip_fail(c, e);
         }
     } else {
-        if (!d_staging) return AGT_ERR_ARG;
-        e = hipMemcpyAsync(d_staging, h_frame, (size_t)src_w * src_h * 3, hipMemcpyHostToDevice, c->stream);
-        if (e != hipSuccess) return hip_fail(c, e);
-        int rc = agt_preprocess_bgr(c, d_staging, (size_t)src_w * 3, (size_t)src_w * src_h * 3, src_w, src_h, 1, undistort, roi_x, roi_y, W, H,
+        // BGR: without undistortion the gray conversion streams through the frame once -- from pinned host memory it reads the frame
+        // over PCIe itself (no 2.8 MB copy first); the undistortion's gather keeps the frame in HBM (d_staging)
+        const uint8_t* src = d_staging;
+        if (h_dev && !undistort) src = h_dev;
+        else {
+            if (!d_staging) return AGT_ERR_ARG;
+            e = hipMemcpyAsync(d_staging, h_frame, (size_t)src_w * src_h * 3, hipMemcpyHostToDevice, c->stream);
+            if (e != hipSuccess) return hip_fail(c, e);
+        }
+        int rc = agt_preprocess_bgr(c, src, (size_t)src_w * 3, (size_t)src_w * src_h * 3, src_w, src_h, 1, undistort, roi_x, roi_y, W, H,
                                     d_gray, gpitch, gpitch * (size_t)H);
         if (rc) return rc;
     }
     AGT_TQ(1);
-    int rc = registered ? AGT_OK : agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_state);
-    if (rc) return rc;
-    AGT_TQ(2);
-    rc = join_pipeline(c);
+    int rc = AGT_OK;
+    unsigned long long want = 0;
+    if (polled) c->host_seq_on = 1;            // (every pose launch issued from here on reports the frames it solves)
+    if (!registered) rc = agt_track_frame(c, d_gray, gpitch, gpitch * (size_t)H, 1, d_rec);
+    if (polled && rc == AGT_OK) { want = c->hseq_off + (unsigned long long)c->trk_frame; c->hseq_last = want; }
+    if (rc == AGT_OK) { AGT_TQ(2); rc = join_pipeline(c); }
+    c->host_seq_on = 0;
     if (rc) return rc;
     AGT_TQ(3);
-    // (Measured and dropped, round 4: the record written by the solver straight into host-mapped memory with a system-scope
-    // sequence word behind it, polled by this thread -- no copy command, no stream wait: 91.4 us per call against 84.8-91.5 this way,
-    // box to box.  The call's time is the device pipeline itself: the copy engine's 19 us of PCIe transfer plus ~16 us of
-    // submission and engine hand-over around it, then the two launches; HSA_ENABLE_SDMA=0 -- blit-kernel copies -- 107 us.)
-    e = hipMemcpyAsync(h_state, d_state, AGT_STATE_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream);
-    AGT_TQ(4);
-    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    if (e != hipSuccess) return hip_fail(c, e);
+    if (polled) {
+        if (d_state) {          // the device copy of the record, for callers that keep one (stream-ordered; nobody waits for it here)
+            e = hipMemcpyAsync(d_state, c->hrec_dev, AGT_STATE_STRIDE * sizeof(double), hipMemcpyDeviceToDevice, c->stream);
+            if (e != hipSuccess) return hip_fail(c, e);
+        }
+        AGT_TQ(4);
+        const volatile unsigned long long* seq = c->hseq_host;
+        timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+        for (unsigned long spins = 1; *seq < want; spins++) {
+            __builtin_ia32_pause();
+            if ((spins & 0xffff) == 0) {
+                // nothing after 2 s: a launch failed or the device is gone -- let the runtime say which
+                timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+                if ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) {
+                    e = hipStreamSynchronize(c->stream);
+                    if (e != hipSuccess) return hip_fail(c, e);
+                    if (*seq < want) return AGT_ERR_STATE;
+                }
+            }
+        }
+        __atomic_thread_fence(__ATOMIC_ACQUIRE);
+        memcpy(h_state, c->hrec_host, AGT_STATE_STRIDE * sizeof(double));
+#ifdef AGT_DEBUG_KNOBS
+        if (timing) { const double t5 = now(); for (int i = 0; i < 4; i++) acc.t[i] += tq[i + 1] - tq[i]; acc.t[4] += t5 - tq[4]; acc.t[5] += t5 - tq[0]; acc.n++; }
+#endif
+        return *(volatile int*)c->fault_host ? AGT_ERR_CHAIN : AGT_OK;
+    }
+    // (the waited form: profiling spans armed, or the knobs build's AGT_HOST_POLL=0.  HSA_ENABLE_SDMA=0 -- blit-kernel copies -- made
+    // the copy-first form of round 3 slower still: 107 us.)
+    if (d_state) {
+        e = hipMemcpyAsync(h_state, d_state, AGT_STATE_STRIDE * sizeof(double), hipMemcpyDeviceToHost, c->stream);
+        AGT_TQ(4);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+    } else {                                   // (no device record asked for: the record is in the context's host-mapped memory once the stream is done)
+        AGT_TQ(4);
+        e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        memcpy(h_state, c->hrec_host, AGT_STATE_STRIDE * sizeof(double));
+    }
 #ifdef AGT_DEBUG_KNOBS
     if (timing) { const double t5 = now(); for (int i = 0; i < 4; i++) acc.t[i] += tq[i + 1] - tq[i]; acc.t[4] += t5 - tq[4]; acc.t[5] += t5 - tq[0]; acc.n++; }
 #endif
@@ -1209,6 +1279,7 @@ int agt_tracker_rewind(agt_ctx* c)
     if (rc) return rc;
     c->prebuilt_t = -1;
     c->trk_frame -= 1;
+    c->hseq_off += 1;                         // (the next frame re-uses the frame index: its sequence number must not)
     c->n_lk = c->n_pnp = c->trk_frame;
     for (int s = 0; s < AGT_MAX_LEVELS; s++)
         if (c->n_stage[s] > c->trk_frame) c->n_stage[s] = c->trk_frame;

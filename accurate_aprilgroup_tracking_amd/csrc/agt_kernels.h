@@ -74,7 +74,19 @@ struct AgtPnpParams {
     int* fault;                    // chained launch: host-mapped word set to 1 when a wait gave up (agt_synchronize reports it), or null
     float* seed_pts;               // agt_track_frame_detected: the detector's corner table (img, mask) becomes the frame's corner set
     uint8_t* seed_status;          // / LK status ([B][n][2], [B][n]: the tracker's ring entry of the frame), or null
+    // agt_track_host_frame: host-mapped sequence word the solver of stream 0 stores (system scope) behind the frame's record -- whose
+    // destination is host-mapped too -- so that the calling thread can poll for the record instead of waiting for the stream;
+    // frame k of a launch stores host_seq_base + k.  null: off.
+    unsigned long long* host_seq;
+    unsigned long long host_seq_base;
 };
+
+// the frame's record (written by this wave a moment ago, to host-mapped memory) is complete: tell the polling host thread
+__device__ __forceinline__ void agt_host_seq_store(unsigned long long* host_seq, unsigned long long value, bool writer_lane)
+{
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");                  // system scope: the record's stores are performed first
+    if (writer_lane) __hip_atomic_store(host_seq, value, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
 
 // device-resident per-stream tracker state: the attributes of PoseDetector
 // (detect_pose.py:74-83) that _estimate_pose mutates

@@ -12,6 +12,7 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 {
     __shared__ agt_pnp::PnpShared sh;
     agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh, P.img, P.mask, P.state_out);
+    if (P.host_seq && blockIdx.x == 0) agt_host_seq_store(P.host_seq, P.host_seq_base, threadIdx.x == 0);
 }
 
 // n > 64: four waves.  A solve that starts from a guess is shared by all of them (agt_pnp_body.h, COOP); one without (first
@@ -39,6 +40,7 @@ __global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const A
     __syncthreads();
     if (guess) agt_pnp::pnp_body<T, 1, agt_pnp::PnpNoHook, false, COOP_WAVES>(P, b, sh, P.img, P.mask, P.state_out);
     else if (threadIdx.x < AGT_WAVE) agt_pnp::pnp_body<T, agt_pnp::MAX_PPL>(P, b, sh, P.img, P.mask, P.state_out);
+    if (P.host_seq && b == 0 && threadIdx.x < AGT_WAVE) agt_host_seq_store(P.host_seq, P.host_seq_base, threadIdx.x == 0);      // (wave 0 writes the record in both bodies)
 }
 
 template <typename T>

@@ -337,6 +337,9 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
         if (NWV > 1) {
             if (lane == 0) *(volatile int*)&sh.seq = k + 1;
         }
+        // agt_track_host_frame: the host thread polls for this frame's record (behind the hand-over to the other wave: the
+        // system-scope release waits for the record's stores to reach the host)
+        if (S.pnp.host_seq && blk == 0) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, lane == 0);
     }
 }
 
@@ -398,6 +401,7 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
         if (wave == 0) {            // (wave 0 ran the state update of frame k in either body: its own LDS accesses are in program order)
             agt_pnp::pnp_sync();
             if (tid == 0) *(volatile int*)&sh.coop[(k + 1) & 1] = *(volatile int*)&sh.ts.has_guess;
+            if (S.pnp.host_seq && blk == 0) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, tid == 0);
         }
     }
     __syncthreads();

@@ -483,7 +483,8 @@ class _DeviceStream:
         self.H.check(ctx.L.agt_track_host_frame(ctx.h, C.c_void_p(pin.data_ptr()), 3 if color else 1, self.src_hw[1], self.src_hw[0],
                                                 C.c_void_p(self.bgr.data_ptr()) if color else None, int(self.undistort and color),
                                                 self.roi[0] if color else 0, self.roi[1] if color else 0, C.c_void_p(g.data_ptr()), self.gpitch,
-                                                C.c_void_p(self.rec_dev.data_ptr()), C.c_void_p(self.rec_host.data_ptr())), "agt_track_host_frame")
+                                                None,      # (no device copy of the record: it arrives in host memory, polled)
+                                                C.c_void_p(self.rec_host.data_ptr())), "agt_track_host_frame")
         self.trk._alive.append(g)
         if len(self.trk._alive) > self.trk._keep_frames:
             del self.trk._alive[0]

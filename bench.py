@@ -689,8 +689,8 @@ def live_latency(bench, n=300):
 
 def drop_in_latency(bench, n=200):
     """the class a reference user instantiates (detect_pose.py:57) on the device-resident path --
-    PoseDetector(backend="stream")._detect_and_get_pose(frame), one HOST frame per call: pinned upload -> (BGR: gray kernel)
-    -> agt_track_frame -> 128-byte record download.  Median / p90 of the host-observed call time over n tracked frames;
+    PoseDetector(backend="stream")._detect_and_get_pose(frame), one HOST frame per call (agt_track_host_frame: the pinned frame read by the
+    pyramid pass / gray kernel itself -> chained LK|PnP launch -> record polled in host-mapped memory).  Median / p90 of the host-observed call time over n tracked frames;
     gray (0.9 MB) and BGR (2.8 MB) frames, from the detector's pinned frame buffer and from an ordinary numpy array (one
     more host copy).  The first frame is seeded by a detector answer (ground truth), then the detector is removed (LK path)."""
     import json as js, logging, tempfile
@@ -730,8 +730,9 @@ def drop_in_latency(bench, n=200):
         ok = det.last_error is not None and det.last_error < 2
         out[name] = {"median": round(float(np.median(ts)), 1), "p90": round(float(np.percentile(ts, 90)), 1), "last_accepted": bool(ok)}
         del det
-    out["note"] = ("PoseDetector(backend='stream')._detect_and_get_pose(host frame) at %dx%d, LK path: upload + [gray kernel] + pyramid launch + "
-                   "chained LK|PnP launch + 128 B download, one frame per call; *_pageable adds the host copy into the pinned staging buffer"
+    out["note"] = ("PoseDetector(backend='stream')._detect_and_get_pose(host frame) at %dx%d, LK path, one frame per call: pyramid pass reading the pinned frame "
+                   "over PCIe [BGR: gray kernel reading it] + chained LK|PnP launch, record polled in host-mapped memory; *_pageable adds the host "
+                   "copy into the pinned staging buffer"
                    % (bench.W, bench.H))
     return out
 

@@ -230,12 +230,21 @@ int agt_track_frame_detected(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch
  * agt_track_frame; PoseDetector(backend="stream") does.  All B streams go back together (use it with B = 1). */
 int agt_tracker_rewind(agt_ctx* ctx);
 /* The body of the reference's live loop (detect_pose.py:669-681) for ONE stream whose frames live on the HOST, in one call:
- * h_frame (pinned for an asynchronous copy; channels = 1: gray W x H of the context, channels = 3: BGR src_w x src_h, uploaded
- * into d_staging and passed through agt_preprocess_bgr with the given undistort flag and ROI origin) -> d_gray (context-size
- * gray frame, row pitch gpitch; must stay valid while the NEXT frame is tracked: alternate at least two buffers) ->
- * agt_track_frame -> agt_tracker_join -> the frame's record copied to h_state (AGT_STATE_STRIDE doubles) -> the stream is
- * waited for.  On return h_state is valid.  Needs B = 1 and a seeded tracker (agt_tracker_reset with corners or
- * agt_track_frame_detected). */
+ * h_frame -> d_gray (context-size gray frame in device memory, row pitch gpitch; must stay valid while the NEXT frame is
+ * tracked: alternate at least two buffers) -> agt_track_frame -> agt_tracker_join -> the frame's record in h_state
+ * (AGT_STATE_STRIDE doubles, valid on return).  Needs B = 1 and a seeded tracker (agt_tracker_reset with corners or
+ * agt_track_frame_detected).
+ *   h_frame   channels = 1: gray W x H of the context (undistort, roi_x, roi_y must be 0); channels = 3: BGR src_w x src_h, passed
+ *             through agt_preprocess_bgr with the given undistort flag and ROI origin.  PINNED host memory (hipHostMalloc /
+ *             hipHostRegister -- PoseDetector.frame_buffer) is read by the device directly: a gray frame by the pyramid pass
+ *             itself (which writes d_gray on the way: no separate upload), a BGR frame without undistortion by the gray
+ *             conversion.  Pageable memory, BGR with undistortion, profiling spans and the stage-by-stage mode copy first.
+ *   d_staging device buffer of src_w * src_h * 3 bytes for the copied BGR frame; may be NULL for channels = 1 (required for
+ *             channels = 3 whenever the frame has to be copied: AGT_ERR_ARG without it)
+ *   d_state   optional device copy of the record (stream-ordered, complete at the next synchronisation); NULL = none
+ * The record reaches h_state without a copy command: the pose solver writes it to host-mapped memory of the context and
+ * stores a sequence number behind it, which this call polls (falls back to waiting for the stream after 2 s and reports the
+ * runtime's error).  A chain fault of the step is returned as AGT_ERR_CHAIN. */
 int agt_track_host_frame(agt_ctx* ctx, const uint8_t* h_frame, int channels, int src_w, int src_h, uint8_t* d_staging,
                          int undistort, int roi_x, int roi_y, uint8_t* d_gray, size_t gpitch, double* d_state, double* h_state);
 /* A clip: `count` consecutive frames of the B streams in one call, frame k at d_frames + k * frame_stride (bytes), its

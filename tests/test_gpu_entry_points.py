@@ -269,14 +269,25 @@ def test_track_host_frame_record_paths(seq10):
                 H.check(L.agt_tracker_join(h), "join")
                 H.check(L.agt_download(h, C.c_void_p(rec_h.data_ptr()), C.c_void_p(rec_d.data_ptr()), H.STATE_STRIDE * 8), "down")
             else:
-                np.copyto(pin.numpy(), s.frame(k))
-                H.check(L.agt_track_host_frame(h, C.c_void_p(pin.data_ptr()), 1, W, Hh, None, 0, 0, 0, C.c_void_p(g.data_ptr()), W,
-                                               C.c_void_p(rec_d.data_ptr()), C.c_void_p(rec_h.data_ptr())), "host_frame")
+                # the frame: pinned host memory (read by the pyramid pass itself) or pageable (copied first);
+                # the device copy of the record is optional
+                src = np.ascontiguousarray(s.frame(k)) if kind == "pageable_frame" else pin.numpy()
+                if kind != "pageable_frame":
+                    np.copyto(src, s.frame(k))
+                want_d = kind != "no_device_record"
+                H.check(L.agt_track_host_frame(h, C.c_void_p(src.ctypes.data), 1, W, Hh, None, 0, 0, 0, C.c_void_p(g.data_ptr()), W,
+                                               C.c_void_p(rec_d.data_ptr()) if want_d else None, C.c_void_p(rec_h.data_ptr())),
+                        "host_frame")
+                if want_d:
+                    torch.cuda.synchronize()
+                    assert np.array_equal(rec_d.cpu().numpy()[0], rec_h.numpy()), "device copy of the record"
+                assert np.array_equal(g[0].cpu().numpy(), s.frame(k)), "d_gray holds the frame afterwards"
             out.append(rec_h.numpy().copy())
         return np.stack(out)
-    sep, pinned, pageable = run("separate"), run("pinned"), run("pageable")
+    sep = run("separate")
     assert sep[:, H.ST_OK].all()
-    assert np.array_equal(sep, pinned) and np.array_equal(sep, pageable)
+    for kind in ("pinned", "pageable", "pageable_frame", "no_device_record"):
+        assert np.array_equal(sep, run(kind)), kind
 
 
 def test_hip_tracker_vs_opencv_float_accumulation_on_c2_stream(tmp_path, oracle, seq720_long):
