@@ -51,6 +51,10 @@ struct agt_ctx {
     int y_ev_hist[2];                        // event slots of the two most recent PnP launches (-1 = none)
     long trk_frame;                          // frames supplied since reset (0 = only the reset frame)
     long prebuilt_t = -1;                    // serial step, clip submission: frame whose pyramid the previous frame's dense launch built (-1 = none)
+    // clip submission of the dense stage: the previous frame's last step (final update + re-seed) waits for this frame's LK launch
+    // (agt_step.hip lk_reseed_kernel); only ever set between two frames of one agt_track_frames_dense call
+    int dense_pending = 0;
+    AgtDenseFinal dense_final;
     long n_stage[AGT_MAX_LEVELS];            // frames whose pyramid stage s (level s -> s+1) is done
     long n_lk, n_pnp;                        // frames whose LK / PnP is done (enqueued)
     // chained launches (fused step): per ring entry, [max_streams] arrival counters the LK role counts corners into and
@@ -998,6 +1002,16 @@ static int ms_join(agt_ctx* c)
 // next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
 // stream stride -- its two-level pyramid pass rides in this frame's PnP launch (more than 64 corners) or second dense launch (agt_dense.hip) instead of being the
 // first launch of its own chain.
+static bool dense_defer_on()
+{
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_DENSE_DEFER=0 keeps dense_final_kernel a launch of its own in clips
+    static const int on = [] { const char* e = getenv("AGT_DENSE_DEFER"); return e ? atoi(e) : 1; }();
+    return on != 0;
+#else
+    return true;
+#endif
+}
+
 static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                        double* d_state_out, double* d_dense_out, hipEvent_t* pev, const uint8_t* next_frame = nullptr)
 {
@@ -1044,9 +1058,16 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
             for (int l = 0; l <= c->eff_max_level; l++) T.lk.img[k][l] = l == 0 ? c->l0_ptr[q] : c->lmem[q][l];
         }
         T.lk.next[0] = c->corners[slot]; T.lk.status[0] = c->status[slot];
-        hipError_t e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
+        hipError_t e;
+        if (c->dense_pending) { e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_final); c->dense_pending = 0; }
+        else e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
         if (e != hipSuccess) return hip_fail(c, e);
     } else {
+    if (c->dense_pending) {          // (cannot happen: the deferral is decided with this frame's launch form known)
+        c->dense_pending = 0;
+        hipError_t e = agt_launch_dense_final(M, c->dense_final, B);
+        if (e != hipSuccess) return hip_fail(c, e);
+    }
     rc = lk_track_on(c, M, pslot, slot, c->corners[pslot], c->status[pslot], c->corners[slot], c->status[slot], nullptr,
                      c->trk_n, B, AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig);
     if (rc) return rc;
@@ -1064,11 +1085,17 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     if (e != hipSuccess) return hip_fail(c, e);
     if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
     if (d_dense_out) {
+        // Clip submission: the stage's last step (final update + re-seed, a one-workgroup launch of 5.5 us) is left to the NEXT
+        // frame's LK launch, whose workgroups do it as their prologue (agt_step.hip lk_reseed_kernel) -- when that launch will be the
+        // four-waves-per-corner LK role launch (same geometry as this frame's) and no stage spans are being recorded
+        const bool defer = next_frame && !pev && c->dn_iters > 0 && c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && dense_defer_on();
         // dense photometric + geometric refinement of the frame's accepted pose, then (reseed) the corner set from it
         e = agt_launch_dense(M, d_frames, (long)pitch, (long)batch_stride, c->cfg.width, c->cfg.height, c->dn_xyz, c->dn_t, c->dn_M,
                              c->obj, c->corners[slot], c->status[slot], c->trk_n, c->cam, c->pose, c->dense_partials, nullptr,
                              c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, c->dn_reseed ? c->corners[slot] : nullptr,
-                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX, (ride && !ride_pnp) ? npyr : nullptr);
+                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX, (ride && !ride_pnp) ? npyr : nullptr,
+                             defer ? &c->dense_final : nullptr);
+        if (e == hipSuccess && defer) c->dense_pending = 1;
         if (pev) c->prof_dense[c->prof_n - 1] = c->dn_iters < AGT_PROF_DENSE_MAX ? c->dn_iters : AGT_PROF_DENSE_MAX;
         if (e != hipSuccess) return hip_fail(c, e);
     }
@@ -1529,7 +1556,10 @@ int agt_track_frames_dense(agt_ctx* c, const uint8_t* d_frames, size_t pitch, si
         int rc = step_serial(c, d_frames + (size_t)k * frame_stride, pitch, batch_stride, B,
                              d_state_out ? d_state_out + (size_t)k * B * AGT_STATE_STRIDE : nullptr,
                              d_dense_out + (size_t)k * B * AGT_DENSE_STRIDE, pev, k + 1 < count ? d_frames + (size_t)(k + 1) * frame_stride : nullptr);
-        if (rc) return rc;
+        if (rc) {
+            if (c->dense_pending) { c->dense_pending = 0; (void)agt_launch_dense_final(c->stream, c->dense_final, B); }     // (a frame failed before its LK launch)
+            return rc;
+        }
     }
     return AGT_OK;
 }

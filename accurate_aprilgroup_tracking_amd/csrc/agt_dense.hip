@@ -22,6 +22,7 @@
 // iters Gauss-Newton iterations = iters + 1 launches (round 2: 2 * iters + 1 re-seed launch); nothing synchronises.
 // No MFMA: the contraction is 6x6.
 #undef AGT_PNP_STAMPS
+#include <cstring>
 #include "agt_pnp_body.h"
 #include "agt_pyramid2_body.h"
 
@@ -37,128 +38,13 @@ extern "C" int agt_debug_dense_stamps(unsigned long long* host16)
 #define DSTAMP(i)
 #endif
 
+#include "agt_dense_body.h"
+
 #pragma clang fp contract(fast)      // FP64 pose code only, see agt_device.h
 
 namespace {
 
-constexpr int DN = 29;                 // 21 (upper JtJ) + 6 (Jt r) + r^2 + valid count
-constexpr int DROW = 32;               // doubles per block row in the partials buffer
-
-struct DenseParams {
-    const uint8_t* img; long pitch, ibatch; int w, h;
-    const float* mxyz; const float* mt; int M;
-    const float* obj; const float* ipts; const uint8_t* mask; int N;
-    AgtCameraHost cam;
-    double* pose;                      // [B][6]
-    double* partials;                  // [2][B][nblk + 1][DROW]: block rows, double-buffered by iteration parity
-    double* ppose;                     // [2][B][8]: linearisation point of iteration k + 1 (published by block 0 of launch k + 1)
-    long pstride;                      // doubles between the two row buffers
-    int nblk;
-    double* stats;                     // [B][stats_stride]: 5 values written per iteration
-    int stats_stride;
-    double* rec;                       // tracker stage: per-frame record [B][AGT_DENSE_STRIDE] (pose, refined flag, stats) or null
-    int* done;                         // [B]
-    double photo_weight, mu;
-    int iter;
-    float* seed_pts; uint8_t* seed_status;     // tracker stage with re-seed: the frame's corner set / LK status ([B][N][2], [B][N]) or null
-    // clip submission (agt_track_frames_dense): the two-level pyramid pass of the NEXT frame rides in the first accumulate launch
-    // as extra workgroups (blockIdx.x > nblk) -- it depends on nothing this frame computes, and alone it was a 6.5 us launch
-    // in the frame's serial chain
-    AgtPyrArgs py0, py1;
-    int n_pyr;                                 // tiles per stream (0 = none)
-};
-
-struct DenseShared {
-    double wtot[4][DROW];
-    double rows8[8][DROW];             // update prologue: partial sums of the previous iteration's rows
-    double geo[DROW];                  // ... and its corner (geometric) row
-    double totw[4][2 * DROW];          // per wave: totals of the photometric rows | the corner row
-};
-
-// The Gauss-Newton update of iteration P.iter - 1 from its block rows: called by all 256 threads of a block; on return
-// pose_new[0..5] holds the new pose in EVERY thread and the return value says "stop" -- the same bits in every thread of every
-// block.  `publish`: this block also writes pose / statistics / record / done word to global memory.
-// One global round trip: the block rows, the corner row and the previous pose are all requested up front; after the one
-// barrier every wave reduces and solves for itself (redundantly: no second barrier, no LDS hand-over of the result).
-// done_word != null: the stream's done word is tested here, AFTER the loads have been requested (its round trip runs beside
-// theirs instead of in front); a set word returns "stop" before anything is written.
-__device__ __forceinline__ bool dense_update(const DenseParams& P, DenseShared& sh, int b, const double* rows, const double* pose_in,
-                                             double* pose_out, bool publish, int iter_done, double (&pose_new)[6], const int* done_word = nullptr,
-                                             bool* solved = nullptr)
-{
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int k = threadIdx.x & 31, g = threadIdx.x >> 5;
-    const int done_v = done_word ? *done_word : 0;
-    double param[6];
-#pragma unroll
-    for (int q = 0; q < 6; q++) param[q] = pose_in[q];
-    const double geo = (g == 0 && P.N > 0) ? rows[(long)P.nblk * DROW + k] : 0.0;
-    {
-        // every row load of the thread in flight at once (a rolled loop issues them one L2 round trip at a time: 7 us at 240
-        // rows; round 2's 16 per trip still needed two trips for the 240 rows of BASELINE configs[4]), summed in row order: the
-        // result does not depend on timing
-        double s = 0.0;
-        for (int j0 = g; j0 < P.nblk; j0 += 256) {
-            double v[32];
-#pragma unroll
-            for (int u = 0; u < 32; u++) { const int j = j0 + 8 * u; v[u] = j < P.nblk ? rows[(long)j * DROW + k] : 0.0; }
-            if (done_v) return true;
-#pragma unroll
-            for (int u = 0; u < 32; u++) s += v[u];
-        }
-        DSTAMP(8);
-        sh.rows8[g][k] = s;
-        if (g == 0) sh.geo[k] = geo;
-    }
-    __syncthreads();
-    DSTAMP(9);
-    // per wave: lanes 0..31 total the eight group rows, lanes 32..63 fetch the corner row; the wave's own copy in LDS, then
-    // every lane reads what it needs (broadcast reads)
-    double* tw = sh.totw[wave];
-    if (lane < DROW)
-        tw[lane] = ((sh.rows8[0][lane] + sh.rows8[1][lane]) + (sh.rows8[2][lane] + sh.rows8[3][lane])) +
-                   ((sh.rows8[4][lane] + sh.rows8[5][lane]) + (sh.rows8[6][lane] + sh.rows8[7][lane]));
-    else tw[lane] = sh.geo[lane - DROW];
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    double A[36], gv[6], dx[6];
-    int idx = 0;
-#pragma unroll
-    for (int q = 0; q < 6; q++)
-#pragma unroll
-        for (int c = q; c < 6; c++) { const double v = tw[DROW + idx] + tw[idx]; A[q * 6 + c] = v; A[c * 6 + q] = v; idx++; }
-#pragma unroll
-    for (int q = 0; q < 6; q++) { gv[q] = tw[DROW + 21 + q] + tw[21 + q]; A[q * 7] *= 1.0 + P.mu; }
-    DSTAMP(10);
-    const bool ok = agt_solve6(A, gv, dx);
-    if (solved) *solved = ok;
-    DSTAMP(11);
-    double dn = 0.0, pn = 0.0;
-#pragma unroll
-    for (int q = 0; q < 6; q++) { dn += dx[q] * dx[q]; pn += param[q] * param[q]; }
-    const bool stop = !ok || sqrt(dn) / (sqrt(pn) + DBL_EPSILON) < (double)FLT_EPSILON;
-#pragma unroll
-    for (int q = 0; q < 6; q++) pose_new[q] = ok ? param[q] - dx[q] : param[q];
-    if (publish && threadIdx.x == 0) {
-        const double ph_r2 = tw[27], ph_n = tw[28], geo_r2 = tw[DROW + 27], n_used = tw[DROW + 28];
-        double* st = P.stats + (long)b * P.stats_stride;
-        st[0] = ph_n > 0.0 ? sqrt(ph_r2 / ph_n) : 0.0;
-        st[1] = n_used > 0.0 ? sqrt(geo_r2 / (2.0 * n_used)) : 0.0;
-        st[2] = ph_n; st[3] = (double)iter_done; st[4] = n_used;
-        if (!P.rec) st[5] = st[6] = st[7] = 0.0;
-        if (ok) {
-#pragma unroll
-            for (int q = 0; q < 6; q++) { P.pose[(long)b * 6 + q] = pose_new[q]; if (pose_out) pose_out[q] = pose_new[q]; }
-            if (P.rec) {
-                double* rc = P.rec + (long)b * AGT_DENSE_STRIDE;
-#pragma unroll
-                for (int q = 0; q < 6; q++) rc[q] = pose_new[q];
-                rc[AGT_DN_REFINED] = 1.0;
-            }
-        }
-        if (stop) P.done[b] = 1;
-    }
-    return stop;
-}
+using namespace agt_dense;
 
 __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
 {
@@ -323,28 +209,8 @@ __global__ __launch_bounds__(256) void dense_final_kernel(const DenseParams P)
     extern __shared__ __attribute__((aligned(16))) uint8_t lds_raw[];
     DenseShared& sh = *reinterpret_cast<DenseShared*>(lds_raw);
     const int b = blockIdx.x;
-    const int par = (P.iter - 1) & 1;                 // P.iter = iterations launched
-    // the record as earlier launches left it (requested before the update: its round trip runs beside the row loads)
-    double rec0[7];
-    const double* rc = P.rec ? P.rec + (long)b * AGT_DENSE_STRIDE : nullptr;
-#pragma unroll
-    for (int k = 0; k < 7; k++) rec0[k] = rc ? rc[k < 6 ? k : AGT_DN_REFINED] : 0.0;
     double param[6];
-    bool refined = rec0[6] != 0.0;
-#pragma unroll
-    for (int k = 0; k < 6; k++) param[k] = rec0[k];
-    if (!P.done[b] && P.iter > 0) {
-        // the last update: every thread holds the new pose, the re-seed below needs no trip through the record thread 0 writes
-        double fin[6];
-        bool ok = false;
-        dense_update(P, sh, b, P.partials + (long)par * P.pstride + (long)b * (P.nblk + 1) * DROW, P.ppose + ((long)par * gridDim.x + b) * 8,
-                     nullptr, true, P.iter, fin, nullptr, &ok);
-        if (ok) {
-            refined = true;
-#pragma unroll
-            for (int k = 0; k < 6; k++) param[k] = fin[k];
-        }
-    }
+    const bool refined = dense_finish(P, sh, b, (int)gridDim.x, true, true, param);
     if (!P.seed_pts || !P.rec || !refined) return;
     AgtCamera cam;
     agt_pnp::load_cam<float>(P.cam, cam);
@@ -369,8 +235,9 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
                             int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
-                            hipEvent_t* ev, int n_ev, const AgtPyrArgs* next_pyr)
+                            hipEvent_t* ev, int n_ev, const AgtPyrArgs* next_pyr, AgtDenseFinal* defer_final)
 {
+    static_assert(sizeof(DenseParams) <= sizeof(AgtDenseFinal::bytes), "AgtDenseFinal holds a DenseParams");
     DenseParams P;
     P.n_pyr = 0;
     P.py0 = AgtPyrArgs(); P.py1 = AgtPyrArgs();
@@ -402,6 +269,12 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
         if (ev && n_ev >= 2 && it == iters - 1) (void)hipEventRecord(ev[0], stream);
         e = hipGetLastError();
     }
+    if (e == hipSuccess && defer_final) {
+        // clip submission: the last update and the re-seed ride in the next frame's LK launch (agt_step.hip lk_reseed_kernel)
+        P.iter = iters; P.n_pyr = 0;
+        memcpy(defer_final->bytes, &P, sizeof(P));
+        return e;
+    }
     if (e == hipSuccess) {
         P.iter = iters;
         hipLaunchKernelGGL(dense_final_kernel, dim3(B), dim3(256), sizeof(DenseShared), stream, P);
@@ -409,6 +282,14 @@ hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, 
         e = hipGetLastError();
     }
     return e;
+}
+
+hipError_t agt_launch_dense_final(hipStream_t stream, const AgtDenseFinal& F, int B)
+{
+    DenseParams P;
+    memcpy(&P, F.bytes, sizeof(P));
+    hipLaunchKernelGGL(dense_final_kernel, dim3(B), dim3(256), sizeof(DenseShared), stream, P);
+    return hipGetLastError();
 }
 
 // rows of block partials per stream: the photometric blocks and one geometric (corner) block

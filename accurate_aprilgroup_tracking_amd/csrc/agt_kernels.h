@@ -179,12 +179,17 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
                                  const short2* map1, const unsigned short* map2, int mw,
                                  int rx, int ry, int rw, int rh, uint8_t* dst, long dpitch, long dbatch,
                                  int undistort, int gray, int B);
+// The dense stage's last step (final Gauss-Newton update + corner re-seed) handed on to the LK launch of the NEXT frame instead of
+// being launched: the stage's parameter block as agt_dense.hip fills it (opaque here; agt_step.hip agt_launch_lk_reseed reads it)
+struct AgtDenseFinal { alignas(8) unsigned char bytes[768]; };
+hipError_t agt_launch_lk_reseed(hipStream_t stream, const struct AgtStepParams& S, const struct AgtStepTables& T, int win, const AgtDenseFinal& F);
+hipError_t agt_launch_dense_final(hipStream_t stream, const AgtDenseFinal& F, int B);      // the deferred step as its own launch after all
 hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,
                             const float* mxyz, const float* mt, int M,
                             const float* obj, const float* ipts, const uint8_t* mask, int N,
                             const AgtCameraHost& cam, double* pose, double* partials, double* stats, int* done,
                             int B, int iters, double photo_weight, double mu, double* rec, float* seed_pts, uint8_t* seed_status,
-                            hipEvent_t* ev = nullptr, int n_ev = 0, const AgtPyrArgs* next_pyr = nullptr);
+                            hipEvent_t* ev = nullptr, int n_ev = 0, const AgtPyrArgs* next_pyr = nullptr, AgtDenseFinal* defer_final = nullptr);
 // geometry of the two-level pyramid pass (agt_pyramid.hip) as the pair of argument blocks its body takes
 void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch, uint8_t* dst1, long dpitch1, long dbatch1,
                    uint8_t* dst2, long dpitch2, long dbatch2, int B, AgtPyrArgs* A0, AgtPyrArgs* A1);

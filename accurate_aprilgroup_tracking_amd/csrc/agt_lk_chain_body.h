@@ -256,8 +256,11 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         if (k) lds_barrier();                  // everyone is done with the previous frame's LDS; the table copy is visible
         const LkFrameIo<NLEV> io = frame(k);
         if (k == 0) {
-            px = io.prev_pts[pidx * 2]; py = io.prev_pts[pidx * 2 + 1];
-            pst = P->prev_status ? (int)P->prev_status[pidx] : 1;
+            if (io.have_pos) { px = io.px; py = io.py; pst = io.pst; }       // (lk_reseed_kernel: the start position was computed in the launch)
+            else {
+                px = io.prev_pts[pidx * 2]; py = io.prev_pts[pidx * 2 + 1];
+                pst = P->prev_status ? (int)P->prev_status[pidx] : 1;
+            }
             px = agt_uniform(px); py = agt_uniform(py); pst = agt_uniform(pst);
         }
 #ifdef AGT_STEP_STAMPS

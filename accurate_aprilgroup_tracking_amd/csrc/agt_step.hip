@@ -19,6 +19,7 @@
 #endif
 #undef AGT_PNP_STAMPS
 #include <cstdlib>
+#include <cstring>
 #include <cstddef>
 #include "agt_pyramid2_body.h"
 #include "agt_pyramid3_body.h"
@@ -28,6 +29,7 @@
 #include "agt_lk_rs_body.h"
 #include "agt_lk_chain_body.h"
 #include "agt_pnp_body.h"
+#include "agt_dense_body.h"
 
 // Role timeline of the fused step (diagnostic build only, -DAGT_STEP_STAMPS; tools/stepstamps.py): s_memtime at entry and
 // exit of the PnP block, of the first LK block and the latest exit of any LK / pyramid block.
@@ -127,7 +129,7 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
         if (S.lk.flags == 0 && S.lk.err == nullptr) {
             auto frame = [&](int k) {
                 agt_lk::LkFrameIo<NLEV> io;
-                io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = k > 0; io.px = io.py = 0.f; io.pst = 1;
+                io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
                 if (k == 0) {
 #pragma unroll
                     for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
@@ -460,6 +462,53 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     lk_role<WIN, NW, NLEV, AGT_WAVE * NW, true>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
 }
 
+// Clip submission of the tracker's dense stage (agt_track_frames_dense): the LK launch of frame t + 1 first finishes the dense stage
+// of frame t.  Every workgroup (one corner, four waves) derives the last Gauss-Newton update from the block rows itself
+// (agt_dense_body.h dense_finish: same rows, same order, same bits in every workgroup -- the scheme of the accumulate launches'
+// prologue), projects ITS corner at the refined pose (the re-seed) and tracks it from there; the workgroup of a stream's corner 0
+// also publishes pose / statistics / record.  Replaces dense_final_kernel, a one-workgroup launch of 5.5 us in the frame's serial
+// chain, by ~2.5 us at the head of this launch.  The stream's done word is read, never written here (the other corners read it).
+template <int NLEV>
+__global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    static_assert(sizeof(agt_dense::DenseShared) <= agt_lk::lk_chain_lds_bytes<NLEV>(), "the prologue's LDS fits the tracker's");
+    KParams KS = kernarg_params();
+    const int blk = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);      // XCD-aware corner order (lk_role)
+    if (blk >= S.lk.n * S.lk_B) return;
+    const int b = blk / S.lk.n, pt = blk - b * S.lk.n;
+    const long pidx = (long)b * S.lk.n + pt;
+    // the corner as the previous frame's LK / PnP left it: requested first, used when the stage did not refine the pose
+    const float opx = S.lk.prev_pts[pidx * 2], opy = S.lk.prev_pts[pidx * 2 + 1];
+    const int opst = S.lk.prev_status ? (int)S.lk.prev_status[pidx] : 1;
+    const float X = F.obj[pt * 3], Y = F.obj[pt * 3 + 1], Z = F.obj[pt * 3 + 2];
+    agt_dense::DenseShared& sh = *reinterpret_cast<agt_dense::DenseShared*>(lds);
+    double param[6];
+    const bool refined = agt_dense::dense_finish(F, sh, b, S.lk_B, pt == 0, false, param);
+    float px = opx, py = opy;
+    int pst = opst;
+    if (F.seed_pts && F.rec && refined) {
+        AgtCamera cam;
+        agt_pnp::load_cam<float>(F.cam, cam);
+        double R[9], G[9];
+        agt_rodrigues<false>(param, R, G);
+        double u, v;
+        agt_project<false>(cam, R, G, param + 3, (double)X, (double)Y, (double)Z, u, v, nullptr, nullptr);
+        px = (float)u; py = (float)v; pst = 1;
+        if (threadIdx.x == 0) { F.seed_pts[pidx * 2] = px; F.seed_pts[pidx * 2 + 1] = py; F.seed_status[pidx] = 1; }
+    }
+    __syncthreads();                    // the prologue's LDS is the tracker's from here on
+    auto frame = [&](int) {
+        agt_lk::LkFrameIo<NLEV> io;
+        io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = true; io.px = px; io.py = py; io.pst = pst;
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
+        io.next_pts = T.lk.next[0]; io.status = T.lk.status[0]; io.done = T.lk.done[0];
+        return io;
+    };
+    agt_lk::lk_frames_w4<NLEV>(&KS->lk, pt, b, lds, 1, frame);
+}
+
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
@@ -580,6 +629,27 @@ bool agt_step_fits(int n, int B)
     const long cap = 256;
 #endif
     return n <= AGT_WAVE && (long)n * B <= cap;
+}
+
+// the one-frame LK role launch of step_serial with the previous frame's dense stage finished in its prologue (lk_reseed_kernel)
+hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal& F)
+{
+    if (win != 21 || S.n_lk <= 0 || S.lk_nf != 1 || !agt_lk_wide(S.lk.n, S.lk_B) || S.lk.flags != 0 || S.lk.err != nullptr) return hipErrorInvalidValue;
+    AgtStepParams P = S;
+    P.n_pnp = 0; P.pnp_nf = 0;
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
+    const long corners = (long)P.lk.n * P.lk_B;
+    P.n_lk = (int)corners;
+    agt_dense::DenseParams D;
+    static_assert(sizeof(D) <= sizeof(F.bytes), "AgtDenseFinal holds a DenseParams");
+    memcpy(&D, F.bytes, sizeof(D));
+    if (D.N != P.lk.n || D.seed_pts != P.lk.prev_pts) return hipErrorInvalidValue;      // (the re-seeded corner set IS this launch's start)
+    const bool small = P.lk.max_level < 3;
+    const size_t per = small ? lk_role_lds<21, 4, 3>(P.lk.max_level + 1) : lk_role_lds<21, 4, AGT_MAX_LEVELS>(P.lk.max_level + 1);
+    const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);
+    if (small) hipLaunchKernelGGL((lk_reseed_kernel<3>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
+    else hipLaunchKernelGGL((lk_reseed_kernel<AGT_MAX_LEVELS>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
+    return hipGetLastError();
 }
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, int roles)

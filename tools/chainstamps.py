@@ -5,7 +5,7 @@ import ctypes as C, os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from accurate_aprilgroup_tracking_amd import hiplib
-hiplib.LIB_PATH = os.path.join(os.path.dirname(hiplib.LIB_PATH), "libagt_hip_dbg.so")
+hiplib.LIB_PATH = os.path.join(os.path.dirname(hiplib.LIB_PATH), os.environ.get("AGT_LIB", "libagt_hip_dbg.so"))
 from accurate_aprilgroup_tracking_amd import synthetic as syn
 from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
 W, H, D = 1280, 720, 16
