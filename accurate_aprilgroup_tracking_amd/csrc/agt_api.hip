@@ -1002,13 +1002,13 @@ static int ms_join(agt_ctx* c)
 // next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
 // stream stride -- its two-level pyramid pass rides in this frame's PnP launch (more than 64 corners) or second dense launch (agt_dense.hip) instead of being the
 // first launch of its own chain.
-static bool dense_defer_on()
+static int dense_defer_on()
 {
-#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_DENSE_DEFER=0 keeps dense_final_kernel a launch of its own in clips
-    static const int on = [] { const char* e = getenv("AGT_DENSE_DEFER"); return e ? atoi(e) : 1; }();
-    return on != 0;
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_DENSE_DEFER=0 keeps dense_final_kernel a launch of its own in clips, 1 also the pose solve
+    static const int on = [] { const char* e = getenv("AGT_DENSE_DEFER"); return e ? atoi(e) : 2; }();
+    return on;
 #else
-    return true;
+    return 2;
 #endif
 }
 
@@ -1036,7 +1036,10 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     const bool lk_role_launch = c->cfg.win == 21 && agt_lk_wide(c->trk_n, B) && c->l0_pitch[pslot] == (long)pitch && c->l0_bstride[pslot] == (long)batch_stride;
     const bool ride = next_frame && c->eff_max_level == 2 && B <= AGT_PYR2_MAX_B && nslot != slot && nslot < c->ring &&
                       ((uintptr_t)next_frame & 3) == 0 && (agt_pnp_can_ride(c->trk_n) || (d_dense_out && c->dn_iters > 0));
-    const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n);
+    // Dense clips with the cooperative solver (64 < n <= 256): LK and PnP of the frame in ONE launch, the solver waiting for the
+    // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in the dense launch
+    const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1;
+    const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n) && !chain_pnp;
     if (ride) {
         // (what pyramid_build_on registers for a frame, for frame t + 1 in its ring entry)
         c->l0_ptr[nslot] = next_frame; c->l0_pitch[nslot] = (long)pitch; c->l0_bstride[nslot] = (long)batch_stride;
@@ -1045,6 +1048,14 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
                       c->lmem[nslot][2], c->lpitch[2], db2, B, &npyr[0], &npyr[1]);
         c->built_B[nslot] = B;
         c->prebuilt_t = t + 1;
+    }
+    AgtPnpParams p;
+    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
+    arm_host_seq(c, &p, t);
+    if (d_dense_out) {
+        rc = dense_scratch(c, agt_dense_doubles(c->dn_M, B), B);
+        if (rc) return rc;
+        p.dense_pose = c->pose; p.dense_done = c->dense_done; p.dense_rec = d_dense_out;
     }
     if (lk_role_launch) {
         // four waves per corner: the LK role of the step as a one-frame group (the frame-chained body; see agt_step.hip lk_role)
@@ -1059,8 +1070,17 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         }
         T.lk.next[0] = c->corners[slot]; T.lk.status[0] = c->status[slot];
         hipError_t e;
-        if (c->dense_pending) { e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_final); c->dense_pending = 0; }
-        else e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
+        if (chain_pnp) {
+            S.pnp = p; S.pnp_nf = 1; S.n_pnp = B;
+            c->lk_target[slot] += (unsigned)c->trk_n;
+            T.lk.done[0] = c->lk_done + (size_t)slot * c->cfg.max_streams;
+            T.pnp.img[0] = c->corners[slot]; T.pnp.mask[0] = c->status[slot]; T.pnp.so[0] = d_state_out;
+            T.pnp.wait[0] = T.lk.done[0]; T.pnp.target[0] = c->lk_target[slot];
+        }
+        if (c->dense_pending || chain_pnp) {
+            e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_pending ? &c->dense_final : nullptr);
+            c->dense_pending = 0;
+        } else e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
         if (e != hipSuccess) return hip_fail(c, e);
     } else {
     if (c->dense_pending) {          // (cannot happen: the deferral is decided with this frame's launch form known)
@@ -1073,15 +1093,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     if (rc) return rc;
     }
     if (pev) (void)hipEventRecord(pev[2], M);
-    AgtPnpParams p;
-    fill_estimate(c, &p, c->corners[slot], c->status[slot], d_state_out, c->corners[slot], c->status[slot]);
-    arm_host_seq(c, &p, t);
-    if (d_dense_out) {
-        rc = dense_scratch(c, agt_dense_doubles(c->dn_M, B), B);
-        if (rc) return rc;
-        p.dense_pose = c->pose; p.dense_done = c->dense_done; p.dense_rec = d_dense_out;
-    }
-    hipError_t e = agt_launch_pnp(M, p, B, ride_pnp ? npyr : nullptr);
+    hipError_t e = chain_pnp ? hipSuccess : agt_launch_pnp(M, p, B, ride_pnp ? npyr : nullptr);
     if (e != hipSuccess) return hip_fail(c, e);
     if (pev) { (void)hipEventRecord(pev[3], M); c->prof_n++; }
     if (d_dense_out) {

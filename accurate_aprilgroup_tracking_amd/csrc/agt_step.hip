@@ -469,35 +469,34 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
 // also publishes pose / statistics / record.  Replaces dense_final_kernel, a one-workgroup launch of 5.5 us in the frame's serial
 // chain, by ~2.5 us at the head of this launch.  The stream's done word is read, never written here (the other corners read it).
 template <int NLEV>
-__global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F)
+__device__ __forceinline__ void lk_reseed_role(const AgtStepParams& S, const AgtStepTables& T, KParams KS, const agt_dense::DenseParams& F, bool has_final,
+                                               int bid, int nblk, uint8_t* lds)
 {
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     static_assert(sizeof(agt_dense::DenseShared) <= agt_lk::lk_chain_lds_bytes<NLEV>(), "the prologue's LDS fits the tracker's");
-    KParams KS = kernarg_params();
-    const int blk = ((int)blockIdx.x & 7) * ((int)gridDim.x >> 3) + ((int)blockIdx.x >> 3);      // XCD-aware corner order (lk_role)
+    const int blk = (bid & 7) * (nblk >> 3) + (bid >> 3);      // XCD-aware corner order (lk_role); nblk is a multiple of 8
     if (blk >= S.lk.n * S.lk_B) return;
     const int b = blk / S.lk.n, pt = blk - b * S.lk.n;
     const long pidx = (long)b * S.lk.n + pt;
     // the corner as the previous frame's LK / PnP left it: requested first, used when the stage did not refine the pose
-    const float opx = S.lk.prev_pts[pidx * 2], opy = S.lk.prev_pts[pidx * 2 + 1];
-    const int opst = S.lk.prev_status ? (int)S.lk.prev_status[pidx] : 1;
-    const float X = F.obj[pt * 3], Y = F.obj[pt * 3 + 1], Z = F.obj[pt * 3 + 2];
-    agt_dense::DenseShared& sh = *reinterpret_cast<agt_dense::DenseShared*>(lds);
-    double param[6];
-    const bool refined = agt_dense::dense_finish(F, sh, b, S.lk_B, pt == 0, false, param);
-    float px = opx, py = opy;
-    int pst = opst;
-    if (F.seed_pts && F.rec && refined) {
-        AgtCamera cam;
-        agt_pnp::load_cam<float>(F.cam, cam);
-        double R[9], G[9];
-        agt_rodrigues<false>(param, R, G);
-        double u, v;
-        agt_project<false>(cam, R, G, param + 3, (double)X, (double)Y, (double)Z, u, v, nullptr, nullptr);
-        px = (float)u; py = (float)v; pst = 1;
-        if (threadIdx.x == 0) { F.seed_pts[pidx * 2] = px; F.seed_pts[pidx * 2 + 1] = py; F.seed_status[pidx] = 1; }
+    float px = S.lk.prev_pts[pidx * 2], py = S.lk.prev_pts[pidx * 2 + 1];
+    int pst = S.lk.prev_status ? (int)S.lk.prev_status[pidx] : 1;
+    if (has_final) {
+        const float X = F.obj[pt * 3], Y = F.obj[pt * 3 + 1], Z = F.obj[pt * 3 + 2];
+        agt_dense::DenseShared& sh = *reinterpret_cast<agt_dense::DenseShared*>(lds);
+        double param[6];
+        const bool refined = agt_dense::dense_finish(F, sh, b, S.lk_B, pt == 0, false, param);
+        if (F.seed_pts && F.rec && refined) {
+            AgtCamera cam;
+            agt_pnp::load_cam<float>(F.cam, cam);
+            double R[9], G[9];
+            agt_rodrigues<false>(param, R, G);
+            double u, v;
+            agt_project<false>(cam, R, G, param + 3, (double)X, (double)Y, (double)Z, u, v, nullptr, nullptr);
+            px = (float)u; py = (float)v; pst = 1;
+            if (threadIdx.x == 0) { F.seed_pts[pidx * 2] = px; F.seed_pts[pidx * 2 + 1] = py; F.seed_status[pidx] = 1; }
+        }
+        __syncthreads();                // the prologue's LDS is the tracker's from here on
     }
-    __syncthreads();                    // the prologue's LDS is the tracker's from here on
     auto frame = [&](int) {
         agt_lk::LkFrameIo<NLEV> io;
         io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = true; io.px = px; io.py = py; io.pst = pst;
@@ -507,6 +506,50 @@ __global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepPa
         return io;
     };
     agt_lk::lk_frames_w4<NLEV>(&KS->lk, pt, b, lds, 1, frame);
+}
+
+template <int NLEV>
+__global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    lk_reseed_role<NLEV>(S, T, kernarg_params(), F, true, (int)blockIdx.x, (int)gridDim.x, lds);
+}
+
+// ... and the frame's pose solve chained to it in the SAME launch (n > 64 corners: the four-wave cooperative solver, one workgroup
+// per stream behind the S.n_lk tracker workgroups), waiting for the frame's arrival count as the pose role of the fused step does:
+// the launch boundary between LK and PnP (~2 us at the end of a 25 us launch) and the solver's start-up leave the serial chain.
+// has_final == 0: no dense stage is pending (first frame of a clip).
+template <int NLEV>
+__global__ __launch_bounds__(AGT_WAVE * 4) void lk_pnp_coop_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F, const int has_final)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if ((int)blockIdx.x >= S.n_lk) {
+        // the solve as the stand-alone pnp_coop_kernel runs it (tracker state in global memory: the role form of the group launches,
+        // pnp_role_coop, keeps it in LDS across frames and spills 236 registers for it), behind the wait of a chained launch
+        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
+        const int b = (int)blockIdx.x - S.n_lk;
+        if (threadIdx.x == 0) {
+            const int* fault = &S.pnp.track[b].chain_fault;
+            const unsigned target = (unsigned)T.pnp.target[0];
+            unsigned polls = 0;
+            int timed_out = 0;
+            while ((int)(__hip_atomic_load(T.pnp.wait[0] + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
+                __builtin_amdgcn_s_sleep(4);
+                if (++polls > AGT_CHAIN_POLLS || ((polls & 15) == 1 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { timed_out = 1; break; }
+            }
+            *(volatile int*)&sh.late = timed_out;
+        }
+        __syncthreads();
+        const int late = agt_uniform(*(volatile int*)&sh.late);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const bool guess = agt_uniform(S.pnp.track[b].has_guess) && S.pnp.enhance_ape;
+        __syncthreads();        // every wave has read the decision before wave 0 (alone, without a guess) may rewrite has_guess
+        const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
+        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, false, PNP_COOP>(S.pnp, b, sh, T.pnp.img[0], T.pnp.mask[0], T.pnp.so[0], xf);
+        else if (threadIdx.x < AGT_WAVE) agt_pnp::pnp_body<float, agt_pnp::MAX_PPL>(S.pnp, b, sh, T.pnp.img[0], T.pnp.mask[0], T.pnp.so[0], xf);
+        return;
+    }
+    lk_reseed_role<NLEV>(S, T, kernarg_params(), F, has_final != 0, (int)blockIdx.x, S.n_lk, lds);
 }
 
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
@@ -631,24 +674,38 @@ bool agt_step_fits(int n, int B)
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
 
-// the one-frame LK role launch of step_serial with the previous frame's dense stage finished in its prologue (lk_reseed_kernel)
-hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal& F)
+// the one-frame LK role launch of step_serial with the previous frame's dense stage finished in its prologue (lk_reseed_kernel; F
+// null: nothing pending), and, with S.n_pnp > 0, the frame's cooperative pose solve chained to it in the same launch (lk_pnp_coop_kernel)
+hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal* F)
 {
     if (win != 21 || S.n_lk <= 0 || S.lk_nf != 1 || !agt_lk_wide(S.lk.n, S.lk_B) || S.lk.flags != 0 || S.lk.err != nullptr) return hipErrorInvalidValue;
+    const bool chain = S.n_pnp > 0;
+    if (!chain && !F) return hipErrorInvalidValue;
+    if (chain && (S.pnp_nf != 1 || S.pnp.n <= AGT_WAVE || S.pnp.n > AGT_WAVE * PNP_COOP || !T.pnp.wait[0] || !T.lk.done[0])) return hipErrorInvalidValue;
     AgtStepParams P = S;
-    P.n_pnp = 0; P.pnp_nf = 0;
+    if (!chain) { P.n_pnp = 0; P.pnp_nf = 0; }
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
     const long corners = (long)P.lk.n * P.lk_B;
-    P.n_lk = (int)corners;
-    agt_dense::DenseParams D;
-    static_assert(sizeof(D) <= sizeof(F.bytes), "AgtDenseFinal holds a DenseParams");
-    memcpy(&D, F.bytes, sizeof(D));
-    if (D.N != P.lk.n || D.seed_pts != P.lk.prev_pts) return hipErrorInvalidValue;      // (the re-seeded corner set IS this launch's start)
-    const bool small = P.lk.max_level < 3;
-    const size_t per = small ? lk_role_lds<21, 4, 3>(P.lk.max_level + 1) : lk_role_lds<21, 4, AGT_MAX_LEVELS>(P.lk.max_level + 1);
     const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);
-    if (small) hipLaunchKernelGGL((lk_reseed_kernel<3>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
-    else hipLaunchKernelGGL((lk_reseed_kernel<AGT_MAX_LEVELS>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
+    P.n_lk = (int)grid8;
+    agt_dense::DenseParams D;
+    static_assert(sizeof(D) <= sizeof(F->bytes), "AgtDenseFinal holds a DenseParams");
+    memset(&D, 0, sizeof(D));
+    if (F) {
+        memcpy(&D, F->bytes, sizeof(D));
+        if (D.N != P.lk.n || D.seed_pts != P.lk.prev_pts) return hipErrorInvalidValue;      // (the re-seeded corner set IS this launch's start)
+    }
+    const bool small = P.lk.max_level < 3;
+    size_t per = small ? lk_role_lds<21, 4, 3>(P.lk.max_level + 1) : lk_role_lds<21, 4, AGT_MAX_LEVELS>(P.lk.max_level + 1);
+    if (!chain) {
+        if (small) hipLaunchKernelGGL((lk_reseed_kernel<3>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
+        else hipLaunchKernelGGL((lk_reseed_kernel<AGT_MAX_LEVELS>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
+        return hipGetLastError();
+    }
+    if (per < sizeof(agt_pnp::PnpShared)) per = sizeof(agt_pnp::PnpShared);
+    const unsigned grid = grid8 + (unsigned)P.n_pnp;
+    if (small) hipLaunchKernelGGL((lk_pnp_coop_kernel<3>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0);
+    else hipLaunchKernelGGL((lk_pnp_coop_kernel<AGT_MAX_LEVELS>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0);
     return hipGetLastError();
 }
 
