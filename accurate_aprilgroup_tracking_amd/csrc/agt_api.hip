@@ -1078,7 +1078,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
             T.pnp.wait[0] = T.lk.done[0]; T.pnp.target[0] = c->lk_target[slot];
         }
         if (c->dense_pending || chain_pnp) {
-            e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_pending ? &c->dense_final : nullptr);
+            e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_pending ? &c->dense_final : nullptr, (ride && chain_pnp) ? npyr : nullptr);
             c->dense_pending = 0;
         } else e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
         if (e != hipSuccess) return hip_fail(c, e);
@@ -1105,7 +1105,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         e = agt_launch_dense(M, d_frames, (long)pitch, (long)batch_stride, c->cfg.width, c->cfg.height, c->dn_xyz, c->dn_t, c->dn_M,
                              c->obj, c->corners[slot], c->status[slot], c->trk_n, c->cam, c->pose, c->dense_partials, nullptr,
                              c->dense_done, B, c->dn_iters, c->dn_weight, 1e-3, d_dense_out, c->dn_reseed ? c->corners[slot] : nullptr,
-                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX, (ride && !ride_pnp) ? npyr : nullptr,
+                             c->dn_reseed ? c->status[slot] : nullptr, pev ? pev + 4 : nullptr, 2 * AGT_PROF_DENSE_MAX, (ride && !ride_pnp && !chain_pnp) ? npyr : nullptr,
                              defer ? &c->dense_final : nullptr);
         if (e == hipSuccess && defer) c->dense_pending = 1;
         if (pev) c->prof_dense[c->prof_n - 1] = c->dn_iters < AGT_PROF_DENSE_MAX ? c->dn_iters : AGT_PROF_DENSE_MAX;

@@ -182,7 +182,7 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
 // The dense stage's last step (final Gauss-Newton update + corner re-seed) handed on to the LK launch of the NEXT frame instead of
 // being launched: the stage's parameter block as agt_dense.hip fills it (opaque here; agt_step.hip agt_launch_lk_reseed reads it)
 struct AgtDenseFinal { alignas(8) unsigned char bytes[768]; };
-hipError_t agt_launch_lk_reseed(hipStream_t stream, const struct AgtStepParams& S, const struct AgtStepTables& T, int win, const AgtDenseFinal* F);
+hipError_t agt_launch_lk_reseed(hipStream_t stream, const struct AgtStepParams& S, const struct AgtStepTables& T, int win, const AgtDenseFinal* F, const struct AgtPyrArgs* ride = nullptr);
 hipError_t agt_launch_dense_final(hipStream_t stream, const AgtDenseFinal& F, int B);      // the deferred step as its own launch after all
 hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,
                             const float* mxyz, const float* mt, int M,

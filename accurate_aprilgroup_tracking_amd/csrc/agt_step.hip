@@ -519,10 +519,21 @@ __global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepPa
 // per stream behind the S.n_lk tracker workgroups), waiting for the frame's arrival count as the pose role of the fused step does:
 // the launch boundary between LK and PnP (~2 us at the end of a 25 us launch) and the solver's start-up leave the serial chain.
 // has_final == 0: no dense stage is pending (first frame of a clip).
+// Behind the solver's workgroups: the two-level pyramid pass of the NEXT frame (clip submission; n_pyr tiles per stream, Y0 / Y1 as in
+// pnp_coop_kernel) -- the kernel's registers allow one workgroup per CU, the trackers and the solver hold 241 of the 256, the tiles
+// take the rest and the CUs the trackers leave.
 template <int NLEV>
-__global__ __launch_bounds__(AGT_WAVE * 4) void lk_pnp_coop_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F, const int has_final)
+__global__ __launch_bounds__(AGT_WAVE * 4) void lk_pnp_coop_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F, const int has_final,
+                                                                   const AgtPyrArgs Y0, const AgtPyrArgs Y1, const int n_pyr)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    if ((int)blockIdx.x >= S.n_lk + S.n_pnp) {
+        const int t = (int)blockIdx.x - S.n_lk - S.n_pnp;
+        const int st = t / n_pyr, tile = t - st * n_pyr;
+        const int by = tile / Y0.gx, bx = tile - by * Y0.gx;
+        agt_pyr2::pyr_down2_body(Y0, Y1, bx, by, Y0.src + (long)st * Y0.sbatch, Y0.dst + (long)st * Y0.dbatch, Y1.dst + (long)st * Y1.dbatch, lds);
+        return;
+    }
     if ((int)blockIdx.x >= S.n_lk) {
         // the solve as the stand-alone pnp_coop_kernel runs it (tracker state in global memory: the role form of the group launches,
         // pnp_role_coop, keeps it in LDS across frames and spills 236 registers for it), behind the wait of a chained launch
@@ -676,8 +687,9 @@ bool agt_step_fits(int n, int B)
 
 // the one-frame LK role launch of step_serial with the previous frame's dense stage finished in its prologue (lk_reseed_kernel; F
 // null: nothing pending), and, with S.n_pnp > 0, the frame's cooperative pose solve chained to it in the same launch (lk_pnp_coop_kernel)
-hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal* F)
+hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal* F, const AgtPyrArgs* ride)
 {
+    if (ride && S.n_pnp <= 0) return hipErrorInvalidValue;          // (the pyramid tiles ride in the chained form only)
     if (win != 21 || S.n_lk <= 0 || S.lk_nf != 1 || !agt_lk_wide(S.lk.n, S.lk_B) || S.lk.flags != 0 || S.lk.err != nullptr) return hipErrorInvalidValue;
     const bool chain = S.n_pnp > 0;
     if (!chain && !F) return hipErrorInvalidValue;
@@ -703,9 +715,12 @@ hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, cons
         return hipGetLastError();
     }
     if (per < sizeof(agt_pnp::PnpShared)) per = sizeof(agt_pnp::PnpShared);
-    const unsigned grid = grid8 + (unsigned)P.n_pnp;
-    if (small) hipLaunchKernelGGL((lk_pnp_coop_kernel<3>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0);
-    else hipLaunchKernelGGL((lk_pnp_coop_kernel<AGT_MAX_LEVELS>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0);
+    const AgtPyrArgs none = AgtPyrArgs();
+    const int n_pyr = ride ? ride[0].gx * ride[0].gy : 0;
+    if (ride && per < (size_t)agt_pyr2::PYR2_LDS_BYTES) per = (size_t)agt_pyr2::PYR2_LDS_BYTES;
+    const unsigned grid = grid8 + (unsigned)P.n_pnp + (unsigned)(n_pyr * P.lk_B);
+    if (small) hipLaunchKernelGGL((lk_pnp_coop_kernel<3>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0, ride ? ride[0] : none, ride ? ride[1] : none, n_pyr > 0 ? n_pyr : 1);
+    else hipLaunchKernelGGL((lk_pnp_coop_kernel<AGT_MAX_LEVELS>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0, ride ? ride[0] : none, ride ? ride[1] : none, n_pyr > 0 ? n_pyr : 1);
     return hipGetLastError();
 }
 
