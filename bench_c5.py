@@ -77,7 +77,9 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                 "bytes_per_launch": int(bytes_per_launch),
                 "note": "latency-bound: one stream, 240 blocks, a dependent FP64 chain per sample; the image taps come from L2",
                 "stage_spans_us": {"pyramid": round(float(spans[0]), 2), "lk(240)": round(float(spans[1]), 2), "pnp(240)": round(float(spans[2]), 2),
-                                   "dense_gauss_newton(x%d launches)" % ITERS: round(float(spans[3]), 2), "dense_final(update+reseed)": round(float(spans[4]), 2)}}
+                                   "dense_gauss_newton(x%d launches)" % ITERS: round(float(spans[3]), 2), "dense_final(update+reseed)": round(float(spans[4]), 2)},
+                "stage_spans_note": "instrumented pass: every stage a launch of its own (HIP events between them); the timed blocks run LK | PnP as one "
+                                    "chained launch with the previous frame's final step as the LK prologue, so their frame is shorter than the sum of these spans"}
         cpu = None
         if not args.no_cpu_baseline and world == 1:
             cpu = cpu_baseline_c5(sq, bench.rendered[:, 0], mx, T, bench.NF)
@@ -86,7 +88,7 @@ def main_c5(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP, dense GN)",
                "data": "synthetic",
                "config": {"workload": wl["label"] % B, "streams_per_gpu": B, "dense_samples": M, "gn_iterations": ITERS, "photo_weight": PHOTO_WEIGHT,
-                          "corner_reseed": True, "launch": ("stage kernels in stream order; frames handed over as clips (agt_track_frames_dense): %d launches per frame, the next frame's pyramid pass rides in the four-wave PnP launch" % (2 + ITERS + 1)) if bench.clips else ("stage kernels in stream order, one call per frame (%d launches per frame)" % (3 + ITERS + 1))},
+                          "corner_reseed": True, "launch": ("frames handed over as clips (agt_track_frames_dense): %d launches per frame -- one chained launch [previous frame's last Gauss-Newton update + corner re-seed as the LK workgroups' prologue | LK | four-wave PnP behind the arrival count | the next frame's pyramid pass], then the %d accumulate launches" % (1 + ITERS, ITERS)) if bench.clips else ("stage kernels in stream order, one call per frame (%d launches per frame)" % (3 + ITERS + 1))},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
                "roofline": roof, "cpu_baseline": cpu, "accepted_frac": round(accepted, 4),
