@@ -78,6 +78,15 @@ __device__ __forceinline__ void rs_pack_taps(uint32_t a0, uint32_t a1, uint32_t 
     }
 }
 
+// a * b + c for operands within 24 bits, as ONE full-rate instruction (the compiler prefers v_mul_i32_i24 + v_add3_u32 trees:
+// shorter dependency chains, more instructions -- the one-wave kernel is bound by instruction issue, not by latency)
+__device__ __forceinline__ int rs_mad24(int a, int b, int c)
+{
+    int r;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+
 // three aligned dwords of an LDS row from byte address `a` on; `sh` = a & 3 is applied by the caller
 __device__ __forceinline__ void rs_row3(const uint8_t* s, int a, uint32_t& d0, uint32_t& d1, uint32_t& d2)
 {
@@ -86,24 +95,22 @@ __device__ __forceinline__ void rs_row3(const uint8_t* s, int a, uint32_t& d0, u
 }
 
 // Exact wave sums of two int32 per lane (|v| < 2^28), identical in every lane, ROUNDED ONCE to float.
-// 16-bit halves; each half: v_permlane32_swap folds { v0 | v1 } into one register (lanes 0-31: pair sums of v0, lanes
-// 32-63: of v1), four DPP row steps, one readlane per 16-lane row.  Both half sums are below 2^24 in magnitude, so they are
-// exact as floats and fma(hi, 65536, lo) rounds the exact integer sum once: the value of (float)(double)(int64 sum).
+// v_permlane32_swap folds { v0 | v1 } into one register (lanes 0-31: pair sums of v0, lanes 32-63: of v1); the pair sums (< 2^29)
+// and two DPP steps (x 4: < 2^31) still fit int32, so the values travel WHOLE that far and are split into 16-bit halves only for
+// the last two row steps and the read-lanes (round 4; rounds 2 / 3 ran two complete half-chains: 24 vector instructions against 18).
+// Both half sums are below 2^24 in magnitude, so they are exact as floats and fma(hi, 65536, lo) rounds the exact integer sum
+// once: the value of (float)(double)(int64 sum).
 __device__ __forceinline__ void rs_wave_sum2(int v0, int v1, float& s0, float& s1)
 {
-    auto chain = [](int a, int b, int& ta, int& tb) {
-        const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)a, (unsigned)b, false, false);
-        int x = (int)sw[0] + (int)sw[1];
-        x += agt_dpp_i32<0xB1>(x);
-        x += agt_dpp_i32<0x4E>(x);
-        x += agt_dpp_i32<0x141>(x);
-        x += agt_dpp_i32<0x140>(x);
-        ta = __builtin_amdgcn_readlane(x, 0) + __builtin_amdgcn_readlane(x, 16);
-        tb = __builtin_amdgcn_readlane(x, 32) + __builtin_amdgcn_readlane(x, 48);
-    };
-    int lo0, lo1, hi0, hi1;
-    chain(v0 & 0xffff, v1 & 0xffff, lo0, lo1);
-    chain(v0 >> 16, v1 >> 16, hi0, hi1);
+    const auto sw = __builtin_amdgcn_permlane32_swap((unsigned)v0, (unsigned)v1, false, false);
+    int x = (int)sw[0] + (int)sw[1];
+    x += agt_dpp_i32<0xB1>(x);
+    x += agt_dpp_i32<0x4E>(x);
+    int xl = x & 0xffff, xh = x >> 16;
+    xl += agt_dpp_i32<0x141>(xl); xh += agt_dpp_i32<0x141>(xh);
+    xl += agt_dpp_i32<0x140>(xl); xh += agt_dpp_i32<0x140>(xh);
+    const int lo0 = __builtin_amdgcn_readlane(xl, 0) + __builtin_amdgcn_readlane(xl, 16), lo1 = __builtin_amdgcn_readlane(xl, 32) + __builtin_amdgcn_readlane(xl, 48);
+    const int hi0 = __builtin_amdgcn_readlane(xh, 0) + __builtin_amdgcn_readlane(xh, 16), hi1 = __builtin_amdgcn_readlane(xh, 32) + __builtin_amdgcn_readlane(xh, 48);
     s0 = __builtin_fmaf((float)hi0, 65536.f, (float)lo0);
     s1 = __builtin_fmaf((float)hi1, 65536.f, (float)lo1);
 }
@@ -162,6 +169,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     const bool act = tid < R::NLANE;
     const int rr = act ? tid / R::SEG : 20, ss = act ? tid - rr * R::SEG : R::SEG - 1;     // window row, segment
     const int x0s = PX * ss;                                                               // first window column of the lane
+    const int lane_off = __mul24(rr, C::JP) + x0s;                                         // ... and its byte offset from the window's origin in a search tile
     const long pidx = (long)b * P->n + pt;
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
@@ -394,8 +402,11 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
 #pragma unroll
         for (int k = 0; k < PX; k++) IvR[k] = (1 << (W_BITS - 5 - 1)) - (Iv[k] << (W_BITS - 5));
         // the lane's temporal differences J - I (values * 32) at window position (inx, iny), weights in WL / WH
+        // (requesting the six dwords BEFORE the weights are computed, as the four-wave bodies do, measured slower here: 41.5-41.7
+        // against 41.0-41.1 us per 64-stream step)
         auto window_taps = [&](int inx, int iny, int (&Jv)[PX]) {
-            const int a = __mul24(iny - jy0 + rr, C::JP) + (inx - (jx0 & ~3)) + x0s;
+            // (the window's origin inside the tile is wave-uniform; the lane's own offset is a constant)
+            const int a = (__mul24(iny - jy0, C::JP) + (inx - (jx0 & ~3))) + lane_off;
             const int shj = a & 3;
             const uint32_t* p0 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3));
             const uint32_t* p1 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3) + C::JP);
@@ -438,7 +449,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             window_taps(inx, iny, Jv);
             int b1 = 0, b2 = 0;
 #pragma unroll
-            for (int k = 0; k < PX; k++) { b1 += __mul24(Jv[k], Ix[k]); b2 += __mul24(Jv[k], Iy[k]); }
+            for (int k = 0; k < PX; k++) { b1 = rs_mad24(Jv[k], Ix[k], b1); b2 = rs_mad24(Jv[k], Iy[k], b2); }
             b1 = act ? b1 : 0; b2 = act ? b2 : 0;
             float sb1, sb2;
             sum2(b1, b2, sb1, sb2);

@@ -219,6 +219,7 @@ class Bench:
             self.truth = torch.zeros((4, B, 48, 2))
             self.npts, self.render_s, self.seqs, self.rendered = 48, 0.0, [], None
             self.trk = StubTracker(rank, self.NF, self.nseq)
+            self._views = {}
             self.pos = self.since = 0
             self.clips = False
             return
@@ -246,6 +247,7 @@ class Bench:
         self.render_s = time.time() - t_r
         sq0 = self.seqs[0]
         self.trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+        self._views = {}
         self.pos = 0            # ring index of the newest frame handed to the tracker
         self.clips = not args.per_step_calls
         self.since = 0          # frames since the corner set was last refreshed
@@ -273,7 +275,20 @@ class Bench:
             a = (self.pos + 1) % self.ring_slots
             m = min(n - k, self.ring_slots - a, 2 * REDETECT - self.since)
             if m > 1 and self.clips:
-                self.trk.step_many(self.ring[a:a + m], out[k:k + m] if out is not None else None)
+                # (the views of the ring / of the record buffer are made once: slicing two tensors costs this harness ~4 us per call,
+                # with the GPU idle -- a 20-step block is one call)
+                ck = (a, m)
+                clip = self._views.get(ck)
+                if clip is None:
+                    clip = self._views[ck] = self.ring[a:a + m]
+                ov = None
+                if out is not None:
+                    ok_ = (id(out), k, m)
+                    ov = self._views.get(ok_)
+                    if ov is None:
+                        ov = self._views[ok_] = out[k:k + m]
+                        self._views[("keep", id(out))] = out          # (the id stays unique while the tensor is alive)
+                self.trk.step_many(clip, ov)
             else:
                 m = 1
                 self.trk.step(self.ring[a], out[k] if out is not None else None)
