@@ -298,6 +298,61 @@ def test_dense_clip_submission_equals_single_calls(oracle, n_tags):
         assert np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(dn.view(np.uint64), dn0.view(np.uint64))
 
 
+@pytest.mark.gpu
+def test_dense_clip_with_rejected_and_lost_frames_equals_single_calls(oracle):
+    """The clip form's launches (include/agt_hip.h agt_track_frames_dense: final update + re-seed as the next LK launch's prologue, LK and
+    the four-wave PnP in one chained launch) on two DIFFERENT streams of which one sees a frame from elsewhere in its sequence (the
+    gate rejects: done word set, no refinement, no re-seed) and later a blank frame (LK loses every corner for good): records,
+    corner sets and LK status bitwise those of agt_track_frame_dense called frame by frame, whatever the clip cuts."""
+    import torch
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    seqs = [syn.Sequence(1280, 720, n_tags=60, n_frames=8, seed=8 + i, supersample=2, group_seed=8) for i in range(2)]
+    s = seqs[0]
+    mx = syn.model_samples(s.group, 16)
+    T = _template(s, mx, 0)
+    fr = [sq.frames() for sq in seqs]
+    order0 = [1, 2, 3, 4, 5, 6, 7, 6, 5, 4]
+    order1 = [1, 2, 7, 3, 4, 5, -1, 6, 7, 6]          # stream 1: frame 7 after frame 2 (a jump), later a blank frame
+    K = len(order0)
+    blank = np.full((720, 1280), 128, np.uint8)
+    clip = np.stack([np.stack([fr[0][order0[k]], blank if order1[k] < 0 else fr[1][order1[k]]]) for k in range(K)])
+    clip = torch.from_numpy(clip).cuda().contiguous()                    # [K, 2, H, W]
+    first = torch.from_numpy(np.stack([fr[0][0], fr[1][0]])).cuda().contiguous()
+    c0 = torch.from_numpy(np.stack([seqs[0].corners(0), seqs[1].corners(0)])).cuda().contiguous()
+    outs = []
+    for cuts in (None, [K], [3, 1, 6], [2, 0, 5, 0, 1]):
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2)
+        trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=3, photo_weight=0.05, reseed=True)
+        trk.reset(first, c0)
+        so = trk.new_state_buffer(K)
+        do = torch.zeros((K, 2, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
+        if cuts is None:
+            for k in range(K):
+                trk.step_dense(clip[k], so[k], do[k])
+        else:
+            k = 0
+            for m in cuts:
+                if m == 0:
+                    trk.step_dense(clip[k], so[k], do[k]); k += 1
+                else:
+                    trk.step_many_dense(clip[k:k + m], so[k:k + m], do[k:k + m]); k += m
+            assert k == K
+        torch.cuda.synchronize()
+        import ctypes as C
+        cp, sp = trk.corners()                                           # device addresses of the newest frame's corner set / LK status
+        pts, status = np.zeros((2, 240, 2), np.float32), np.zeros((2, 240), np.uint8)
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, pts.ctypes.data_as(C.c_void_p), C.c_void_p(cp), pts.nbytes), "agt_download")
+        H.check(trk.ctx.L.agt_download(trk.ctx.h, status.ctypes.data_as(C.c_void_p), C.c_void_p(sp), status.nbytes), "agt_download")
+        outs.append((so.cpu().numpy().copy(), do.cpu().numpy().copy(), pts, status))
+    st0, dn0, p0, u0 = outs[0]
+    assert st0[:, 0, H.ST_OK].all() and (dn0[:, 0, H.DN_REFINED] == 1.0).all()              # the undisturbed stream
+    assert not st0[6:, 1, H.ST_OK].any() and (dn0[6:, 1, H.DN_REFINED] == 0.0).all()          # from the blank frame on: nothing tracked, nothing refined
+    for st, dn, p, u in outs[1:]:
+        assert np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(dn.view(np.uint64), dn0.view(np.uint64))
+        assert np.array_equal(p.view(np.uint32), p0.view(np.uint32)) and np.array_equal(u, u0)
+
+
 def test_synthetic_60_tag_layout():
     """the 60-tag model of configs[4]: every tag inside a 1280x720 frame along the trajectory, none overlapping another"""
     s = syn.Sequence(1280, 720, n_tags=60, n_frames=120, seed=8, supersample=1)
