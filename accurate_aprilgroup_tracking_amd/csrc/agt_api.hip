@@ -1038,7 +1038,10 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
                       ((uintptr_t)next_frame & 3) == 0 && (agt_pnp_can_ride(c->trk_n) || (d_dense_out && c->dn_iters > 0));
     // Dense clips with the cooperative solver (64 < n <= 256): LK and PnP of the frame in ONE launch, the solver waiting for the
     // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in the dense launch
-    const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1;
+    // (while trackers + solvers are co-resident at the one workgroup per CU the solver's registers leave: more streams keep the LK
+    // launch of its own, whose 78 registers put several workgroups on a CU)
+    const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1 &&
+                           (long)c->trk_n * B + B <= 256;
     const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n) && !chain_pnp;
     if (ride) {
         // (what pyramid_build_on registers for a frame, for frame t + 1 in its ring entry)

@@ -705,7 +705,7 @@ hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, cons
     memset(&D, 0, sizeof(D));
     if (F) {
         memcpy(&D, F->bytes, sizeof(D));
-        if (D.N != P.lk.n || D.seed_pts != P.lk.prev_pts) return hipErrorInvalidValue;      // (the re-seeded corner set IS this launch's start)
+        if (D.N != P.lk.n || (D.seed_pts && D.seed_pts != P.lk.prev_pts)) return hipErrorInvalidValue;      // (a re-seeded corner set IS this launch's start)
     }
     const bool small = P.lk.max_level < 3;
     size_t per = small ? lk_role_lds<21, 4, 3>(P.lk.max_level + 1) : lk_role_lds<21, 4, AGT_MAX_LEVELS>(P.lk.max_level + 1);

@@ -256,8 +256,8 @@ def test_c5_stream_matches_oracle_chain(oracle, reseed, tmp_path):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("n_tags", [60, 12])
-def test_dense_clip_submission_equals_single_calls(oracle, n_tags):
+@pytest.mark.parametrize("n_tags,reseed", [(60, True), (12, True), (60, False), (12, False)])
+def test_dense_clip_submission_equals_single_calls(oracle, n_tags, reseed):
     """agt_track_frames_dense (include/agt_hip.h): a clip of frames in one call -- the pyramid pass of frame k + 1 rides in a
     launch of frame k: the four-wave PnP launch (240 corners) or the second dense launch (48 corners) -- leaves bitwise the
     records of agt_track_frame_dense called frame by frame; clips cut at arbitrary places, a clip of one frame, a single call
@@ -275,7 +275,7 @@ def test_dense_clip_submission_equals_single_calls(oracle, n_tags):
     outs = []
     for cuts in (None, [K], [1, 4, 1, 6], [5, 0, 6]):
         trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
-        trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=4, photo_weight=0.05, reseed=True)
+        trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=4, photo_weight=0.05, reseed=reseed)
         trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
         so = trk.new_state_buffer(K)
         do = torch.zeros((K, 1, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
