@@ -309,9 +309,12 @@ int agt_track_frame_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, s
                           double* d_state_out, double* d_dense_out);
 /* A clip of `count` consecutive frames (frame k at d_frames + k * frame_stride; all with the same pitch and stream stride):
  * agt_track_frame_dense for each, in order, d_state_out [count][B][AGT_STATE_STRIDE] (or NULL), d_dense_out
- * [count][B][AGT_DENSE_STRIDE].  Same records as `count` single calls; knowing the next frame, the library lets its pyramid
- * pass ride in one of the current frame's launches -- the four-wave PnP launch when there are more than 64 corners, else the SECOND
- * dense launch (one launch less in every frame's serial chain). */
+ * [count][B][AGT_DENSE_STRIDE].  Same records as `count` single calls, bit for bit; knowing the next frame, the library
+ * shortens every frame's serial chain: the next frame's pyramid pass rides in one of the current frame's launches, the dense
+ * stage's last step (final Gauss-Newton update + corner re-seed) of frame k runs at the head of frame k + 1's LK launch, and with
+ * more than 64 corners on one stream LK and PnP of a frame are one chained launch.  All of the clip's work is enqueued when the
+ * call returns, in stream order: frame k's dense record is complete when the work enqueued by this call is (the record of every
+ * frame but the last is finished by the launch that tracks the NEXT frame). */
 int agt_track_frames_dense(agt_ctx* ctx, const uint8_t* d_frames, size_t pitch, size_t batch_stride, size_t frame_stride, int B, int count,
                            double* d_state_out, double* d_dense_out);
 
