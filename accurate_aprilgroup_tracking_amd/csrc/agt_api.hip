@@ -1079,6 +1079,12 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
             T.lk.done[0] = c->lk_done + (size_t)slot * c->cfg.max_streams;
             T.pnp.img[0] = c->corners[slot]; T.pnp.mask[0] = c->status[slot]; T.pnp.so[0] = d_state_out;
             T.pnp.wait[0] = T.lk.done[0]; T.pnp.target[0] = c->lk_target[slot];
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_CHAIN_WITHHOLD_DENSE=k makes the k-th chained LK | PnP launch of the dense tracker expect one
+            // arrival more than its LK role delivers (tests/test_dense.py drives the solver's give-up path with it)
+            { static const int wh = [] { const char* e = getenv("AGT_CHAIN_WITHHOLD_DENSE"); return e ? atoi(e) : 0; }();
+              static int seen = 0;
+              if (wh > 0 && ++seen == wh) T.pnp.target[0] += 1; }
+#endif
         }
         if (c->dense_pending || chain_pnp) {
             e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_pending ? &c->dense_final : nullptr, (ride && chain_pnp) ? npyr : nullptr);

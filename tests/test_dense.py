@@ -2,6 +2,7 @@
 exists; the specification lives in oracle/cv_dense.c.  CPU: the oracle satisfies its own spec
 (finite-difference Jacobian, convergence to a known pose).  GPU: HIP vs oracle."""
 import ctypes as C
+import os
 import numpy as np
 import pytest
 
@@ -351,6 +352,71 @@ def test_dense_clip_with_rejected_and_lost_frames_equals_single_calls(oracle):
     for st, dn, p, u in outs[1:]:
         assert np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(dn.view(np.uint64), dn0.view(np.uint64))
         assert np.array_equal(p.view(np.uint32), p0.view(np.uint32)) and np.array_equal(u, u0)
+
+
+_DENSE_GIVE_UP_CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AGT_REPO_ROOT"])
+import torch
+from accurate_aprilgroup_tracking_amd import hiplib as H
+H.LIB_PATH = os.path.join(os.path.dirname(H.LIB_PATH), "libagt_hip_dbg.so")
+from accurate_aprilgroup_tracking_amd import synthetic as syn
+from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+s = syn.Sequence(1280, 720, n_tags=60, n_frames=6, seed=8, supersample=2)
+mx = syn.model_samples(s.group, 16)
+T = np.nan_to_num(syn.sample_bilinear(s.frame(0), syn.project(mx, s.rvecs[0], s.tvecs[0], s.K)), nan=128.0).astype(np.float32)
+frames = torch.from_numpy(s.frames()).cuda()
+order = [1, 2, 3, 4, 5, 4, 3, 2]
+clip = frames[order].unsqueeze(1).contiguous()
+trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=1)
+trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=3, photo_weight=0.05, reseed=True)
+out = {}
+def run(tag):
+    trk.reset(frames[0:1].contiguous(), torch.from_numpy(s.corners(0)[None]).cuda().contiguous())
+    so = trk.new_state_buffer(len(order))
+    do = torch.zeros((len(order), 1, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
+    trk.step_many_dense(clip, so, do)
+    code = trk.ctx.L.agt_synchronize(trk.ctx.h)
+    out[tag] = dict(st=so.cpu().numpy()[:, 0].tolist(), dn=do.cpu().numpy()[:, 0].tolist(), code=code, chain_fault=trk.read_state()[0].chain_fault)
+run("faulted")          # AGT_CHAIN_WITHHOLD_DENSE=3: the third chained LK | PnP launch never sees its last arrival
+run("recovered")        # the knob has fired; agt_tracker_reset brings the stream back
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.gpu
+def test_dense_chained_launch_give_up_is_fail_stop(oracle):
+    """The chained LK | PnP launch of dense clips (agt_step.hip lk_pnp_coop_kernel) when an arrival never comes (diagnostic library,
+    AGT_CHAIN_WITHHOLD_DENSE): the solver's workgroup gives up after its poll budget, the frame's record is flagged
+    AGT_TRK_CHAIN_TIMEOUT and zero, its dense record unrefined, every later record of the stream flagged too; the clip DRAINS (no
+    hang), agt_synchronize reports AGT_ERR_CHAIN, agt_tracker_reset recovers: the records of a clean run, bit for bit."""
+    import json
+    import subprocess
+    import sys
+    import torch
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "accurate_aprilgroup_tracking_amd", "libagt_hip_dbg.so")
+    if not os.path.exists(dbg):
+        subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(root, "accurate_aprilgroup_tracking_amd", "csrc"), "dbg"])
+    env = dict(os.environ, AGT_CHAIN_WITHHOLD_DENSE="3", AGT_REPO_ROOT=root)
+    res = subprocess.run([sys.executable, "-c", _DENSE_GIVE_UP_CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    f, r = out["faulted"], out["recovered"]
+    st, dn = np.array(f["st"]), np.array(f["dn"])
+    flags = st[:, H.ST_FLAGS].astype(int)
+    bad = np.nonzero(flags & H.TRK_CHAIN_TIMEOUT)[0]
+    assert len(bad) and int(bad[0]) == 2, "the withheld arrival belongs to the third chained launch"
+    assert np.array_equal(bad, np.arange(2, len(st))), "every record after the give-up is flagged (sticky fault)"
+    assert (st[2:, :8] == 0).all() and (dn[2:, H.DN_REFINED] == 0).all(), "nothing is solved or refined on the faulted frames"
+    assert st[:2, H.ST_OK].all() and (dn[:2, H.DN_REFINED] == 1).all()
+    assert f["code"] == -8 and f["chain_fault"] == 1, "agt_synchronize reports AGT_ERR_CHAIN"
+    rs, rd = np.array(r["st"]), np.array(r["dn"])
+    assert r["code"] == 0 and r["chain_fault"] == 0 and rs[:, H.ST_OK].all() and (rd[:, H.DN_REFINED] == 1).all()
+    assert np.array_equal(rs[:2], st[:2]) and np.array_equal(rd[:2], dn[:2]), "the frames before the give-up were those of the clean run"
 
 
 def test_synthetic_60_tag_layout():
