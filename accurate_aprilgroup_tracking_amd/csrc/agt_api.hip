@@ -998,13 +998,10 @@ static int ms_join(agt_ctx* c)
     return AGT_OK;
 }
 
-// pyrDown.. -> LK -> PnP (+ dense stage) as separate launches on the context's stream: pose complete in stream order
-// next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
-// stream stride -- its two-level pyramid pass rides in this frame's PnP launch (more than 64 corners) or second dense launch (agt_dense.hip) instead of being the
-// first launch of its own chain.
+// Dense clips (step_serial below): which of the round-4 forms are on.
 static int dense_defer_on()
 {
-#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_DENSE_DEFER=0 keeps dense_final_kernel a launch of its own in clips, 1 also the pose solve
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_DENSE_DEFER=0 keeps dense_final_kernel a launch of its own in clips, 1 keeps LK and the pose solve separate launches
     static const int on = [] { const char* e = getenv("AGT_DENSE_DEFER"); return e ? atoi(e) : 2; }();
     return on;
 #else
@@ -1012,6 +1009,11 @@ static int dense_defer_on()
 #endif
 }
 
+// pyrDown.. -> LK -> PnP (+ dense stage) as launches on the context's stream: pose complete in stream order.
+// next_frame != null (clip submission with the dense stage): the caller will hand that frame in next, with the same pitch and
+// stream stride -- its two-level pyramid pass rides in one of this frame's launches (the chained LK | PnP launch, the four-wave PnP
+// launch, or the second dense launch) instead of being the first launch of its own chain, and this frame's last dense step is left
+// to that frame's LK launch (c->dense_pending).
 static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B,
                        double* d_state_out, double* d_dense_out, hipEvent_t* pev, const uint8_t* next_frame = nullptr)
 {
@@ -1037,7 +1039,7 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     const bool ride = next_frame && c->eff_max_level == 2 && B <= AGT_PYR2_MAX_B && nslot != slot && nslot < c->ring &&
                       ((uintptr_t)next_frame & 3) == 0 && (agt_pnp_can_ride(c->trk_n) || (d_dense_out && c->dn_iters > 0));
     // Dense clips with the cooperative solver (64 < n <= 256): LK and PnP of the frame in ONE launch, the solver waiting for the
-    // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in the dense launch
+    // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in that launch as well
     // (while trackers + solvers are co-resident at the one workgroup per CU the solver's registers leave: more streams keep the LK
     // launch of its own, whose 78 registers put several workgroups on a CU)
     const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1 &&
