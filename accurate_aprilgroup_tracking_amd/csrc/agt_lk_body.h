@@ -248,7 +248,10 @@ template <int WIN, int NW>
 __host__ __device__ constexpr size_t lk_lds_bytes(int levels)
 {
     using C = LkCfg<WIN, NW>;
-    return (size_t)levels * C::LEVEL_LDS + (size_t)((C::DW * C::DW + 3) & ~3) * sizeof(int) + (size_t)2 * NW * 4 * sizeof(long long);
+    size_t behind = (size_t)((C::DW * C::DW + 3) & ~3) * sizeof(int) + (size_t)2 * NW * 4 * sizeof(long long);
+    // (one wave per corner, 21 x 21: the row-segment body keeps a 23 x 24 int32 grid there instead -- agt_lk_rs_body.h RS_B_BYTES)
+    if (WIN == 21 && NW == 1 && behind < (size_t)23 * 24 * 4) behind = (size_t)23 * 24 * 4;
+    return (size_t)levels * C::LEVEL_LDS + behind;
 }
 
 

@@ -122,6 +122,9 @@ __device__ __forceinline__ const uint8_t* rs_uniform_ptr(const uint8_t* p)
     return (const uint8_t*)(((unsigned long long)hi << 32) | lo);
 }
 
+// the one-wave shape's grid of un-rounded interpolations in LDS: 23 rows (window rows + 2) of 24 int32 (23 columns + pad)
+constexpr int RS_BROWS = 23, RS_BP = 24, RS_B_BYTES = RS_BROWS * RS_BP * 4;
+
 // LDS bytes of one corner: the level tiles only (no derivative tile, no reduction slots)
 __host__ __device__ constexpr size_t lk_rs_lds_bytes(int levels) { return (size_t)levels * LkCfg<21, 1>::LEVEL_LDS; }
 
@@ -315,6 +318,65 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         int Iv[PX], Ix[PX], Iy[PX];
         {
             const int offI = (ipx - 1) - ((ipx - 1) & ~3);
+            int Bv[3][NB];
+            if constexpr (NW == 1) {
+                // Round 4: every B value is interpolated ONCE.  The 23 x 23 grid of un-rounded interpolations the window's Scharr
+                // taps touch is split over 46 lanes -- lane l = (row l >> 1, columns 12 (l & 1) .. + 11): two tile rows as four
+                // aligned dwords each, 12 packed taps -- written to LDS as int32 (behind the tiles, where the general body keeps
+                // its derivative tile) and read back by the lanes as their 3 x 9 neighbourhoods; the corner is one wave, LDS
+                // operations of a wave execute in order, no barrier.  (Rounds 2 / 3: every lane interpolated its own 3 x 9 patch
+                // -- 1,701 interpolations for 529 values, 132 vector instructions per lane and level against ~70 now.)
+                constexpr int BP = RS_BP;
+                int* sB = reinterpret_cast<int*>(lds + (P->max_level + 1) * C::LEVEL_LDS);
+                block_sync<NW>();                               // (the previous level's readers are done with sB)
+                {
+                    const bool on = lane < 2 * RS_BROWS;
+                    const int br = on ? lane >> 1 : RS_BROWS - 1, seg = lane & 1;
+                    const int c0 = offI + 12 * seg, sh = c0 & 3;
+                    uint32_t ea[4], eb[4];                      // bytes 0 .. 15 from column c0 of tile rows br, br + 1 (byte 12 is the last one used)
+                    {
+                        const uint32_t* pa = reinterpret_cast<const uint32_t*>(sI + __mul24(br, C::IP) + (c0 & ~3));
+                        const uint32_t* pb = reinterpret_cast<const uint32_t*>(sI + __mul24(br + 1, C::IP) + (c0 & ~3));
+                        uint32_t qa[4], qb[4];
+#pragma unroll
+                        for (int d = 0; d < 4; d++) { qa[d] = pa[d]; qb[d] = pb[d]; }
+#pragma unroll
+                        for (int d = 0; d < 3; d++) { ea[d] = __builtin_amdgcn_alignbyte(qa[d + 1], qa[d], sh); eb[d] = __builtin_amdgcn_alignbyte(qb[d + 1], qb[d], sh); }
+                        ea[3] = __builtin_amdgcn_alignbyte(0u, qa[3], sh); eb[3] = __builtin_amdgcn_alignbyte(0u, qb[3], sh);
+                    }
+                    uint32_t Pk[12];
+                    Pk[0] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL0); Pk[1] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL1); Pk[2] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL2);
+                    {
+                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[1], ea[0], 3), mu = __builtin_amdgcn_alignbyte(eb[1], eb[0], 3);      // bytes 3..6
+                        Pk[3] = __builtin_amdgcn_perm(mu, m, RS_SEL0); Pk[4] = __builtin_amdgcn_perm(mu, m, RS_SEL1); Pk[5] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
+                    }
+                    Pk[6] = __builtin_amdgcn_perm(eb[1], ea[1], RS_SEL2);                                                                      // bytes 6, 7
+                    {
+                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[2], ea[1], 3), mu = __builtin_amdgcn_alignbyte(eb[2], eb[1], 3);      // bytes 7..10
+                        Pk[7] = __builtin_amdgcn_perm(mu, m, RS_SEL0); Pk[8] = __builtin_amdgcn_perm(mu, m, RS_SEL1); Pk[9] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
+                    }
+                    Pk[10] = __builtin_amdgcn_perm(eb[2], ea[2], RS_SEL2);                                                                     // bytes 10, 11
+                    {
+                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[3], ea[2], 3), mu = __builtin_amdgcn_alignbyte(eb[3], eb[2], 3);      // bytes 11..14
+                        Pk[11] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
+                    }
+                    int Bw[12];
+#pragma unroll
+                    for (int k = 0; k < 12; k++) Bw[k] = rs_tap(Pk[k], WL, WH, 0u);
+                    if (neg11) rs_fix_taps<12>(Bw, Pk, neg11);
+                    if (on) {
+                        int4* o = reinterpret_cast<int4*>(sB + br * BP + 12 * seg);
+                        o[0] = make_int4(Bw[0], Bw[1], Bw[2], Bw[3]); o[1] = make_int4(Bw[4], Bw[5], Bw[6], Bw[7]); o[2] = make_int4(Bw[8], Bw[9], Bw[10], Bw[11]);
+                    }
+                }
+                block_sync<NW>();
+#pragma unroll
+                for (int i = 0; i < 3; i++) {
+                    const int* r = sB + (rr + i) * BP + x0s;
+#pragma unroll
+                    for (int k = 0; k < NB; k++) Bv[i][k] = r[k];
+                }
+            } else {
             const int c0 = offI + x0s, sh = c0 & 3;
             uint32_t e[4][3];                                   // four tile rows, bytes 0..11 from column c0 on
 #pragma unroll
@@ -327,7 +389,6 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 e[i][1] = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
                 e[i][2] = __builtin_amdgcn_alignbyte(q[3], q[2], sh);
             }
-            int Bv[3][NB];
 #pragma unroll
             for (int i = 0; i < 3; i++) {
                 uint32_t Pk[NB];
@@ -335,6 +396,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
 #pragma unroll
                 for (int k = 0; k < NB; k++) Bv[i][k] = rs_tap(Pk[k], WL, WH, 0u);
                 if (neg11) rs_fix_taps<NB>(Bv[i], Pk, neg11);
+            }
             }
             int Cs[NB], Es[NB];                                 // vertical Scharr halves per column
             // (3 x as shift-add, 10 x as a 24-bit multiply: B < 2^22, so every operand fits; v_mul_lo_u32 is quarter rate)
