@@ -8,4 +8,4 @@ run c2k20 --steps 20 --warmup 5
 run c3 --workload c3 --steps 256 --warmup 16 --render-frames 8
 run c3pairs --workload c3pairs --steps 256
 run c4 --workload c4 --no-extras
-run c5 --workload c5 --steps 100 --warmup 10
+run c5 --workload c5
