@@ -257,6 +257,20 @@ struct lk_level_ctx {
 long cvo_dbg_iters[CVO_MAX_LEVELS], cvo_dbg_points[CVO_MAX_LEVELS];
 void cvo_dbg_reset(void) { memset(cvo_dbg_iters, 0, sizeof(cvo_dbg_iters)); memset(cvo_dbg_points, 0, sizeof(cvo_dbg_points)); }
 
+/* ---- CVO_ACC_FLOAT_SIMD: the accumulation order of OpenCV's CV_SIMD128 (x86 SSE baseline, no FMA) loops of LKTrackerInvoker
+ * [OpenCV-knowledge: 4.x modules/video/src/lkpyramid.cpp, universal intrinsics; the apt / pip builds the reference runs on].
+ * A window row is consumed 8 pixels at a time while x <= ww - 8; the remaining ww % 8 pixels go through the scalar loop into the
+ * scalar float accumulators (iA11.., ib1, ib2), which are added to the horizontal sum of the vector accumulators at the end.
+ *   covariance: two groups of four pixels per step; lane l of qA11 / qA12 / qA22 (four float lanes, alive across rows) takes
+ *     pixel 4 * group + l:  qA = qA + fx * fy  with the product rounded to float before the add (v_muladd without FMA);
+ *   mismatch:   v_dotprod on int16 pairs gives EXACT int32 pair sums  d[k] * I[k] + d[k + 4] * I[k + 4]  (k = 0..3 of the
+ *     8-pixel step), converted to float and added:  k = 0, 1 into qb0 (lanes x, y, x, y), k = 2, 3 into qb1;  at the end
+ *     q = qb0 + qb1,  ib1 += (q[0] + 0) + (q[2] + 0),  ib2 += (q[1] + 0) + (q[3] + 0);
+ *   v_reduce_sum(float32x4) = (l0 + l2) + (l1 + l3)  (SSE: add the high half onto the low half, then lane 1 onto lane 0).
+ * The level-0 error sum has no vector form there: scalar order. */
+struct simd_acc3 { float q11[4], q12[4], q22[4]; float t11, t12, t22; };
+static inline float simd_reduce4(const float* q) { float lo = q[0] + q[2], hi = q[1] + q[3]; return lo + hi; }
+
 /* LKTrackerInvoker::operator() for one point */
 static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, float* next_pts,
                            uint8_t* status, float* err, int ptidx, int16_t* patch /* 3*win area */)
@@ -298,6 +312,8 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
     int16_t* dIwin = patch + ww * wh;      /* 2*ww*wh */
     int64_t sA11 = 0, sA12 = 0, sA22 = 0;
     float fA11 = 0, fA12 = 0, fA22 = 0;
+    struct simd_acc3 qa; memset(&qa, 0, sizeof(qa));
+    const int simd_w = c->acc_mode == CVO_ACC_FLOAT_SIMD ? (ww / 8) * 8 : 0;     /* window columns the 8-pixel vector loop covers */
     for (int y = 0; y < wh; y++) {
         const uint8_t* src = Ibase + (ptrdiff_t)(y + ipy) * stepI + ipx;
         const int16_t* dsrc = c->deriv + (ptrdiff_t)(y + ipy) * dstep + ipx * 2;
@@ -310,6 +326,11 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
             Ip[x] = (int16_t)ival; dIp[0] = (int16_t)ixval; dIp[1] = (int16_t)iyval;
             if (c->acc_mode == CVO_ACC_EXACT) {
                 sA11 += (int64_t)ixval * ixval; sA12 += (int64_t)ixval * iyval; sA22 += (int64_t)iyval * iyval;
+            } else if (x < simd_w) {
+                /* vector lane x % 4: float(ix) * float(iy) rounded, then added (no FMA) */
+                const float fx = (float)ixval, fy = (float)iyval;
+                const float p11 = fx * fx, p12 = fx * fy, p22 = fy * fy;
+                qa.q11[x & 3] = qa.q11[x & 3] + p11; qa.q12[x & 3] = qa.q12[x & 3] + p12; qa.q22[x & 3] = qa.q22[x & 3] + p22;
             } else {
                 fA11 += (float)(ixval * ixval); fA12 += (float)(ixval * iyval); fA22 += (float)(iyval * iyval);
             }
@@ -320,6 +341,7 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
         /* exact sum (< 2^53) rounded once to float */
         A11 = (float)(double)sA11 * FLT_SCALE; A12 = (float)(double)sA12 * FLT_SCALE; A22 = (float)(double)sA22 * FLT_SCALE;
     } else {
+        if (simd_w) { fA11 += simd_reduce4(qa.q11); fA12 += simd_reduce4(qa.q12); fA22 += simd_reduce4(qa.q22); }
         A11 = fA11 * FLT_SCALE; A12 = fA12 * FLT_SCALE; A22 = fA22 * FLT_SCALE;
     }
     float D = A11 * A22 - A12 * A12;
@@ -347,11 +369,25 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
         iw10 = cv_round_f((1.f - a) * b * (1 << W_BITS));
         iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;
         int64_t sb1 = 0, sb2 = 0; float fb1 = 0, fb2 = 0;
+        float qb0[4] = { 0, 0, 0, 0 }, qb1[4] = { 0, 0, 0, 0 };
         for (int y = 0; y < wh; y++) {
             const uint8_t* Jp = Jbase + (ptrdiff_t)(y + iny) * stepJ + inx;
             const int16_t* Ip = Iwin + y * ww;
             const int16_t* dIp = dIwin + y * ww * 2;
-            for (int x = 0; x < ww; x++, dIp += 2) {
+            int x = 0;
+            for (; x < simd_w; x += 8, dIp += 16) {
+                int d8[8];
+                for (int k = 0; k < 8; k++)
+                    d8[k] = (int16_t)(DESCALE(Jp[x + k] * iw00 + Jp[x + k + 1] * iw01 + Jp[x + k + stepJ] * iw10 + Jp[x + k + stepJ + 1] * iw11, W_BITS - 5) - Ip[x + k]);
+                /* v_dotprod: int32 pair sums of pixels (k, k + 4); k = 0, 1 -> qb0 lanes (x, y, x, y), k = 2, 3 -> qb1 */
+                for (int k = 0; k < 4; k++) {
+                    const int px = d8[k] * dIp[2 * k] + d8[k + 4] * dIp[2 * (k + 4)];
+                    const int py = d8[k] * dIp[2 * k + 1] + d8[k + 4] * dIp[2 * (k + 4) + 1];
+                    float* q = k < 2 ? qb0 : qb1;
+                    q[2 * (k & 1)] = q[2 * (k & 1)] + (float)px; q[2 * (k & 1) + 1] = q[2 * (k & 1) + 1] + (float)py;
+                }
+            }
+            for (; x < ww; x++, dIp += 2) {
                 int diff = DESCALE(Jp[x] * iw00 + Jp[x + 1] * iw01 + Jp[x + stepJ] * iw10 + Jp[x + stepJ + 1] * iw11, W_BITS - 5) - Ip[x];
                 if (c->acc_mode == CVO_ACC_EXACT) {
                     sb1 += (int64_t)diff * dIp[0]; sb2 += (int64_t)diff * dIp[1];
@@ -362,7 +398,15 @@ static void lk_track_point(const struct lk_level_ctx* c, const float* prev_pts, 
         }
         float b1, b2;
         if (c->acc_mode == CVO_ACC_EXACT) { b1 = (float)(double)sb1 * FLT_SCALE; b2 = (float)(double)sb2 * FLT_SCALE; }
-        else { b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE; }
+        else {
+            if (simd_w) {
+                /* v_recombine(v_interleave_pairs(qb0 + qb1), 0): qf0 = (X0, X1, 0, 0), qf1 = (Y0, Y1, 0, 0); v_reduce_sum of each */
+                float q[4]; for (int k = 0; k < 4; k++) q[k] = qb0[k] + qb1[k];
+                const float qf0[4] = { q[0], q[2], 0.f, 0.f }, qf1[4] = { q[1], q[3], 0.f, 0.f };
+                fb1 += simd_reduce4(qf0); fb2 += simd_reduce4(qf1);
+            }
+            b1 = fb1 * FLT_SCALE; b2 = fb2 * FLT_SCALE;
+        }
         float dx = (A12 * b2 - A22 * b1) * D;
         float dy = (A12 * b1 - A11 * b2) * D;
         nextx += dx; nexty += dy;

@@ -51,6 +51,9 @@ extern "C" {
 /* accumulation mode for the LK inner sums */
 #define CVO_ACC_EXACT        0  /* exact integer sums, rounded once (every OpenCV build approximates this) */
 #define CVO_ACC_FLOAT_SCALAR 1  /* OpenCV's non-SIMD order: sequential float adds in (y,x) order */
+#define CVO_ACC_FLOAT_SIMD   2  /* OpenCV's CV_SIMD128 order on x86 (SSE baseline, no FMA) [OpenCV-knowledge, 4.x lkpyramid.cpp]: four float
+                                   lanes per covariance sum over 8-pixel steps, int32 pair sums (v_dotprod) for the mismatch sums, the
+                                   window's last ww % 8 columns through the scalar loop, horizontal sums (l0 + l2) + (l1 + l3) at the end */
 
 typedef struct cvo_pyramid cvo_pyramid;
 

@@ -19,7 +19,7 @@ SOLVEPNP_ITERATIVE = 0
 OPTFLOW_USE_INITIAL_FLOW = 4
 OPTFLOW_LK_GET_MIN_EIGENVALS = 8
 TERM_COUNT, TERM_EPS = 1, 2
-ACC_EXACT, ACC_FLOAT_SCALAR = 0, 1
+ACC_EXACT, ACC_FLOAT_SCALAR, ACC_FLOAT_SIMD = 0, 1, 2
 
 
 def build(force=False):

@@ -8,7 +8,10 @@ DESCALE shifts, the 2x2 solve, the three stop rules, the level-0 error -- has a 
 implementation to be compared with BIT FOR BIT (tests/test_oracle.py::test_lk_oracle_equals_numpy_statement).
 
 Inner sums are formed exactly and rounded once to float32 (the oracle's CVO_ACC_EXACT mode, DESIGN.md section 2
-deviation 1); `float_order=True` instead accumulates in float32 in raster order, which is OpenCV's scalar loop.
+deviation 1); `float_order=True` instead accumulates in float32 in raster order, which is OpenCV's scalar loop;
+`float_order="simd"` is the order of OpenCV's CV_SIMD128 loops on x86 [OpenCV-knowledge, 4.x lkpyramid.cpp; SURVEY.md
+Appendix A step 4 "SIMD builds sum int32 pairs first"], stated here with float32 VECTORS of four lanes (numpy arrays)
+where the C oracle (CVO_ACC_FLOAT_SIMD) walks the lanes one scalar at a time.
 """
 import numpy as np
 from scipy.ndimage import correlate1d
@@ -64,7 +67,44 @@ def _bilinear(pad, off, ix, iy, win, w):
     return p[:-1, :-1] * w[0] + p[:-1, 1:] * w[1] + p[1:, :-1] * w[2] + p[1:, 1:] * w[3]
 
 
-def _sum_f32(prod, float_order):
+def _reduce4(q):
+    """v_reduce_sum(v_float32x4) on SSE: the high half is added onto the low half, then lane 1 onto lane 0"""
+    half = (q[:2] + q[2:]).astype(F)
+    return F(half[0] + half[1])
+
+
+def _sum_f32_simd(prod, kind):
+    """float32 sum of the integer window `prod` ([win, win]) in the vector loops' order.  The first win // 8 * 8 columns of
+    every row go through the vector loop in steps of eight, the other columns through the scalar loop (its own accumulator,
+    raster order); the two meet at the end.  kind "cov": two groups of four pixels per step, pixel 4 g + l into lane l
+    (products rounded to float, then added: no FMA).  kind "mis": the step's int32 PAIR sums p[k] + p[k + 4], k = 0..3 --
+    k = 0, 1 are lanes of one register, k = 2, 3 of a second one; the registers are added, then the two lanes."""
+    win = prod.shape[1]
+    vw = win // 8 * 8
+    tail = F(0.0)
+    for v in prod[:, vw:].ravel():
+        tail = F(tail + F(int(v)))
+    if vw == 0 or kind == "err":
+        return _sum_f32(prod, True)
+    if kind == "cov":
+        q = np.zeros(4, F)
+        for row in prod[:, :vw].reshape(prod.shape[0], vw // 4, 4):
+            for four in row:
+                q = (q + four.astype(F)).astype(F)
+        return F(tail + _reduce4(q))
+    qa, qb = np.zeros(2, F), np.zeros(2, F)                              # this sum's two lanes of qb0 (k = 0, 1) and of qb1 (k = 2, 3)
+    for row in prod[:, :vw].reshape(prod.shape[0], vw // 8, 2, 4):
+        for step in row:
+            pairs = step[0] + step[1]                                    # exact integers: p[k] + p[k + 4]
+            qa = (qa + pairs[:2].astype(F)).astype(F)
+            qb = (qb + pairs[2:].astype(F)).astype(F)
+    q = (qa + qb).astype(F)
+    return F(tail + _reduce4(np.array([q[0], q[1], 0, 0], F)))
+
+
+def _sum_f32(prod, float_order, kind="cov"):
+    if float_order == "simd":
+        return _sum_f32_simd(prod, kind)
     if float_order:
         acc = F(0.0)
         for v in prod.ravel():
@@ -140,8 +180,8 @@ def calc_optical_flow_pyr_lk(prev, nxt, prev_pts, next_pts=None, win=21, max_lev
                     break
                 w = _weights(F(q[0] - F(jx)), F(q[1] - F(jy)))
                 diff = _descale(_bilinear(pad_j, off, jx, jy, win, w), W_BITS - 5) - patch
-                b1 = _sum_f32(diff * gx, float_order) * flt_scale
-                b2 = _sum_f32(diff * gy, float_order) * flt_scale
+                b1 = _sum_f32(diff * gx, float_order, "mis") * flt_scale
+                b2 = _sum_f32(diff * gy, float_order, "mis") * flt_scale
                 delta = np.array([F(F(F(a12 * b2) - F(a22 * b1)) * inv), F(F(F(a12 * b1) - F(a11 * b2)) * inv)], F)
                 q = q + delta
                 out[i] = q + half
@@ -159,5 +199,5 @@ def calc_optical_flow_pyr_lk(prev, nxt, prev_pts, next_pts=None, win=21, max_lev
                     continue
                 w = _weights(F(e[0] - F(ex)), F(e[1] - F(ey)))
                 diff = np.abs(_descale(_bilinear(pad_j, off, ex, ey, win, w), W_BITS - 5) - patch)
-                err[i] = F(_sum_f32(diff, float_order) * F(1.0)) / F(32 * win * win)
+                err[i] = F(_sum_f32(diff, float_order, "err") * F(1.0)) / F(32 * win * win)
     return out.reshape(-1, 1, 2), status.reshape(-1, 1), err.reshape(-1, 1)

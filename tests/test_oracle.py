@@ -262,11 +262,12 @@ def _lk_scenes(seq640):
 def test_lk_oracle_equals_numpy_statement(oracle, seq640):
     """The C oracle's per-point LK loop against a second, structurally different statement of SURVEY.md Appendix A
     (tests/lk_numpy.py: scipy-filtered whole images, 21x21 array windows, int64) -- nextPts (u32 view), status and err
-    BIT-EXACT, in the exact-sum mode the HIP kernels are held to and in OpenCV's scalar float accumulation order."""
+    BIT-EXACT, in the exact-sum mode the HIP kernels are held to, in OpenCV's scalar float accumulation order and (round 5)
+    in the order of its CV_SIMD128 loops (four float lanes, int32 pair sums: what the shipped x86 builds execute)."""
     from tests import lk_numpy
     seen_neg = False
     for name, a, b, pts, kw in _lk_scenes(seq640):
-        for mode, forder in ((oracle.ACC_EXACT, False), (oracle.ACC_FLOAT_SCALAR, True)):
+        for mode, forder in ((oracle.ACC_EXACT, False), (oracle.ACC_FLOAT_SCALAR, True), (oracle.ACC_FLOAT_SIMD, "simd")):
             if forder and name not in ("tags", "texture_border"):
                 continue
             o = oracle.calcOpticalFlowPyrLK(a, b, pts, acc_mode=mode, **kw)
