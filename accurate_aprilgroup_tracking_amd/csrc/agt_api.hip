@@ -20,6 +20,7 @@
 
 struct agt_ctx {
     agt_config cfg;
+    AgtChip chip;                            // the device the context was created on (CU / XCD counts: launch rules and block orders)
     hipStream_t stream;
     int last_hip;
     int eff_max_level;                       // after OpenCV's early stop
@@ -160,6 +161,44 @@ int dense_scratch(agt_ctx* c, size_t need, int B)
 
 }  // namespace
 
+// ---- the device's geometry (agt_kernels.h AgtChip), queried once per device
+static AgtChip g_chip[16];
+static int g_chip_state[16];                   // 0 = not queried, 1 = valid, -1 = query failed
+static const AgtChip g_chip_default = { 256, 8, 3, "gfx950" };       // a whole MI355X
+
+void agt_chip_from_props(int cus, const char* gcn_arch, AgtChip* out)
+{
+    memset(out, 0, sizeof(*out));
+    out->cus = cus;
+    size_t i = 0;
+    for (; gcn_arch && gcn_arch[i] && gcn_arch[i] != ':' && i + 1 < sizeof(out->arch); i++) out->arch[i] = gcn_arch[i];
+    out->arch[i] = 0;
+    // gfx950: 32 CUs per XCD; workgroups are dealt round-robin to the XCDs of the partition.  A CU count that is not 32 x a power of
+    // two (a CU mask, an unknown part) gets the plain block order: still correct, just not L2-aware.
+    int x = cus / 32;
+    out->xcds = (cus % 32 == 0 && (x == 1 || x == 2 || x == 4 || x == 8)) ? x : 1;
+    out->xshift = out->xcds == 8 ? 3 : out->xcds == 4 ? 2 : out->xcds == 2 ? 1 : 0;
+}
+
+const AgtChip* agt_chip_of(int device)
+{
+    if (device < 0 || device >= 16) return nullptr;
+    if (g_chip_state[device] == 0) {
+        hipDeviceProp_t p;
+        if (hipGetDeviceProperties(&p, device) == hipSuccess) { agt_chip_from_props(p.multiProcessorCount, p.gcnArchName, &g_chip[device]); g_chip_state[device] = 1; }
+        else { (void)hipGetLastError(); g_chip_state[device] = -1; }
+    }
+    return g_chip_state[device] == 1 ? &g_chip[device] : nullptr;
+}
+
+const AgtChip& agt_chip_current(void)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return g_chip_default; }
+    const AgtChip* c = agt_chip_of(dev);
+    return c ? *c : g_chip_default;
+}
+
 extern "C" {
 
 int agt_version(void) { return AGT_VERSION; }
@@ -180,6 +219,22 @@ const char* agt_error_string(int code)
     }
 }
 
+int agt_xcd_tile_order(int block, int nblocks, int xcds)
+{
+    const int xs = xcds == 8 ? 3 : xcds == 4 ? 2 : xcds == 2 ? 1 : xcds == 1 ? 0 : -1;
+    if (xs < 0 || nblocks <= 0 || (nblocks & (xcds - 1)) || block < 0 || block >= nblocks) return AGT_ERR_ARG;
+    return agt_xcd_order(block, nblocks, xs);
+}
+
+int agt_device_info(const agt_ctx* c, int* cus, int* xcds, char* arch, size_t arch_cap)
+{
+    if (!c) return AGT_ERR_ARG;
+    if (cus) *cus = c->chip.cus;
+    if (xcds) *xcds = c->chip.xcds;
+    if (arch && arch_cap) { strncpy(arch, c->chip.arch, arch_cap - 1); arch[arch_cap - 1] = 0; }
+    return AGT_OK;
+}
+
 int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
 {
     if (!cfg || !out) return AGT_ERR_ARG;
@@ -191,10 +246,15 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     for (int i = 0; i < 8; i++) if (cfg->reserved[i] != 0) return AGT_ERR_ARG;
     hipError_t e = hipSetDevice(cfg->device);
     if (e != hipSuccess) return hip_fail(nullptr, e);
+    // the library holds gfx950 code objects only: refuse any other device here, with a code, instead of failing at the first launch
+    const AgtChip* chip = agt_chip_of(cfg->device);
+    if (!chip) return hip_fail(nullptr, hipErrorInvalidDevice);
+    if (strcmp(chip->arch, "gfx950") != 0) return AGT_ERR_UNSUPPORTED;
     agt_ctx* c = new (std::nothrow) agt_ctx;
     if (!c) return AGT_ERR_ALLOC;
     memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
+    c->chip = *chip;
     c->stream = (hipStream_t)hip_stream;
     // buildOpticalFlowPyramid level geometry + early stop
     int w = cfg->width, h = cfg->height;
@@ -1042,8 +1102,9 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in that launch as well
     // (while trackers + solvers are co-resident at the one workgroup per CU the solver's registers leave: more streams keep the LK
     // launch of its own, whose 78 registers put several workgroups on a CU)
+    // (the LK role's grid is rounded up to a multiple of the XCD count; the device's CU count, not a literal: ADVICE r4)
     const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1 &&
-                           (long)c->trk_n * B + B <= 256;
+                           (long)agt_xcd_grid((long)c->trk_n * B, c->chip.xshift) + B <= c->chip.cus;
     const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n) && !chain_pnp;
     if (ride) {
         // (what pyramid_build_on registers for a frame, for frame t + 1 in its ring entry)
@@ -1077,10 +1138,11 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         hipError_t e;
         if (chain_pnp) {
             S.pnp = p; S.pnp_nf = 1; S.n_pnp = B;
-            c->lk_target[slot] += (unsigned)c->trk_n;
+            // (the slot's arrival target advances only once the launch is known to be out: ADVICE r4 -- a failed launch must leave
+            // the counters' bookkeeping and the deferred dense step as they were)
             T.lk.done[0] = c->lk_done + (size_t)slot * c->cfg.max_streams;
             T.pnp.img[0] = c->corners[slot]; T.pnp.mask[0] = c->status[slot]; T.pnp.so[0] = d_state_out;
-            T.pnp.wait[0] = T.lk.done[0]; T.pnp.target[0] = c->lk_target[slot];
+            T.pnp.wait[0] = T.lk.done[0]; T.pnp.target[0] = c->lk_target[slot] + (unsigned)c->trk_n;
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_CHAIN_WITHHOLD_DENSE=k makes the k-th chained LK | PnP launch of the dense tracker expect one
             // arrival more than its LK role delivers (tests/test_dense.py drives the solver's give-up path with it)
             { static const int wh = [] { const char* e = getenv("AGT_CHAIN_WITHHOLD_DENSE"); return e ? atoi(e) : 0; }();
@@ -1090,7 +1152,10 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
         }
         if (c->dense_pending || chain_pnp) {
             e = agt_launch_lk_reseed(M, S, T, c->cfg.win, c->dense_pending ? &c->dense_final : nullptr, (ride && chain_pnp) ? npyr : nullptr);
-            c->dense_pending = 0;
+            if (e == hipSuccess) {                  // on failure dense_pending stays set: the caller's error path flushes it (agt_launch_dense_final)
+                c->dense_pending = 0;
+                if (chain_pnp) c->lk_target[slot] += (unsigned)c->trk_n;
+            }
         } else e = agt_launch_step(M, S, T, c->cfg.win, AGT_STEP_LK);
         if (e != hipSuccess) return hip_fail(c, e);
     } else {
@@ -1280,7 +1345,11 @@ int agt_track_host_frame(agt_ctx* c, const uint8_t* h_frame, int channels, int s
         const volatile unsigned long long* seq = c->hseq_host;
         timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
         for (unsigned long spins = 1; *seq < want; spins++) {
+#if defined(__x86_64__) || defined(__i386__)
             __builtin_ia32_pause();
+#else
+            __asm__ __volatile__("" ::: "memory");       // (other hosts: a compiler barrier; the volatile load above is the poll)
+#endif
             if ((spins & 0xffff) == 0) {
                 // nothing after 2 s: a launch failed or the device is gone -- let the runtime say which
                 timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);

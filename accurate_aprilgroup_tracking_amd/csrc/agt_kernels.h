@@ -11,12 +11,34 @@ struct AgtLevel {
     int w, h;
 };
 
+// ---- the chip a context runs on (round 5: no literal 8 XCDs / 256 CUs in kernels or launch rules).
+// Workgroups of a launch are dealt round-robin to the XCDs, each with its own L2; the kernels that re-use lines between
+// neighbouring work items (pyramid tiles / strips, LK corners of a stream, undistortion bands) re-order their block index so
+// that every XCD walks a CONTIGUOUS run of items:  item = (b mod X) * (n / X) + b / X  for a grid of n blocks, n a multiple of
+// X = 2^xshift.  A pure index map (a permutation of 0 .. n - 1 for every X): correct on any device, tuned when X is the device's
+// XCD count.  gfx950: one XCD = 32 CUs (MI355X: 256 CUs = 8 XCDs; its CPX / QPX / DPX partitions: 32 / 64 / 128 CUs = 1 / 2 / 4).
+struct AgtChip {
+    int cus;                  // hipDeviceProp_t::multiProcessorCount
+    int xcds;                 // 1, 2, 4 or 8 (cus / 32 when that is a power of two, else 1: plain order)
+    int xshift;               // log2(xcds)
+    char arch[32];            // gcnArchName up to the first ':'
+};
+__host__ __device__ inline int agt_xcd_order(int b, int nblk, int xshift)
+{
+    return (b & ((1 << xshift) - 1)) * (nblk >> xshift) + (b >> xshift);
+}
+inline unsigned agt_xcd_grid(long items, int xshift) { const long x = 1L << xshift; return (unsigned)((items + x - 1) / x * x); }
+const AgtChip* agt_chip_of(int device);        // cached device query (agt_api.hip); null when the query fails
+const AgtChip& agt_chip_current(void);         // of the calling thread's current device; MI355X's figures if the query fails
+
 struct AgtPyrArgs {
     const uint8_t* src; uint8_t* dst;
     long spitch, sbatch, dpitch, dbatch;
     int sw, sh, dw, dh;
     int gx, gy, B;            // tile grid (x, y) and images
     int pad;
+    int xshift;               // log2 of the XCD count the block order is laid out for (agt_xcd_order); set by the launchers
+    int rsv_;                 // two-level rolling pass: 1 = every strip top-down (diagnostic A/B; 0 = alternating directions)
 };
 
 #define AGT_MAX_GROUP 32         // frames one fused launch may advance each pipeline stage by (the per-frame tables are kernel arguments: 7.4 KB with the parameters)
@@ -35,6 +57,8 @@ struct AgtLkParams {
     float* next_pts;          // [B][n][2]
     uint8_t* status;          // [B][n]
     float* err;               // [B][n] or null
+    int xshift;               // XCD-aware corner order (agt_xcd_order); set by the launchers
+    int rsv_;
 };
 
 struct AgtCameraHost {
@@ -123,6 +147,8 @@ struct AgtStepParams {
     AgtPnpParams pnp;
     int pnp_nf;
     int n_pnp;                        // blocks of the PnP role (= streams) or 0
+    int xshift;                       // XCD-aware block orders of the LK and pyramid roles (agt_xcd_order); set by the launchers
+    int rsv_;
 };
 
 // per-frame pointer tables of the fused launch: its SECOND kernel argument.  They are indexed with run-time
@@ -198,7 +224,7 @@ size_t agt_dense_doubles(int M, int B);
 bool agt_lk_window_supported(int win);
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
-bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used up to 256 corners in flight
+bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used while its LK workgroups fit one per CU (256 corners on a whole MI355X)
 // role subsets of one pipeline group (split mode launches them separately, each with its own LDS size and register budget)
 #define AGT_STEP_PYR 1
 #define AGT_STEP_LK  2

@@ -6,16 +6,15 @@ namespace {
 
 // OCC: waves per SIMD the register allocation leaves room for.  The one-wave-per-corner 21x21 kernel sits 3
 // registers above the 128 that allow a fourth wave; big batches are throughput-bound, so it is held to 128.
-// XCD-aware corner order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so workgroup g takes corner
-// (g % 8) * per_xcd + g / 8 of the launch's n * B -- every XCD walks a CONTIGUOUS run of corners, i.e. whole streams: the tiles of
+// XCD-aware corner order (agt_kernels.h agt_xcd_order): workgroups are dealt round-robin to the X XCDs (each with its own L2), so workgroup g takes corner
+// (g % X) * per_xcd + g / X of the launch's n * B -- every XCD walks a CONTIGUOUS run of corners, i.e. whole streams: the tiles of
 // a tag's four corners (and of neighbouring tags) overlap, and with consecutive corners on eight different XCDs each of those
 // L2s fetched the shared lines from HBM for itself (FETCH_SIZE 2.9x the algorithmic bytes at 64 streams).
 template <int WIN, int NW, int NLEV, int OCC>
 __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_kernel(const AgtLkParams P, const int total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int cidx = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int cidx = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, P.xshift);
     if (cidx >= total) return;
     const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
     agt_lk::LkFrameIo<NLEV> io;
@@ -37,12 +36,14 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
 }
 
 template <int WIN, int NW>
-hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p, int B)
+hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p_in, int B)
 {
+    AgtLkParams p = p_in;
+    p.xshift = agt_chip_current().xshift; p.rsv_ = 0;
     const size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
     const long total = (long)p.n * B;
     if (total <= 0 || total > (1L << 30)) return hipErrorInvalidValue;
-    const dim3 grid((unsigned)((total + 7) / 8 * 8)), block(AGT_WAVE * NW);
+    const dim3 grid(agt_xcd_grid(total, p.xshift)), block(AGT_WAVE * NW);
     constexpr int OCC = (WIN == 21 && NW == 1) ? 4 : 1;
     if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3, OCC>), grid, block, lds, stream, p, (int)total);
     else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC>), grid, block, lds, stream, p, (int)total);

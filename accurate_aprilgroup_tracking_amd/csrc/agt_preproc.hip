@@ -57,6 +57,7 @@ struct RemapParams {
     uint8_t* dst; long dpitch, dbatch;
     int undistort;                                               // 0: taps come straight from (x, y)
     int B;                                                       // images (gray path: flattened work order)
+    int xshift;                                                  // log2 of the XCD count the gray path's band order is laid out for
 };
 
 struct __attribute__((packed)) Tap6 { uint32_t lo; uint16_t hi; };
@@ -111,14 +112,14 @@ template <bool GRAY>
 __global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
 {
     if (GRAY) {
-        // A workgroup = 4 rows x 64 groups of four output pixels.  Grid (8 * 2 * nseg, images, bands / 8): gridDim.x
-        // is a multiple of 8 and workgroups are dealt round-robin to the 8 XCDs in x-fastest order, so
-        // blockIdx.x % 8 IS the XCD: XCD k owns the bands k * gridDim.z .. (k + 1) * gridDim.z - 1 (8 rows each),
+        // A workgroup = 4 rows x 64 groups of four output pixels.  Grid (X * 2 * nseg, images, bands / X), X = 2^xshift XCDs: gridDim.x
+        // is a multiple of X and workgroups are dealt round-robin to the X XCDs in x-fastest order, so
+        // blockIdx.x % X IS the XCD: XCD k owns the bands k * gridDim.z .. (k + 1) * gridDim.z - 1 (8 rows each),
         // and walks band by band, image by image.  Inside a band the map rows (6 B/px, shared by all images) stay
         // in that XCD's L2 while the images go by, and the source rows that consecutive output rows share
         // (sy and sy + 1) are fetched into one L2 instead of two.  No divisions: the split is done by the grid.
-        const int nseg = (int)gridDim.x >> 4;
-        const int xcd = blockIdx.x & 7, j = (int)blockIdx.x >> 3;
+        const int nseg = (int)gridDim.x >> (P.xshift + 1);
+        const int xcd = blockIdx.x & ((1 << P.xshift) - 1), j = (int)blockIdx.x >> P.xshift;
         const int strip = j >= nseg ? 1 : 0, seg = j - strip * nseg;
         const int band = xcd * (int)gridDim.z + (int)blockIdx.z;
         const int bz = blockIdx.y;
@@ -252,8 +253,9 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
     P.map1 = map1; P.map2 = map2; P.mw = mw; P.rx = rx; P.ry = ry; P.rw = rw; P.rh = rh;
     P.dst = dst; P.dpitch = dpitch; P.dbatch = dbatch; P.undistort = undistort;
     P.B = B;
-    const int nseg = (rw + 255) / 256, bands = (rh + 7) / 8;
-    if (gray) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(16 * nseg, B, (bands + 7) / 8), dim3(256), 0, stream, P);
+    P.xshift = agt_chip_current().xshift;
+    const int nseg = (rw + 255) / 256, bands = (rh + 7) / 8, X = 1 << P.xshift;
+    if (gray) hipLaunchKernelGGL(preprocess_kernel<true>, dim3(2 * X * nseg, B, (bands + X - 1) / X), dim3(256), 0, stream, P);
     else hipLaunchKernelGGL(preprocess_kernel<false>, dim3((rw + 255) / 256, rh, B), dim3(256), 0, stream, P);
     return hipGetLastError();
 }

@@ -11,12 +11,11 @@ namespace {
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    // XCD-aware tile order: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so
-    // workgroup b takes tile (b % 8) * per_xcd + b / 8 -- every XCD walks a CONTIGUOUS row-major run of
+    // XCD-aware tile order (agt_kernels.h agt_xcd_order): workgroups are dealt round-robin to the X XCDs (each with its own L2), so
+    // workgroup b takes tile (b % X) * per_xcd + b / X -- every XCD walks a CONTIGUOUS row-major run of
     // tiles and the 128-B lines shared by neighbouring tiles (16-B side halos, 3 halo rows) hit in its L2
     // instead of being fetched once per XCD.
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A.xshift);
     const int per_img = A.gx * A.gy;
     if (t >= per_img * A.B) return;
     const int bz = t / per_img, r = t - bz * per_img;
@@ -25,10 +24,12 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down_kernel(const AgtPyrArgs 
 }
 
 // register-rolling form (agt_pyramid3_body.h): A.gx = workgroups per image, A.pad = output rows per strip; same XCD-aware order
-__global__ __launch_bounds__(agt_pyr::NT) void pyr_roll_kernel(const AgtPyrArgs A)
+#ifndef AGT_PYR3_ATTR
+#define AGT_PYR3_ATTR
+#endif
+__global__ __launch_bounds__(agt_pyr::NT) AGT_PYR3_ATTR void pyr_roll_kernel(const AgtPyrArgs A)
 {
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A.xshift);
     if (t >= A.gx * A.B) return;
     const int bz = t / A.gx;
     agt_pyr3::pyr_roll_body(A, t - bz * A.gx, A.src + (long)bz * A.sbatch, A.dst + (long)bz * A.dbatch);
@@ -38,8 +39,7 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_roll_kernel(const AgtPyrArgs 
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_down2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A0.xshift);
     const int per_img = A0.gx * A0.gy;
     if (t >= per_img * A0.B) return;
     const int bz = t / per_img, r = t - bz * per_img;
@@ -52,23 +52,20 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_down2_kernel(const AgtPyrArgs
 // HBM (`copy`), levels 1 and 2 written -- the two-level register-rolling pass with COPY (agt_pyramid4_body.h)
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_upload2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1, uint8_t* copy, const int cpitch)
 {
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A0.xshift);
     if (t >= A0.gx) return;
-    agt_pyr4::pyr_roll2_body<true>(A0, A1, t, A0.src, A0.dst, A1.dst, copy, cpitch);
+    agt_pyr4::pyr_roll2_body<true, false>(A0, A1, t, A0.src, A0.dst, A1.dst, copy, cpitch);
 }
 
-#ifdef AGT_DEBUG_KNOBS
-// two levels per pass, register-rolling form (agt_pyramid4_body.h): A0.gx = workgroups per image, A0.pad = level-2 rows per strip
+// two levels per pass, register-rolling form with alternating strip directions (agt_pyramid4_body.h): A0.gx = workgroups per image,
+// A0.pad = level-2 rows per strip
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_roll2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1)
 {
-    const int per_xcd = (int)gridDim.x >> 3;
-    const int t = (int)(blockIdx.x & 7) * per_xcd + (int)(blockIdx.x >> 3);
+    const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A0.xshift);
     if (t >= A0.gx * A0.B) return;
     const int bz = t / A0.gx;
     agt_pyr4::pyr_roll2_body(A0, A1, t - bz * A0.gx, A0.src + (long)bz * A0.sbatch, A0.dst + (long)bz * A0.dbatch, A1.dst + (long)bz * A1.dbatch);
 }
-#endif
 
 }  // namespace
 
@@ -90,6 +87,7 @@ void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch,
     agt_pyr2_grid(A1.dw, A1.dh, &A0.gx, &A0.gy);              // the tile grid of the pass rides in A0
     A1.gx = A0.gx; A1.gy = A0.gy;
     A0.B = A1.B = B; A0.pad = A1.pad = 0;
+    A0.xshift = A1.xshift = agt_chip_current().xshift; A0.rsv_ = A1.rsv_ = 0;
 }
 
 // The register-rolling form of the two-level pass where it applies: A0.pad = level-2 rows per strip, A0.gx = workgroups per image,
@@ -104,34 +102,38 @@ void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintpt
     const bool ok = ((src_align | (uintptr_t)A0.spitch | (uintptr_t)A0.sbatch | (uintptr_t)A0.sw) & 15) == 0 &&
                     ((dst_align | (uintptr_t)A0.dpitch | (uintptr_t)A0.dbatch) & 7) == 0 && ((dst_align | (uintptr_t)A1.dpitch | (uintptr_t)A1.dbatch) & 3) == 0 &&
                     A0.sw >= 32 && A0.sh >= 32 && (long)A0.sh * A0.spitch < (1L << 31) && (long)A0.dh * A0.dpitch < (1L << 31);
-    // MEASURED AND NOT SHIPPED (round 4): the rolling two-level pass is bit-exact (tests/test_gpu_parity.py ran it on every shape of
-    // test_pyramid_build_all_levels_bit_exact) but a strip of oh2 level-2 rows is a serial chain of 4 oh2 + 9 level-0 rows per lane with
-    // 8 in flight, and short strips re-read (4 oh2 + 9) / (4 oh2) of the image through the L2: 64 x 720p 24.0-25.5 us per pass
-    // (oh2 = 4 .. 8) against 24.9 for two single-level rolling passes; one frame 5.9-8.5 us against 6.5-7.3 for the tiled pass.
-    // A 16-row ring changes nothing: one frame takes 0.24 us per strip row at every ring depth (7.8 / 11.5 / 15.5 / 19.3 us at
-    // oh2 = 4 / 8 / 12 / 16) -- a wave's ~100 instructions per level-0 row are the chain, not the memory round trips.
-    // Only the knobs build takes it (AGT_PYR4=1, AGT_PYR4_OH=n).
-#ifndef AGT_DEBUG_KNOBS
-    (void)ok; (void)frames;
-    return;
-#else
-    { static const int on = [] { const char* e = getenv("AGT_PYR4"); return e ? atoi(e) : 0; }(); if (!on) return; }
-    if (!ok) return;
-    // strip height (level-2 rows, even): ~3 waves on each SIMD where the launch has that many units, strips of at most 16 rows
-    // (73 level-0 rows: 14 % of them the halo), at least 2 (17 rows)
+    // Round 4 measured this pass and did not ship it: every strip walked top-down, its 9 halo rows came from memory a second time
+    // ((4 oh2 + 9) / (4 oh2) of the image: FETCH_SIZE 76.1 MB for 59.0 MB of frames at oh2 = 8) and a lane spent ~70 VALU per level-0
+    // row; 64 x 720p: 24.0-25.5 us per pass against 24.9 for two single-level passes.  Round 5 ships it for launches of >= 16 images:
+    // alternating strip directions (neighbouring strips read their shared rows at the same time: FETCH_SIZE 60.4 MB) and the lean
+    // horizontal / vertical passes (agt_pyramid_body.h hgroup8b / vgroup8b: ~50 VALU per row).  The pipelined cold-pair step of
+    // BASELINE configs[2] (which is VALU- and HBM-bound together): 54.6-56.2 -> 48.1-49.1 us; traffic of the pass 94.5 -> 78.9 MB
+    // against the 77.4 MB of SURVEY 8d (profiles/r05_experiments.md).  Smaller launches keep the tiled pass (one frame: 6.5-7.3 us
+    // tiled, 5.9-8.5 rolling).
     const long images = (long)A0.B * (frames > 0 ? frames : 1);
+    int want = images >= 16 ? 1 : 0;
+#ifdef AGT_DEBUG_KNOBS      // AGT_PYR4=0 / 1 forces the choice, AGT_PYR4_OH=n the strip height, AGT_PYR4_REV=0 top-down strips only
+    { static const int on = [] { const char* e = getenv("AGT_PYR4"); return e ? atoi(e) : -1; }(); if (on >= 0) want = on; }
+    { static const int rv = [] { const char* e = getenv("AGT_PYR4_REV"); return e ? atoi(e) : 1; }(); A0.rsv_ = A1.rsv_ = rv ? 0 : 1; }
+#endif
+    if (!ok || !want) return;
+    // strip height (level-2 rows, even): ~2 waves on each SIMD where the launch has that many units (the pass shares the chip with
+    // the LK kernels of other batches; measured on 64 x 720p inside the pipelined step: oh2 = 4: 53.5 us, 6: 50.3, 8: 48.8-49.1,
+    // 10: 48.1, 12: 49.7, 16: 52.8), strips of at most 16 rows (73 level-0 rows: 14 % of them the halo), at least 2 (17 rows)
     const int ncol = ((A0.sw >> 4) + agt_pyr4::TILE_GROUPS - 1) / agt_pyr4::TILE_GROUPS;
-    long per_image = (12288 + images - 1) / images;
+    const long want_units = 32L * agt_chip_current().cus;                 // 2 waves x 4 units x 4 SIMDs per CU
+    long per_image = (want_units + images - 1) / images;
     long strips = (per_image + ncol - 1) / ncol;
     if (strips < 1) strips = 1;
     constexpr int Q = agt_pyr4::L2_PER_TRIP;
-    int oh = (int)(A1.dh / strips) / Q * Q;
+    int oh = (int)((A1.dh + strips - 1) / strips + Q - 1) / Q * Q;
     oh = oh < Q ? Q : (oh > 16 ? 16 : oh);
+#ifdef AGT_DEBUG_KNOBS
     { static const int f = [] { const char* e = getenv("AGT_PYR4_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = (f + Q - 1) / Q * Q; }
+#endif
     A0.pad = A1.pad = oh;
     A0.gx = A1.gx = agt_pyr4::roll2_blocks(A0.sw, A1.dh, oh);
     A0.gy = A1.gy = 1;
-#endif
 }
 
 // Fused upload + two-level pyramid of ONE frame: src = device address of the caller's gray frame in pinned host memory; copy = the
@@ -151,7 +153,7 @@ hipError_t agt_launch_pyr_upload2(hipStream_t stream, const uint8_t* src, int sw
     A0.pad = A1.pad = oh;
     A0.gx = A1.gx = agt_pyr4::roll2_blocks(sw, A1.dh, oh);
     A0.gy = A1.gy = 1;
-    hipLaunchKernelGGL(pyr_upload2_kernel, dim3((unsigned)((A0.gx + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A0, A1, copy, (int)cpitch);
+    hipLaunchKernelGGL(pyr_upload2_kernel, dim3(agt_xcd_grid(A0.gx, A0.xshift)), dim3(agt_pyr::NT), 0, stream, A0, A1, copy, (int)cpitch);
     return hipGetLastError();
 }
 
@@ -163,11 +165,8 @@ hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, 
     agt_pyr2_args(src, sw, sh, spitch, sbatch, dst1, dpitch1, dbatch1, dst2, dpitch2, dbatch2, B, &A0, &A1);
     agt_pyr2_plan(&A0, &A1, (uintptr_t)src, (uintptr_t)dst1 | (uintptr_t)dst2, 1);
     const long tiles = (long)A0.gx * A0.gy * B;
-#ifdef AGT_DEBUG_KNOBS
-    if (A0.pad) hipLaunchKernelGGL(pyr_roll2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A0, A1);
-    else
-#endif
-    hipLaunchKernelGGL(pyr_down2_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr2::PYR2_LDS_BYTES, stream, A0, A1);
+    if (A0.pad) hipLaunchKernelGGL(pyr_roll2_kernel, dim3(agt_xcd_grid(tiles, A0.xshift)), dim3(agt_pyr::NT), 0, stream, A0, A1);
+    else hipLaunchKernelGGL(pyr_down2_kernel, dim3(agt_xcd_grid(tiles, A0.xshift)), dim3(agt_pyr::NT), agt_pyr2::PYR2_LDS_BYTES, stream, A0, A1);
     return hipGetLastError();
 }
 
@@ -184,6 +183,7 @@ void agt_pyr_plan(AgtPyrArgs* pA, uintptr_t src_align, uintptr_t dst_align, int 
 {
     AgtPyrArgs& A = *pA;
     A.pad = 0;
+    A.xshift = agt_chip_current().xshift; A.rsv_ = 0;
     agt_pyr_grid(A.dw, A.dh, &A.gx, &A.gy);
     const bool ok = ((src_align | (uintptr_t)A.spitch | (uintptr_t)A.sbatch | (uintptr_t)A.sw) & 15) == 0 &&
                     ((dst_align | (uintptr_t)A.dpitch | (uintptr_t)A.dbatch) & 7) == 0 &&
@@ -192,12 +192,13 @@ void agt_pyr_plan(AgtPyrArgs* pA, uintptr_t src_align, uintptr_t dst_align, int 
     { static const int on = [] { const char* e = getenv("AGT_PYR3"); return e ? atoi(e) : 1; }(); if (!on) return; }
 #endif
     if (!ok) return;
-    // strip height: enough units (four per wave) to put ~3 waves on each of the 1024 SIMDs -- a wave keeps 8 KB of reads in
+    // strip height: enough units (four per wave) to put ~3 waves on each of the chip's SIMDs (1024 on MI355X: 12,288 units) -- a wave keeps 8 KB of reads in
     // flight --, strips no longer than 16 output rows (measured on 64 x 720p, L0 -> L1: 8 rows 17.8 us, 16: 17.0, 24: 21.2,
     // 32: 22.1, 48: 27 -- the tiled kernel: 18.6), no shorter than 4 (3 halo rows per strip are re-read through the L2)
     const long images = (long)A.B * (frames > 0 ? frames : 1);
     const int ncol = ((A.sw >> 4) + 15) >> 4;
-    long per_image = (12288 + images - 1) / images;
+    const long want_units = 48L * agt_chip_current().cus;                 // 3 waves x 4 units x 4 SIMDs per CU
+    long per_image = (want_units + images - 1) / images;
     long strips = (per_image + ncol - 1) / ncol;
     if (strips < 1) strips = 1;
     int oh = (int)(A.dh / strips) & ~3;
@@ -219,7 +220,7 @@ hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, i
     A.B = B;
     agt_pyr_plan(&A, (uintptr_t)src, (uintptr_t)dst, 1);
     const long tiles = (long)A.gx * A.gy * B;
-    if (A.pad) hipLaunchKernelGGL(pyr_roll_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), 0, stream, A);
-    else hipLaunchKernelGGL(pyr_down_kernel, dim3((unsigned)((tiles + 7) / 8 * 8)), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
+    if (A.pad) hipLaunchKernelGGL(pyr_roll_kernel, dim3(agt_xcd_grid(tiles, A.xshift)), dim3(agt_pyr::NT), 0, stream, A);
+    else hipLaunchKernelGGL(pyr_down_kernel, dim3(agt_xcd_grid(tiles, A.xshift)), dim3(agt_pyr::NT), agt_pyr::PYR_LDS_BYTES, stream, A);
     return hipGetLastError();
 }

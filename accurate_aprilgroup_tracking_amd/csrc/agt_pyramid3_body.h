@@ -47,7 +47,10 @@ __device__ __forceinline__ int roll_reflect_row(int y, int sh)
     return y < 0 ? 0 : y;
 }
 
-// horizontal sums of one source row of the lane (d: its 16 bytes, e: the dword across the tile boundary for lanes 0 / 15)
+// horizontal sums of one source row of the lane (d: its 16 bytes, e: the dword across the tile boundary for lanes 0 / 15);
+// ODD: the row sits at an odd offset of the vertical windows it enters (rows 1 / 3 of five): its sums carry the +16 bias of
+// agt_pyramid_body.h hgroup8b / vgroup8b
+template <bool ODD>
 __device__ __forceinline__ uint4 roll_hrow(u32x4 d, uint32_t e, bool left_edge, bool right_edge)
 {
     // bytes -2, -1 of the image = bytes 2, 1 (reflect-101): as the high half of the dword "before"
@@ -55,7 +58,7 @@ __device__ __forceinline__ uint4 roll_hrow(u32x4 d, uint32_t e, bool left_edge, 
     uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp((int)pm_old, (int)d.w, 0x111, 0xf, 0xf, false);    // row_shr:1
     uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp((int)e, (int)d.x, 0x101, 0xf, 0xf, false);         // row_shl:1
     nx = right_edge ? (d.w >> 16) : nx;                                   // byte 16 = byte sw of the image = byte sw - 2
-    return hgroup8(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
+    return hgroup8b<ODD>(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
 }
 
 // One 256-thread workgroup = 16 units of the image at `img` (units blk * 16 ..).  A.pad = output rows per strip (multiple of UO).
@@ -69,35 +72,37 @@ __device__ __forceinline__ void pyr_roll_rows(const AgtPyrArgs& A, const RS rs, 
     const bool eon = lane_on && ((q == 0 && g > 0) || (q == 15 && g + 1 < G));
     const int eoff = q == 0 ? -4 : 16;
     const int xoff = g * 16;
-    const int vbase = EDGE ? xoff : y0 * pitch + xoff;           // (non-edge waves: every row of the strip is inside the image)
+    // Lanes that own no group (and lanes without an edge dword) load from an offset past the buffer: the load is issued
+    // unconditionally and returns 0 for them (buffer range check) -- no exec-mask changes and no copies of the old slot
+    // contents around every load (round 5; 0x80000000 + any in-image offset stays >= 2^31 > num_records)
+    const int vbase = lane_on ? (EDGE ? xoff : y0 * pitch + xoff) : (int)0x80000000u;           // (non-edge waves: every row of the strip is inside the image)
+    const int ebase = eon ? (EDGE ? xoff : y0 * pitch + xoff) + eoff : (int)0x80000000u;
     u32x4 d[RING];
     uint32_t e[RING];
-#pragma unroll
-    for (int k = 0; k < RING; k++) { d[k] = (u32x4)(0u); e[k] = 0u; }
     auto issue = [&](int slot, int r) {                          // r: row of the strip (wave-uniform)
-        int vo = vbase, so = 0;
-        if constexpr (EDGE) vo = vbase + roll_reflect_row(y0 + r, sh) * pitch;
+        int ro = 0, so = 0;
+        if constexpr (EDGE) ro = roll_reflect_row(y0 + r, sh) * pitch;
         else so = r * pitch;
-        if (lane_on) { const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t); }
-        if (eon) e[slot] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo + eoff, so, 0);
+        const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vbase + ro, so, 0); d[slot] = __builtin_bit_cast(u32x4, t);
+        e[slot] = __builtin_amdgcn_raw_buffer_load_b32(rs, ebase + ro, so, 0);
     };
 #pragma unroll
     for (int k = 0; k < RING; k++) issue(k, k);
     uint4 H0, H1, H2;
-    H0 = roll_hrow(d[0], e[0], left_edge, right_edge); if (RING + 0 < NR) issue(0, RING + 0);
-    H1 = roll_hrow(d[1], e[1], left_edge, right_edge); if (RING + 1 < NR) issue(1, RING + 1);
-    H2 = roll_hrow(d[2], e[2], left_edge, right_edge); if (RING + 2 < NR) issue(2, RING + 2);
+    H0 = roll_hrow<false>(d[0], e[0], left_edge, right_edge); if (RING + 0 < NR) issue(0, RING + 0);
+    H1 = roll_hrow<true>(d[1], e[1], left_edge, right_edge); if (RING + 1 < NR) issue(1, RING + 1);
+    H2 = roll_hrow<false>(d[2], e[2], left_edge, right_edge); if (RING + 2 < NR) issue(2, RING + 2);
     const int obase = oy0 * dpitch + g * 8;
     for (int t = 0; t < oh / UO; t++) {
 #pragma unroll
         for (int u = 0; u < UO; u++) {
             const int r = 3 + RING * t + 2 * u;                  // rows r, r + 1 complete output row j
             const int s0 = (3 + 2 * u) % RING, s1 = (4 + 2 * u) % RING;
-            const uint4 H3 = roll_hrow(d[s0], e[s0], left_edge, right_edge);
+            const uint4 H3 = roll_hrow<true>(d[s0], e[s0], left_edge, right_edge);
             if (r + RING < NR) issue(s0, r + RING);
-            const uint4 H4 = roll_hrow(d[s1], e[s1], left_edge, right_edge);
+            const uint4 H4 = roll_hrow<false>(d[s1], e[s1], left_edge, right_edge);
             if (r + 1 + RING < NR) issue(s1, r + 1 + RING);
-            const uint2 o = vgroup8(H0, H1, H2, H3, H4);
+            const uint2 o = vgroup8b(H0, H1, H2, H3, H4);
             const int j = UO * t + u;
             if (lane_on && oy0 + j < dh)
                 __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(v2u, o), rd, obase, j * dpitch, 0);

@@ -66,23 +66,53 @@ __device__ __forceinline__ uint32_t vgroup4(uint2 r0, uint2 r1, uint2 r2, uint2 
     return __builtin_amdgcn_perm(p1, p0, 0x06040200u);
 }
 
+// round 5: the chain form of agt_pyramid_body.h hgroup8b for the level-1 row of a lane (8 bytes: lo, hi), BIAS = +16 on every sum
+template <bool BIAS>
+__device__ __forceinline__ uint2 hgroup4b(uint32_t lo, uint32_t hi, uint32_t pm, uint32_t nx)
+{
+    const uint32_t WB = 0x04010000u, WA = 0x00010406u, WC = 0x04060401u, WD = 0x00000001u;
+    const uint32_t c0 = BIAS ? 16u : 0u;
+    const uint32_t e0 = __builtin_amdgcn_udot4(lo, WA, __builtin_amdgcn_udot4(pm, WB, c0, false), false);
+    const uint32_t o0 = __builtin_amdgcn_udot4(lo, WC, __builtin_amdgcn_udot4(hi, WD, c0, false), false);
+    const uint32_t e1 = __builtin_amdgcn_udot4(hi, WA, __builtin_amdgcn_udot4(lo, WB, c0, false), false);
+    const uint32_t o1 = __builtin_amdgcn_udot4(hi, WC, __builtin_amdgcn_udot4(nx, WD, c0, false), false);
+    return make_uint2(e0 | (o0 << 16), e1 | (o1 << 16));
+}
+
+// ... and of vgroup8b: rows 1 and 3 of the window carry the bias
+__device__ __forceinline__ uint32_t vgroup4b(uint2 r0, uint2 r1, uint2 r2, uint2 r3, uint2 r4)
+{
+    const uint32_t p0 = vcol_b(r0.x, r1.x, r2.x, r3.x, r4.x), p1 = vcol_b(r0.y, r1.y, r2.y, r3.y, r4.y);
+    return __builtin_amdgcn_perm(p1, p0, 0x07050301u);
+}
+
 // level-0 horizontal sums of one row (no edge dword: the halo lanes stand in for the tile's neighbours)
+template <bool ODD>
 __device__ __forceinline__ uint4 roll2_hrow(u32x4 d, bool left_edge, bool right_edge)
 {
     // (the image's first group sits on lane 1 of tile 0, behind an idle halo lane: selected AFTER the shift, unlike agt_pyramid3_body.h)
-    uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d.w, 0x111, 0xf, 0xf, false);                     // row_shr:1
-    uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)d.x, 0x101, 0xf, 0xf, false);                     // row_shl:1
+    // (bound_ctrl: the row's first / last lane reads 0 -- no register has to be zeroed for the shift's "old" operand)
+    uint32_t pm = (uint32_t)__builtin_amdgcn_mov_dpp((int)d.w, 0x111, 0xf, 0xf, true);                            // row_shr:1
+    uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)d.x, 0x101, 0xf, 0xf, true);                            // row_shl:1
     pm = left_edge ? __builtin_amdgcn_perm(d.x, d.x, 0x01020000u) : pm;
     nx = right_edge ? (d.w >> 16) : nx;
-    return hgroup8(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
+    return hgroup8b<ODD>(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
 }
+
+template <bool V> struct Odd { static constexpr bool value = V; };
 
 // COPY: the level-0 rows the strip owns (4 oy2 .. 4 oy2 + 4 oh2 - 1; interior lanes) are also stored to `rc` (pitch cpitch): the
 // source then is the caller's frame in pinned HOST memory, read over PCIe exactly once per byte that matters, and the copy is the
 // frame's level 0 in HBM -- upload and pyramid in one pass (agt_track_host_frame).
-template <bool EDGE, bool COPY, typename RS>
+// REV (round 5): the unit may walk its strip BOTTOM-UP (`rev`, per lane: the units of a wave belong to different strips).  The filters
+// are symmetric, so the same rolling windows work on the reversed row sequence; only the row a stream index stands for changes
+// (level 0: ylast - r, level 1: y1last - i, level 2: oy2 + oh2 - 1 - j).  Alternating directions (strip s top-down, s + 1 bottom-up)
+// make neighbouring strips read their shared 9 halo rows AT THE SAME TIME -- both start at, or both end at, their common border --
+// so the second reader finds the lines in the XCD's L2 instead of fetching them again from memory (measured before: FETCH_SIZE of
+// the pass = (4 oh2 + 9) / (4 oh2) of the image, every halo row came from memory a second time).
+template <bool EDGE, bool COPY, bool REV, typename RS>
 __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPyrArgs& A1, const RS rs, const RS r1, const RS r2, const RS rc, int cpitch,
-                                               int oy2, int g, int q, int G, bool lane_on)
+                                               int oy2, int g, int q, int G, bool lane_on, bool rev)
 {
     const int sh = A0.sh, h1 = A0.dh, h2 = A1.dh, oh2 = A0.pad;
     const int pitch = (int)A0.spitch, pitch1 = (int)A0.dpitch, pitch2 = (int)A1.dpitch;
@@ -92,54 +122,69 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
     const bool left_edge = g == 0, right_edge = g == G - 1;
     const bool writer = lane_on && q >= 1 && q <= TILE_GROUPS;   // interior lane: stores its level-1 and level-2 pixels
     const int xoff = g * 16;
-    const int vbase = EDGE ? xoff : y0 * pitch + xoff;
+    const int ylast = y0 + NR - 1;
+    const int ybase = REV && rev ? ylast : y0, dir = REV && rev ? -1 : 1;      // level-0 row of stream index r: ybase + dir * r
+    // (lanes without a group load from past the buffer's end: issued unconditionally, 0 comes back -- agt_pyramid3_body.h)
+    const int vbase = lane_on ? (EDGE ? xoff : ybase * pitch + xoff) : (int)0x80000000u;
+    const int dpitch_lane = lane_on ? dir * pitch : 0;
     u32x4 d[RING];
-#pragma unroll
-    for (int k = 0; k < RING; k++) d[k] = (u32x4)(0u);
+    // (a row past the strip's last one is "loaded" from past the buffer's end as well: no branch around the load, no copy of
+    // the slot's old contents for the path that skips it)
     auto issue = [&](int slot, int r) {
         int vo = vbase, so = 0;
-        if constexpr (EDGE) vo = vbase + roll_reflect_row(y0 + r, sh) * pitch;
+        if constexpr (EDGE) vo = vbase + roll_reflect_row(ybase + dir * r, sh) * pitch;
+        else if constexpr (REV) vo = vbase + r * dpitch_lane;
         else so = r * pitch;
-        if (lane_on) { const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t); }
+        if (r >= NR) vo = (int)0x80000000u;
+        const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t);
     };
-    auto take = [&](int slot, int r) {                           // horizontal sums of strip row r (in `slot`), then refill the slot
+    auto take = [&](int slot, int r, auto odd) {                 // horizontal sums of strip row r (in `slot`), then refill the slot
         if constexpr (COPY) {
-            const int y = y0 + r;
-            if (writer && r >= 6 && r < 4 * oh2 + 6 && y < sh)
+            const int y = ybase + dir * r;
+            if (writer && y >= 4 * oy2 && y < 4 * oy2 + 4 * oh2 && y < sh)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, d[slot]), rc, y * cpitch + xoff, 0, 0);
         }
-        const uint4 h = roll2_hrow(d[slot], left_edge, right_edge);
-        if (r + RING < NR) issue(slot, r + RING);
+        const uint4 h = roll2_hrow<decltype(odd)::value>(d[slot], left_edge, right_edge);
+        issue(slot, r + RING);
         return h;
     };
+    constexpr Odd<false> EV{}; constexpr Odd<true> OD{};
     // level-1 row `i` of the strip (image row y1a + i) from the level-0 window: the pixels (two dwords), stored by the interior
     // lanes if the row is the strip's own, and their horizontal sums for level 2
     const int o1base = 2 * oy2 * pitch1 + g * 8;                   // (level-1 row i = 2: the strip's first own row; offsets stay non-negative)
-    auto level1 = [&](const uint4& a0, const uint4& a1, const uint4& a2, const uint4& a3, const uint4& a4, int i) {
-        const uint2 px = vgroup8(a0, a1, a2, a3, a4);
-        const int y1 = y1a + i;
-        if (writer && i >= 2 && i < 2 * oh2 + 2 && y1 < h1)
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, o1base, (i - 2) * pitch1, 0);
+    const int y1last = y1a + 2 * oh2 + 2;
+    auto level1 = [&](const uint4& a0, const uint4& a1, const uint4& a2, const uint4& a3, const uint4& a4, int i, auto odd) {
+        const uint2 px = vgroup8b(a0, a1, a2, a3, a4);
+        if constexpr (REV) {
+            const int y1 = rev ? y1last - i : y1a + i;
+            if (writer && y1 >= 2 * oy2 && y1 < 2 * oy2 + 2 * oh2 && y1 < h1)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, y1 * pitch1 + g * 8, 0, 0);
+        } else {
+            const int y1 = y1a + i;
+            if (writer && i >= 2 && i < 2 * oh2 + 2 && y1 < h1)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, o1base, (i - 2) * pitch1, 0);
+        }
         // neighbours' level-1 pixels: -2, -1 from the lane on the left, 8 from the lane on the right; the image's own edges
         // reflect level 1 (pixel -2 = 2, -1 = 1; pixel w1 = w1 - 2)
-        uint32_t pm = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)px.y, 0x111, 0xf, 0xf, false);
-        uint32_t nx = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)px.x, 0x101, 0xf, 0xf, false);
+        uint32_t pm = (uint32_t)__builtin_amdgcn_mov_dpp((int)px.y, 0x111, 0xf, 0xf, true);
+        uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)px.x, 0x101, 0xf, 0xf, true);
         pm = left_edge ? __builtin_amdgcn_perm(px.x, px.x, 0x01020000u) : pm;
         nx = right_edge ? (px.y >> 16) : nx;
-        return hgroup4(px.x, px.y, pm, nx);
+        return hgroup4b<decltype(odd)::value>(px.x, px.y, pm, nx);
     };
 #pragma unroll
     for (int k = 0; k < RING; k++) issue(k, k);
     // prologue: level-0 rows 0..8 -> level-1 rows 0, 1, 2 (row r lives in slot r % RING)
-    uint4 H0 = take(0, 0), H1 = take(1, 1), H2 = take(2, 2);
+    // (stream rows at odd indices and level-1 rows at odd indices are rows 1 / 3 of the vertical windows they enter: biased sums)
+    uint4 H0 = take(0, 0, EV), H1 = take(1, 1, OD), H2 = take(2, 2, EV);
     uint2 K0, K1, K2;
     {
-        uint4 H3 = take(3, 3), H4 = take(4, 4);
-        K0 = level1(H0, H1, H2, H3, H4, 0); H0 = H2; H1 = H3; H2 = H4;
-        H3 = take(5, 5); H4 = take(6, 6);
-        K1 = level1(H0, H1, H2, H3, H4, 1); H0 = H2; H1 = H3; H2 = H4;
-        H3 = take(7, 7); H4 = take(8 % RING, 8);
-        K2 = level1(H0, H1, H2, H3, H4, 2); H0 = H2; H1 = H3; H2 = H4;
+        uint4 H3 = take(3, 3, OD), H4 = take(4, 4, EV);
+        K0 = level1(H0, H1, H2, H3, H4, 0, EV); H0 = H2; H1 = H3; H2 = H4;
+        H3 = take(5, 5, OD); H4 = take(6, 6, EV);
+        K1 = level1(H0, H1, H2, H3, H4, 1, OD); H0 = H2; H1 = H3; H2 = H4;
+        H3 = take(7, 7, OD); H4 = take(8 % RING, 8, EV);
+        K2 = level1(H0, H1, H2, H3, H4, 2, EV); H0 = H2; H1 = H3; H2 = H4;
     }
     const int o2base = oy2 * pitch2 + g * 4;
     for (int T = 0; T < oh2 / L2_PER_TRIP; T++) {
@@ -147,22 +192,28 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         for (int u = 0; u < L2_PER_TRIP; u++) {
             const int j = L2_PER_TRIP * T + u;                   // level-2 row of the strip
             const int r = 9 + 4 * j;                             // its four new level-0 rows r .. r + 3: slots (9 + 4 u + k) % RING
-            uint4 H3 = take((9 + 4 * u) % RING, r), H4 = take((10 + 4 * u) % RING, r + 1);
-            const uint2 K3 = level1(H0, H1, H2, H3, H4, 3 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
-            H3 = take((11 + 4 * u) % RING, r + 2); H4 = take((12 + 4 * u) % RING, r + 3);
-            const uint2 K4 = level1(H0, H1, H2, H3, H4, 4 + 2 * j); H0 = H2; H1 = H3; H2 = H4;
+            uint4 H3 = take((9 + 4 * u) % RING, r, OD), H4 = take((10 + 4 * u) % RING, r + 1, EV);
+            const uint2 K3 = level1(H0, H1, H2, H3, H4, 3 + 2 * j, OD); H0 = H2; H1 = H3; H2 = H4;
+            H3 = take((11 + 4 * u) % RING, r + 2, OD); H4 = take((12 + 4 * u) % RING, r + 3, EV);
+            const uint2 K4 = level1(H0, H1, H2, H3, H4, 4 + 2 * j, EV); H0 = H2; H1 = H3; H2 = H4;
             uint2 E0 = K0, E1 = K1, E3 = K3, E4 = K4;
+            const int row2 = REV && rev ? oy2 + oh2 - 1 - j : oy2 + j;           // the level-2 row this trip completes
             if constexpr (EDGE) {
-                // level-1 rows outside the image: their reflections are in the window (centre row yc = 2 (oy2 + j))
-                const int yc = 2 * (oy2 + j);
+                // level-1 rows outside the image: their reflections are in the window (centre row yc = 2 row2).  In space the window is
+                // (up2, up1, c, dn1, dn2) = (K0 .. K4) top-down and (K4 .. K0) bottom-up; the rules: above the first row up2 <- dn2,
+                // up1 <- dn1; below the last row dn1 <- up1, dn2 <- c (one row out) or up2 (two rows out)
+                const int yc = 2 * row2;
                 const bool top = yc == 0, b1 = yc + 2 == h1, b2 = yc + 1 == h1;
-                E0.x = top ? K4.x : K0.x; E0.y = top ? K4.y : K0.y;
-                E1.x = top ? K3.x : K1.x; E1.y = top ? K3.y : K1.y;
-                E3.x = b2 ? K1.x : K3.x; E3.y = b2 ? K1.y : K3.y;
-                E4.x = b1 ? K2.x : (b2 ? K0.x : K4.x); E4.y = b1 ? K2.y : (b2 ? K0.y : K4.y);
+                const bool rv = REV && rev;
+                const uint2 up2 = rv ? K4 : K0, up1 = rv ? K3 : K1, dn1 = rv ? K1 : K3, dn2 = rv ? K0 : K4;
+                E0.x = top ? dn2.x : up2.x; E0.y = top ? dn2.y : up2.y;
+                E1.x = top ? dn1.x : up1.x; E1.y = top ? dn1.y : up1.y;
+                E3.x = b2 ? up1.x : dn1.x; E3.y = b2 ? up1.y : dn1.y;
+                E4.x = b1 ? K2.x : (b2 ? up2.x : dn2.x); E4.y = b1 ? K2.y : (b2 ? up2.y : dn2.y);
             }
-            const uint32_t o = vgroup4(E0, E1, K2, E3, E4);
-            if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, 0);
+            const uint32_t o = vgroup4b(E0, E1, K2, E3, E4);
+            if constexpr (REV) { if (writer && row2 < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, row2 * pitch2 + g * 4, 0, 0); }
+            else if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, 0);
             K0 = K2; K1 = K3; K2 = K4;
         }
     }
@@ -170,7 +221,7 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
 
 // One 256-thread workgroup = 16 units of the image at `img`.  A0: level 0 -> 1 geometry (A0.pad = level-2 rows per strip, even),
 // A1: level 1 -> 2 geometry.
-template <bool COPY = false>
+template <bool COPY = false, bool REV = true>
 __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPyrArgs& A1, int blk, const uint8_t* __restrict__ img,
                                                uint8_t* __restrict__ out1, uint8_t* __restrict__ out2, uint8_t* copy = nullptr, int cpitch = 0)
 {
@@ -191,8 +242,9 @@ __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPy
     const auto r2 = __builtin_amdgcn_make_buffer_rsrc(out2, 0, A1.dh * (int)A1.dpitch, 0x00020000);
     const auto rc = __builtin_amdgcn_make_buffer_rsrc(COPY ? copy : out2, 0, COPY ? A0.sh * cpitch : 0, 0x00020000);
     if (__builtin_amdgcn_ballot_w64(uvalid) == 0) return;
-    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true, COPY>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on);
-    else pyr_roll2_rows<false, COPY>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on);
+    const bool rev = REV && (s & 1) && A0.rsv_ == 0;              // odd strips bottom-up
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true, COPY, REV>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
+    else pyr_roll2_rows<false, COPY, REV>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
 }
 
 __host__ __device__ inline int roll2_blocks(int sw, int h2, int oh2)

@@ -88,6 +88,55 @@ __device__ __forceinline__ uint2 vgroup8(uint4 r0, uint4 r1, uint4 r2, uint4 r3,
     return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x06040200u), __builtin_amdgcn_perm(p3, p2, 0x06040200u));
 }
 
+// ---- round 5: the same two passes with fewer instructions (the register-rolling kernels are VALU-bound once their re-reads are gone).
+// hgroup8b: every output as a CHAIN of two dot4 on aligned dwords -- no v_alignbyte, no tap extraction:
+//   even output of dword j (centre byte 4 j):     (x[-2], x[-1]) . (1, 4) of the dword before  +  (x0, x1, x2) . (6, 4, 1)
+//   odd  output of dword j (centre byte 4 j + 2): (x0 .. x3) . (1, 4, 6, 4)                    +  x0 of the dword after
+// 16 dot4 + 4 packs per 16 source bytes (before: 8 dot4 + 4 alignbyte + 8 extractions + 4 packs).  BIAS: 16 is added to each of the
+// eight sums (free: it is the accumulator input of the chain's first dot4).  The vertical pass takes the rows at ODD offsets of its
+// window biased: 4 * (16 + 16) = the +128 of the rounding, so vgroup8b needs no rounding add; and it takes the HIGH byte of every
+// 16-bit sum with the byte gather itself (no shift): 4 instructions per register pair of the window + 1 gather per two (before 7 + 1).
+// The largest intermediate is unchanged: 16 * 4080 + 128 = 65,408 < 2^16.  Same bits as hgroup8 / vgroup8 (tests/test_gpu_parity.py).
+template <bool BIAS>
+__device__ __forceinline__ uint4 hgroup8b(uint4 d, uint32_t pm, uint32_t nx)
+{
+    const uint32_t WB = 0x04010000u, WA = 0x00010406u, WC = 0x04060401u, WD = 0x00000001u;
+    const uint32_t c0 = BIAS ? 16u : 0u;
+    const uint32_t e0 = __builtin_amdgcn_udot4(d.x, WA, __builtin_amdgcn_udot4(pm, WB, c0, false), false);
+    const uint32_t o0 = __builtin_amdgcn_udot4(d.x, WC, __builtin_amdgcn_udot4(d.y, WD, c0, false), false);
+    const uint32_t e1 = __builtin_amdgcn_udot4(d.y, WA, __builtin_amdgcn_udot4(d.x, WB, c0, false), false);
+    const uint32_t o1 = __builtin_amdgcn_udot4(d.y, WC, __builtin_amdgcn_udot4(d.z, WD, c0, false), false);
+    const uint32_t e2 = __builtin_amdgcn_udot4(d.z, WA, __builtin_amdgcn_udot4(d.y, WB, c0, false), false);
+    const uint32_t o2 = __builtin_amdgcn_udot4(d.z, WC, __builtin_amdgcn_udot4(d.w, WD, c0, false), false);
+    const uint32_t e3 = __builtin_amdgcn_udot4(d.w, WA, __builtin_amdgcn_udot4(d.z, WB, c0, false), false);
+    const uint32_t o3 = __builtin_amdgcn_udot4(d.w, WC, __builtin_amdgcn_udot4(nx, WD, c0, false), false);
+    return make_uint4(e0 | (o0 << 16), e1 | (o1 << 16), e2 | (o2 << 16), e3 | (o3 << 16));
+}
+
+// t * 4 + c on both 16-bit halves, as ONE instruction (the compiler turns the multiplication by 4 into a shift and an add)
+__device__ __forceinline__ uint32_t pk_mad4(uint32_t t, uint32_t c)
+{
+    uint32_t r;
+    asm("v_pk_mad_u16 %0, %1, 4, %2 op_sel_hi:[1,0,1]" : "=v"(r) : "v"(t), "v"(c));
+    return r;
+}
+
+// one register (two columns) of the vertical pass on a window whose rows 1 and 3 carry the +16 bias: the two sums, UNSHIFTED
+__device__ __forceinline__ uint32_t vcol_b(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t a3, uint32_t a4)
+{
+    const uint32_t K6 = 0x00060006u;
+    uint32_t v = pk_mad4(pk_add(a1, a3), pk_add(a0, a4));
+    return pk_mad(a2, K6, v);
+}
+
+__device__ __forceinline__ uint2 vgroup8b(uint4 r0, uint4 r1, uint4 r2, uint4 r3, uint4 r4)
+{
+    const uint32_t p0 = vcol_b(r0.x, r1.x, r2.x, r3.x, r4.x), p1 = vcol_b(r0.y, r1.y, r2.y, r3.y, r4.y);
+    const uint32_t p2 = vcol_b(r0.z, r1.z, r2.z, r3.z, r4.z), p3 = vcol_b(r0.w, r1.w, r2.w, r3.w, r4.w);
+    // the HIGH byte of each half = (sum + 128) >> 8: (p.b1, p.b3, q.b1, q.b3) -> one dword
+    return make_uint2(__builtin_amdgcn_perm(p1, p0, 0x07050301u), __builtin_amdgcn_perm(p3, p2, 0x07050301u));
+}
+
 // one 128x16 output tile (bx, by) of the image at `img` -> `out`.  lds: PYR_LDS_BYTES, 16-B aligned
 __device__ __forceinline__ void pyr_down_body(const AgtPyrArgs& A, int bx, int by, const uint8_t* __restrict__ img,
                                               uint8_t* __restrict__ out, uint8_t* lds)

@@ -23,9 +23,7 @@
 #include <cstddef>
 #include "agt_pyramid2_body.h"
 #include "agt_pyramid3_body.h"
-#ifdef AGT_DEBUG_KNOBS
 #include "agt_pyramid4_body.h"
-#endif
 #include "agt_lk_rs_body.h"
 #include "agt_lk_chain_body.h"
 #include "agt_pnp_body.h"
@@ -100,7 +98,7 @@ template <int WIN, int NW, int NLEV, int THREADS, bool XCD_MAP = false>
 __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTables& T, KParams KS, KTables KT, int blk, uint8_t* lds)
 {
     constexpr int CPB = THREADS / (AGT_WAVE * NW);
-    if constexpr (XCD_MAP) blk = (blk & 7) * ((int)gridDim.x >> 3) + (blk >> 3);
+    if constexpr (XCD_MAP) blk = agt_xcd_order(blk, (int)gridDim.x, KS->xshift);
     const int wave = threadIdx.x / AGT_WAVE;
     const long corner = (long)blk * CPB + (NW == 1 ? wave : 0);
     if (corner >= (long)S.lk.n * S.lk_B) return;
@@ -208,15 +206,16 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
         const int n = KS->n_pyr[s];
         if (blk < n) {
             AgtPyrArgs A;
-            A.src = nullptr; A.dst = nullptr; A.pad = 0;
+            A.src = nullptr; A.dst = nullptr; A.pad = 0; A.rsv_ = 0;
             A.spitch = KS->pyr[s].spitch; A.sbatch = KS->pyr[s].sbatch; A.dpitch = KS->pyr[s].dpitch; A.dbatch = KS->pyr[s].dbatch;
             A.sw = KS->pyr[s].sw; A.sh = KS->pyr[s].sh; A.dw = KS->pyr[s].dw; A.dh = KS->pyr[s].dh;
             A.gx = KS->pyr[s].gx; A.gy = KS->pyr[s].gy; A.B = KS->pyr[s].B; A.pad = KS->pyr[s].pad;
-            // XCD-aware tile order (see agt_pyramid.hip): workgroup index % 8 is the XCD; the stage's
+            // XCD-aware tile order (see agt_pyramid.hip): workgroup index % X is the XCD (X = 2^xshift XCDs); the stage's
             // workgroups on XCD j take a contiguous run of tiles, runs laid out in XCD order.
-            const int j = (blk + base) & 7;
-            int tile = (blk - ((j - base) & 7)) >> 3;
-            for (int q = 0; q < j; q++) tile += (n - ((q - base) & 7) + 7) >> 3;
+            const int xs = KS->xshift, xm = (1 << xs) - 1;
+            const int j = (blk + base) & xm;
+            int tile = (blk - ((j - base) & xm)) >> xs;
+            for (int q = 0; q < j; q++) tile += (n - ((q - base) & xm) + xm) >> xs;
             const int per_img = A.gx * A.gy;
             const int bz = tile / per_img, r = tile - bz * per_img;      // bz = frame * B + stream
             const int by = r / A.gx, bx = r - by * A.gx;
@@ -228,13 +227,12 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
                 A1.spitch = KS->pyr[1].spitch; A1.sbatch = KS->pyr[1].sbatch; A1.dpitch = KS->pyr[1].dpitch; A1.dbatch = KS->pyr[1].dbatch;
                 A1.sw = KS->pyr[1].sw; A1.sh = KS->pyr[1].sh; A1.dw = KS->pyr[1].dw; A1.dh = KS->pyr[1].dh;
                 A1.gx = A.gx; A1.gy = A.gy; A1.B = A.B;
-#ifdef AGT_DEBUG_KNOBS      // (the register-rolling two-level pass is not shipped: agt_pyramid.hip agt_pyr2_plan)
-                if (A.pad) {      // bx = workgroup of the image, no LDS
+                if (A.pad) {      // register-rolling form, alternating strip directions (agt_pyramid.hip agt_pyr2_plan): bx = workgroup of the image, no LDS
+                    A.rsv_ = KS->pyr[0].rsv_;
                     agt_pyr4::pyr_roll2_body(A, A1, bx, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
                                              KT->pyr_dst[1][fr] + (long)st * A1.dbatch);
                     return;
                 }
-#endif
                 agt_pyr2::pyr_down2_body(A, A1, bx, by, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
                                          KT->pyr_dst[1][fr] + (long)st * A1.dbatch, lds);
                 return;
@@ -341,7 +339,10 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
         }
         // agt_track_host_frame: the host thread polls for this frame's record (behind the hand-over to the other wave: the
         // system-scope release waits for the record's stores to reach the host)
-        if (S.pnp.host_seq && blk == 0) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, lane == 0);
+        // ONLY the launch's last frame is reported: frames k and k + 1 are solved by different waves, nothing orders
+        // their stores, and a word that steps back from `want` to `want - 1` would leave the host polling until its time-out.  The
+        // host waits for the newest frame only, launches are stream-ordered, and a launch's last frame is written by one wave.
+        if (S.pnp.host_seq && blk == 0 && k == S.pnp_nf - 1) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, lane == 0);
     }
 }
 
@@ -403,7 +404,7 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
         if (wave == 0) {            // (wave 0 ran the state update of frame k in either body: its own LDS accesses are in program order)
             agt_pnp::pnp_sync();
             if (tid == 0) *(volatile int*)&sh.coop[(k + 1) & 1] = *(volatile int*)&sh.ts.has_guess;
-            if (S.pnp.host_seq && blk == 0) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, tid == 0);
+            if (S.pnp.host_seq && blk == 0 && k == S.pnp_nf - 1) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, tid == 0);
         }
     }
     __syncthreads();
@@ -473,7 +474,7 @@ __device__ __forceinline__ void lk_reseed_role(const AgtStepParams& S, const Agt
                                                int bid, int nblk, uint8_t* lds)
 {
     static_assert(sizeof(agt_dense::DenseShared) <= agt_lk::lk_chain_lds_bytes<NLEV>(), "the prologue's LDS fits the tracker's");
-    const int blk = (bid & 7) * (nblk >> 3) + (bid >> 3);      // XCD-aware corner order (lk_role); nblk is a multiple of 8
+    const int blk = agt_xcd_order(bid, nblk, KS->xshift);      // XCD-aware corner order (lk_role); nblk is a multiple of the XCD count
     if (blk >= S.lk.n * S.lk_B) return;
     const int b = blk / S.lk.n, pt = blk - b * S.lk.n;
     const long pidx = (long)b * S.lk.n + pt;
@@ -591,6 +592,8 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
+    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift; P.lk.rsv_ = 0;
+    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.pyr[s].xshift = P.xshift;
     if (roles == AGT_STEP_PNP) {
         if (P.n_pnp <= 0) return hipSuccess;
         if (P.pnp.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
@@ -649,7 +652,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         constexpr int OCCL = (WIN == 21 && NW == 1) ? AGT_LKG_OCC : 1;
         const long corners = (long)P.lk.n * P.lk_B;
         const size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
-        const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
+        const unsigned grid8 = agt_xcd_grid(corners, P.xshift);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
         if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         return hipGetLastError();
@@ -677,10 +680,11 @@ bool agt_step_supported(int win) { return win == 21; }
 // 8: 24.6 / 20.4, 12: 33.9 / 25.4, 16: 38.0 / 33.5, 21: 46.7 / 36.9, 32: 42.9 / 40.6, 42: 56.0 / 46.2 (profiles/r03_stream_sweep.txt).
 bool agt_step_fits(int n, int B)
 {
+    // one LK workgroup per CU, all co-resident (the PnP role's registers leave room for one workgroup per CU): the chip's CU count,
+    // 256 on a whole MI355X
+    long cap = agt_chip_current().cus;
 #ifdef AGT_DEBUG_KNOBS
-    static const long cap = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 256L; }();
-#else
-    const long cap = 256;
+    { static const long f = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 0L; }(); if (f > 0) cap = f; }
 #endif
     return n <= AGT_WAVE && (long)n * B <= cap;
 }
@@ -698,7 +702,8 @@ hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, cons
     if (!chain) { P.n_pnp = 0; P.pnp_nf = 0; }
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
     const long corners = (long)P.lk.n * P.lk_B;
-    const unsigned grid8 = (unsigned)((corners + 7) / 8 * 8);
+    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift; P.lk.rsv_ = 0;
+    const unsigned grid8 = agt_xcd_grid(corners, P.xshift);
     P.n_lk = (int)grid8;
     agt_dense::DenseParams D;
     static_assert(sizeof(D) <= sizeof(F->bytes), "AgtDenseFinal holds a DenseParams");

@@ -15,10 +15,12 @@ def env_rank():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def init(backend=None):
-    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun)."""
+def init(backend=None, force=False):
+    """Join the job described by RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT (torchrun).  A single process (world 1) joins
+    nothing unless `force` (the world-1 RCCL test: process group of one rank, so that the collective branch of gather_poses
+    runs on a machine with one GPU)."""
     rank, local_rank, world = env_rank()
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or force) and not dist.is_initialized():
         if backend is None:
             backend = os.environ.get("AGT_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         if backend == "nccl":
@@ -34,11 +36,12 @@ def shard_streams(n_streams, rank, world):
     return range(lo, lo + base + (1 if rank < rem else 0))
 
 
-def gather_poses(local, world=None):
+def gather_poses(local, world=None, force_collective=False):
     """local: [frames, streams_local, 8] f64 (rvec 3, tvec 3, ok, frame index).  Returns
     [world, frames, streams_local, 8] on every rank (equal shard sizes required), or
-    local[None] when not distributed."""
-    if not dist.is_initialized() or dist.get_world_size() == 1:
+    local[None] when not distributed.  force_collective: take the all_gather branch even for a process group of ONE rank
+    (tests/test_gpu_distributed.py: RCCL initialisation + a device-tensor all_gather on the one GPU a test box has)."""
+    if not dist.is_initialized() or (dist.get_world_size() == 1 and not force_collective):
         return local.unsqueeze(0)
     world = dist.get_world_size()
     local = local.contiguous()

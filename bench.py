@@ -433,7 +433,7 @@ def main():
             kernel_us = float(stage_us[dom]) / launches
             achieved = B * ab[names[dom]] / launches / (kernel_us * 1e-6) / 1e9
             whole = B * ab["frame"] / (med / K) / 1e9
-            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_roll_kernel (register-rolling pyrDown: L0->L1 and L1->L2 launches)", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
+            roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_group_kernel (register-rolling pyrDown, both levels in one pass since round 5)", "lk": "lk_kernel<21,1,3>", "pnp": "pnp_kernel<float,1>"}[names[dom]],
                     "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6),
                     "traffic": None, "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(B * ab[names[dom]] / launches),
                     "whole_step": {"algorithmic_GBs": round(whole, 1), "frac_of_8TBs": round(whole / HBM_PEAK_GBS, 4),
@@ -516,7 +516,7 @@ def dry_run(args, torch, D, rank, world):
         print(json.dumps({"metric": "frames/sec (LK+PnP) on 1280x720 dodeca stream", "value": round(world * bench.B * bench.K / med, 2),
                           "unit": "frames/s", "n_gpus": world, "steps": bench.K, "warmup": bench.Wm, "ms_per_step": round(med / bench.K * 1e3, 5),
                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "none", "data": "dry-run (stub tracker, no GPU work: NOT a measurement)",
-                          "config": {"workload": "dry-run"}, "timing": {"blocks": len(dts), "steps_per_block": bench.K},
+                          "config": {"workload": "dry-run", "geometry_of": args.workload}, "timing": {"blocks": len(dts), "steps_per_block": bench.K},
                           "gathered_shape": list(gathered.shape), "gather_ok": bool(ok), "dry_run": True}), flush=True)
     D.barrier()
     if not ok:
@@ -638,7 +638,7 @@ def batch_extra(torch, D, HL, args, rank, dev):
             "whole_step_algorithmic_GBs": round(step_bytes / (med / a.steps) / 1e9, 1), "whole_step_frac_of_8TBs": round(step_bytes / (med / a.steps) / 1e9 / HBM_PEAK_GBS, 4),
             "span_us": {"pyramid": round(float(spans[0]), 2), "lk": round(float(spans[1]), 2), "pnp": round(float(spans[2]), 2)},
             "pyr_down_algorithmic_GBs": round(pyr_gbs, 1), "pyr_down_frac_of_8TBs": round(pyr_gbs / HBM_PEAK_GBS, 4),
-            "pyr_down_bytes_note": "W*H*1.3125 per frame (SURVEY 8d); the two single-level passes' own traffic (level 1 read again) would be %.1f GB/s = %.4f of 8 TB/s"
+            "pyr_down_bytes_note": "W*H*1.3125 per frame (SURVEY 8d); on the bytes of two single-level passes (level 1 read again: rounds 3-4) that would be %.1f GB/s = %.4f of 8 TB/s"
                                    % (pyr2_gbs, pyr2_gbs / HBM_PEAK_GBS),
             "accepted_frac": round(ok, 4), "pose_err_vs_cpu": pose_err, "copies_bitwise_equal_to_their_seed_stream": bool(copies_ok)}
 
@@ -669,6 +669,20 @@ def pairs_extra(args):
 
 
 _native = []
+
+
+def cpu_available():
+    try:
+        return len(os.sched_getaffinity(0))
+    except AttributeError:
+        return os.cpu_count() or 1
+
+
+def cpu_thread_counts():
+    """1, 4, 16, 64, ... up to every core available to the process (SURVEY 8d's os.cpu_count() leg; the last entry)"""
+    top = max(1, cpu_available())
+    out = [c for c in (1, 4, 16, 64) if c < top]
+    return out + [top] if top > 1 else [1]
 
 
 def native_oracle():
@@ -806,27 +820,32 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
         if time.perf_counter() - t0 > 10.0 or n >= 20000:
             break
     dt = time.perf_counter() - t0
-    try:
-        nthr = len(os.sched_getaffinity(0))
-    except AttributeError:
-        nthr = os.cpu_count() or 1
-    nthr = max(1, min(nthr, 16))          # the GPU box grants about 16 cores per GPU
-    pyr2 = cvo.Pyramid(frames[0]); pts2 = seq.corners(0)
-    r2, t2 = seq.rvecs[0].copy(), seq.tvecs[0].copy()
-    n2 = 0; t1 = time.perf_counter()
-    while nthr > 1:
-        k = pingpong(n2 + 1, NF)
-        pyr2, pts2, _, _, _, r2, t2 = cvo.track_frame(pyr2, frames[k], pts2, seq.obj, seq.K, None, r2, t2, nthreads=nthr)
-        n2 += 1
-        if time.perf_counter() - t1 > 5.0 or n2 >= 8000:
-            break
-    dt2 = time.perf_counter() - t1
+
+    def threaded(nthr, seconds):
+        pyr2 = cvo.Pyramid(frames[0]); pts2 = seq.corners(0)
+        r2, t2 = seq.rvecs[0].copy(), seq.tvecs[0].copy()
+        n2 = 0; t1 = time.perf_counter()
+        while True:
+            k = pingpong(n2 + 1, NF)
+            pyr2, pts2, _, _, _, r2, t2 = cvo.track_frame(pyr2, frames[k], pts2, seq.obj, seq.K, None, r2, t2, nthreads=nthr)
+            n2 += 1
+            if time.perf_counter() - t1 > seconds or n2 >= 8000:
+                break
+        return n2, time.perf_counter() - t1
+    # "at 1 thread and at os.cpu_count() threads" -- and the steps between, so that the plateau is visible (one stream is
+    # 48 corners and three image levels: pyrDown / Scharr in bands of rows, LK over points; the threads past ~16 have nothing to do)
+    curve = [{"cores": 1, "value": round(n / dt, 2)}]
+    for nthr in cpu_thread_counts()[1:]:
+        n2, dt2 = threaded(nthr, 2.5)
+        curve.append({"cores": nthr, "value": round(n2 / dt2, 2), "sample": "%d frames, %.1f s" % (n2, dt2)})
+    top = curve[-1]
     cpu = {"value": round(n / dt, 2), "unit": "frames/s", "cores": 1, "kind": "port",
-           "sample": "%d frames of the same %dx%d stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores"
-                     % (n, W_, H_, dt, os.cpu_count()),
+           "sample": "%d frames of the same %dx%d stream, oracle cvo_track_frame (pyramid+Scharr+LK+LM), 1 thread, %.1f s; host has %d cores, %d available to this process"
+                     % (n, W_, H_, dt, os.cpu_count(), cpu_available()),
            "cpu_model": cpu_model(), "build": flags,
-           "all_cores": {"value": round(n2 / dt2, 2), "cores": nthr,
-                         "sample": "%d frames, %.1f s; pyrDown / Scharr in %d bands of rows, LK over points (OpenMP)" % (n2, dt2, nthr)} if n2 else None}
+           "all_cores": {"value": top["value"], "cores": top["cores"],
+                         "sample": "%s; pyrDown / Scharr in %d bands of rows, LK over points (OpenMP); every core available to the process" % (top.get("sample", ""), top["cores"])} if len(curve) > 1 else None,
+           "threads_curve": curve}
     return cpu, pose_gap_vs_cpu_chain(seq, frames, gpu_state, NF, 60)
 
 

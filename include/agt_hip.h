@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 400
+#define AGT_VERSION 500
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -97,6 +97,17 @@ typedef struct agt_config {
 
 /* ---- lifetime ---- */
 int  agt_version(void);
+/* What the context's device reported at agt_create (round 5): CU count (hipDeviceProp_t::multiProcessorCount), the XCD count the
+ * XCD-aware block orders are laid out for (gfx950: one XCD per 32 CUs -- 8 on a whole MI355X, 4 / 2 / 1 on its DPX / QPX / CPX
+ * partitions; 1 = plain order when the CU count is not 32 x a power of two) and the architecture name.  agt_create refuses
+ * devices other than gfx950 with AGT_ERR_UNSUPPORTED (the library holds gfx950 code objects only).  The launch rules that used to
+ * say "256 CUs" (fused step while one LK workgroup per CU is co-resident, chained dense launch) read this CU count. */
+int  agt_device_info(const agt_ctx* ctx, int* cus, int* xcds, char* arch, size_t arch_cap);
+/* The XCD-aware block order as a pure index map (host function, no GPU needed): block `block` of a launch of `nblocks` blocks
+ * (a multiple of xcds; xcds in {1, 2, 4, 8}) works on item (block mod xcds) * (nblocks / xcds) + block / xcds.  For every xcds
+ * a permutation of 0 .. nblocks - 1 in which the blocks of one XCD (equal block mod xcds) take a contiguous run of items.
+ * Returns the item, or AGT_ERR_ARG. */
+int  agt_xcd_tile_order(int block, int nblocks, int xcds);
 const char* agt_error_string(int code);
 /* hip_stream: a hipStream_t (NULL = default stream).  Allocates the context's pyramid
  * storage (levels >= 1 for two slots), tracker state and scratch. */
@@ -244,7 +255,11 @@ int agt_tracker_rewind(agt_ctx* ctx);
  *   d_state   optional device copy of the record (stream-ordered, complete at the next synchronisation); NULL = none
  * The record reaches h_state without a copy command: the pose solver writes it to host-mapped memory of the context and
  * stores a sequence number behind it, which this call polls (falls back to waiting for the stream after 2 s and reports the
- * runtime's error).  A chain fault of the step is returned as AGT_ERR_CHAIN. */
+ * runtime's error).  A chain fault of the step is returned as AGT_ERR_CHAIN.
+ * THE STREAM IS NOT IDLE ON RETURN: the call comes back when the record is in h_state, while the tail of the pose kernel and the
+ * optional d_state copy may still be running on the context's stream.  Work the caller issues on that stream is ordered behind
+ * them as usual; a caller that touches d_staging, d_gray or d_state from ANOTHER stream (or from the host) must order itself
+ * behind the context's stream first (agt_synchronize or an event) -- the implicit stream wait of ABI <= 300 is gone. */
 int agt_track_host_frame(agt_ctx* ctx, const uint8_t* h_frame, int channels, int src_w, int src_h, uint8_t* d_staging,
                          int undistort, int roi_x, int roi_y, uint8_t* d_gray, size_t gpitch, double* d_state, double* h_state);
 /* A clip: `count` consecutive frames of the B streams in one call, frame k at d_frames + k * frame_stride (bytes), its

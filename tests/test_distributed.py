@@ -85,6 +85,19 @@ def test_bench_self_launch_world2_gloo():
     assert "dry-run" in j["data"]
 
 
+def test_bench_self_launch_world8_gloo():
+    """BASELINE configs[3] is EIGHT ranks (8 x 1920x1080, one stream per GPU, one gather of the poses per block): the bench's own
+    flow -- self-launch, rendezvous, block timing, all_gather, the gather-order check on the real record layout -- with world 8
+    on the CPU (VERDICT r4 #7b; the tests of rounds 1-4 stopped at world 2).  Every rank's block must land in its own slot:
+    block q holds RANK q's stream (the stub writes the generator's pose of seed 1000 q), and blocks differ from one another."""
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    j = _bench_json([sys.executable, "bench.py", "--gpus", "8", "--workload", "c4", "--steps", "4", "--warmup", "1", "--blocks", "2", "--dry-run"], env)
+    assert j["n_gpus"] == 8 and j["steps"] == 4 and j["dry_run"] and j["gather_ok"]
+    assert j["gathered_shape"] == [8, 4, 1, 16] and j["config"]["geometry_of"] == "c4"
+    # (gather_ok of a dry run IS the gather-order check of the real run at tolerance 1e-12, plus "block q differs from block 0")
+
+
 def test_bench_under_torchrun_world2_gloo():
     """the driver's N > 1 form: python -m torch.distributed.run ... bench.py --gpus 2 (ranks given by the launcher)"""
     import sys
