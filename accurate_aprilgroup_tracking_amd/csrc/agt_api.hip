@@ -21,6 +21,7 @@
 struct agt_ctx {
     agt_config cfg;
     AgtChip chip;                            // the device the context was created on (CU / XCD counts: launch rules and block orders)
+    int lk_lds_pad;                          // agt_lk_occupancy: extra LDS per one-wave LK workgroup (0 = no cap)
     hipStream_t stream;
     int last_hip;
     int eff_max_level;                       // after OpenCV's early stop
@@ -573,6 +574,28 @@ int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_p
     return AGT_OK;
 }
 
+// Occupancy cap of the one-wave-per-corner LK kernel (big batches): at most `waves_per_simd` of its waves resident on a SIMD (0 = no
+// cap: as many as registers and LDS allow, 3-4).  For contexts that SHARE the device with other contexts' kernels: the tracker holds
+// 128 registers and ~9.5 KB of LDS per wave, three of them leave one wave slot of registers per SIMD to anybody else, and a launch
+// lasts as long as its slowest corner -- the HBM-bound pyramid passes of the other batches starve beside it.  The cap is enforced
+// with LDS: every workgroup (one wave) asks for LDS_per_CU / (4 * waves_per_simd) bytes.
+int agt_lk_occupancy(agt_ctx* c, int waves_per_simd)
+{
+    if (!c || waves_per_simd < 0 || waves_per_simd > 8) return AGT_ERR_ARG;
+    int rc = join_pipeline(c);
+    if (rc) return rc;
+    c->lk_lds_pad = 0;
+    if (waves_per_simd > 0) {
+        // gfx950: 160 KB of LDS per CU (MI355X_MICROARCH.md; hipDeviceProp_t reports the 64 KB a workgroup may ask for, not this)
+        const long lds_cu = 160L * 1024;
+        const long per_wave = (lds_cu / (4L * waves_per_simd)) & ~1023L;          // 1 KB below the exact share: allocation granularity
+        const long base = 10L * 1024;                                             // what a three-level corner needs anyway (9.5 KB)
+        c->lk_lds_pad = per_wave > base ? (int)(per_wave - base) : 0;
+        if (c->lk_lds_pad > 48 * 1024) c->lk_lds_pad = 48 * 1024;                 // (a workgroup may ask for 64 KB in all)
+    }
+    return AGT_OK;
+}
+
 int agt_tracker_tag_gate(agt_ctx* c, int corners_per_tag)
 {
     if (!c || (corners_per_tag != 0 && corners_per_tag != 4)) return AGT_ERR_ARG;
@@ -653,6 +676,7 @@ static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slo
     p->flags = flags;
     p->min_eig_threshold = min_eig_threshold;
     p->prev_pts = d_prev; p->prev_status = d_prev_status; p->next_pts = d_next; p->status = d_status; p->err = d_err;
+    p->lds_pad = c->lk_lds_pad;
     return AGT_OK;
 }
 

@@ -58,7 +58,7 @@ struct AgtLkParams {
     uint8_t* status;          // [B][n]
     float* err;               // [B][n] or null
     int xshift;               // XCD-aware corner order (agt_xcd_order); set by the launchers
-    int rsv_;
+    int lds_pad;              // host side only: extra dynamic LDS per one-wave workgroup = an occupancy cap (agt_lk_occupancy); 0 = none
 };
 
 struct AgtCameraHost {

@@ -39,14 +39,21 @@ template <int WIN, int NW>
 hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p_in, int B)
 {
     AgtLkParams p = p_in;
-    p.xshift = agt_chip_current().xshift; p.rsv_ = 0;
-    const size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
+    p.xshift = agt_chip_current().xshift;
+    size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
+    if (NW == 1 && p.lds_pad > 0) lds += (size_t)p.lds_pad;          // agt_lk_occupancy: fewer resident LK waves per CU
+#ifdef AGT_DEBUG_KNOBS      // AGT_LK_LDS_PAD=bytes: extra LDS per workgroup = fewer LK waves per CU (room for other kernels' waves beside them)
+    { static const long pad = [] { const char* e = getenv("AGT_LK_LDS_PAD"); return e ? atol(e) : 0L; }(); if (pad > 0 && NW == 1) lds += (size_t)pad; }
+#endif
     const long total = (long)p.n * B;
     if (total <= 0 || total > (1L << 30)) return hipErrorInvalidValue;
     const dim3 grid(agt_xcd_grid(total, p.xshift)), block(AGT_WAVE * NW);
     constexpr int OCC = (WIN == 21 && NW == 1) ? 4 : 1;
+    // (pyramids of more than three levels: the six-level one-wave body keeps six levels' tile bookkeeping alive and spilled 34 VGPRs
+    // at the 128 registers of four waves per SIMD; it gets the 168 of three -- round 5, no scratch left in the library)
+    constexpr int OCC6 = (WIN == 21 && NW == 1) ? 3 : 1;
     if (p.max_level < 3) hipLaunchKernelGGL((lk_kernel<WIN, NW, 3, OCC>), grid, block, lds, stream, p, (int)total);
-    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC>), grid, block, lds, stream, p, (int)total);
+    else hipLaunchKernelGGL((lk_kernel<WIN, NW, AGT_MAX_LEVELS, OCC6>), grid, block, lds, stream, p, (int)total);
     return hipGetLastError();
 }
 

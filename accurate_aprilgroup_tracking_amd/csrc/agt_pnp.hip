@@ -11,6 +11,9 @@ template <typename T, int PPL>
 __global__ __launch_bounds__(AGT_WAVE) void pnp_kernel(const AgtPnpParams P)
 {
     __shared__ agt_pnp::PnpShared sh;
+#ifdef AGT_PNP_PRIO         // experiment builds (tools/build_variant.sh): issue priority of the solver's wave beside other kernels' waves
+    __builtin_amdgcn_s_setprio(AGT_PNP_PRIO);
+#endif
     agt_pnp::pnp_body<T, PPL>(P, blockIdx.x, sh, P.img, P.mask, P.state_out);
     if (P.host_seq && blockIdx.x == 0) agt_host_seq_store(P.host_seq, P.host_seq_base, threadIdx.x == 0);
 }

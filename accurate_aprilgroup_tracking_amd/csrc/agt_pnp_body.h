@@ -25,12 +25,15 @@
 #ifdef AGT_PNP_STAMPS
 __device__ unsigned long long agt_pnp_stamps[64];
 #define PSTAMP(i) do { if (b == 0 && threadIdx.x == 0) agt_pnp_stamps[i] = __builtin_amdgcn_s_memtime(); } while (0)
+// ... with a marker instruction the disassembly can be cut at (tools/pnp_eval_isa.py): s_mov_b32 sN, 0xbeef00 + i
+#define PSTAMPM(i) do { int mk_; asm volatile("s_mov_b32 %0, %1" : "=s"(mk_) : "n"(0xbeef00 + (i))); PSTAMP(i); } while (0)
 extern "C" int agt_debug_pnp_stamps(unsigned long long* host64)
 {
     return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(agt_pnp_stamps), sizeof(agt_pnp_stamps));
 }
 #else
 #define PSTAMP(i)
+#define PSTAMPM(i)
 #endif
 
 #pragma clang fp contract(fast)      // FP64 pose code only, see agt_device.h
@@ -1015,11 +1018,11 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
         constexpr bool D = decltype(DIST)::value;
         const bool needJ = mode != 0;
         double R[9], G[9];
-        if (mode == 2) PSTAMP(48);
+        if (mode == 2) PSTAMPM(48);
         if (needJ) agt_rodrigues<true>(param, R, G); else agt_rodrigues<false>(param, R, G);
 #pragma unroll
         for (int i = 0; i < 9; i++) Rlast[i] = R[i];
-        if (mode == 2) PSTAMP(49);
+        if (mode == 2) PSTAMPM(49);
         if (needJ) {
             double acc[NACC];
 #pragma unroll
@@ -1046,7 +1049,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 }
                 acc[27] += ex * ex + ey * ey;
             }
-            if (mode == 2) PSTAMP(50);
+            if (mode == 2) PSTAMPM(50);
             if constexpr (COOP == 1) wave_reduce_bfly<NACC>(acc, tot, lane);
             else {
                 double* slot = &sh.part[slab_sel * COOP * 32];
@@ -1062,7 +1065,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
                 slab_sel ^= 1;
             }
             if (mode == 2) {
-                PSTAMP(51);
+                PSTAMPM(51);
                 return tot[27];
             }
 #pragma unroll

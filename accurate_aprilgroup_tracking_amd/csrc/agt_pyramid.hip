@@ -61,6 +61,9 @@ __global__ __launch_bounds__(agt_pyr::NT) void pyr_upload2_kernel(const AgtPyrAr
 // A0.pad = level-2 rows per strip
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_roll2_kernel(const AgtPyrArgs A0, const AgtPyrArgs A1)
 {
+#ifdef AGT_PYR_PRIO         // experiment builds: issue priority of the HBM-bound pass beside the LK kernels' waves
+    __builtin_amdgcn_s_setprio(AGT_PYR_PRIO);
+#endif
     const int t = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, A0.xshift);
     if (t >= A0.gx * A0.B) return;
     const int bz = t / A0.gx;

@@ -87,15 +87,17 @@ __device__ __forceinline__ uint32_t vgroup4b(uint2 r0, uint2 r1, uint2 r2, uint2
 }
 
 // level-0 horizontal sums of one row (no edge dword: the halo lanes stand in for the tile's neighbours)
-template <bool ODD>
+template <bool ODD, bool LR>
 __device__ __forceinline__ uint4 roll2_hrow(u32x4 d, bool left_edge, bool right_edge)
 {
     // (the image's first group sits on lane 1 of tile 0, behind an idle halo lane: selected AFTER the shift, unlike agt_pyramid3_body.h)
     // (bound_ctrl: the row's first / last lane reads 0 -- no register has to be zeroed for the shift's "old" operand)
     uint32_t pm = (uint32_t)__builtin_amdgcn_mov_dpp((int)d.w, 0x111, 0xf, 0xf, true);                            // row_shr:1
     uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)d.x, 0x101, 0xf, 0xf, true);                            // row_shl:1
-    pm = left_edge ? __builtin_amdgcn_perm(d.x, d.x, 0x01020000u) : pm;
-    nx = right_edge ? (d.w >> 16) : nx;
+    if constexpr (LR) {       // (waves whose column tiles touch neither image edge skip the reflection selects: wave-uniform choice)
+        pm = left_edge ? __builtin_amdgcn_perm(d.x, d.x, 0x01020000u) : pm;
+        nx = right_edge ? (d.w >> 16) : nx;
+    }
     return hgroup8b<ODD>(make_uint4(d.x, d.y, d.z, d.w), pm, nx);
 }
 
@@ -110,7 +112,7 @@ template <bool V> struct Odd { static constexpr bool value = V; };
 // make neighbouring strips read their shared 9 halo rows AT THE SAME TIME -- both start at, or both end at, their common border --
 // so the second reader finds the lines in the XCD's L2 instead of fetching them again from memory (measured before: FETCH_SIZE of
 // the pass = (4 oh2 + 9) / (4 oh2) of the image, every halo row came from memory a second time).
-template <bool EDGE, bool COPY, bool REV, typename RS>
+template <bool EDGE, bool COPY, bool REV, bool LR, typename RS>
 __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPyrArgs& A1, const RS rs, const RS r1, const RS r2, const RS rc, int cpitch,
                                                int oy2, int g, int q, int G, bool lane_on, bool rev)
 {
@@ -144,7 +146,7 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
             if (writer && y >= 4 * oy2 && y < 4 * oy2 + 4 * oh2 && y < sh)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4u, d[slot]), rc, y * cpitch + xoff, 0, 0);
         }
-        const uint4 h = roll2_hrow<decltype(odd)::value>(d[slot], left_edge, right_edge);
+        const uint4 h = roll2_hrow<decltype(odd)::value, LR>(d[slot], left_edge, right_edge);
         issue(slot, r + RING);
         return h;
     };
@@ -153,12 +155,22 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
     // lanes if the row is the strip's own, and their horizontal sums for level 2
     const int o1base = 2 * oy2 * pitch1 + g * 8;                   // (level-1 row i = 2: the strip's first own row; offsets stay non-negative)
     const int y1last = y1a + 2 * oh2 + 2;
+    // Stores, REV form: the strip's own rows as a RANGE OF STREAM INDICES per lane (empty for lanes that store nothing) and the
+    // address as base + index * step -- two compares against the wave-uniform index and one 24-bit multiply-add per row.
+    //   level 1, top-down:  row y1a + i,    own rows 2 <= i < 2 oh2 + 2,  inside the image while i < h1 - y1a
+    //            bottom-up: row y1last - i, own rows 1 <= i <= 2 oh2,     inside the image while i > y1last - h1
+    //   level 2, top-down:  row oy2 + j (j < h2 - oy2);  bottom-up: row oy2 + oh2 - 1 - j (j >= oy2 + oh2 - h2)
+    const bool rv = REV && rev;
+    int i_lo = rv ? (y1last - h1 + 1 > 1 ? y1last - h1 + 1 : 1) : 2, i_hi = rv ? 2 * oh2 + 1 : (h1 - y1a < 2 * oh2 + 2 ? h1 - y1a : 2 * oh2 + 2);
+    int j_lo = rv ? (oy2 + oh2 - h2 > 0 ? oy2 + oh2 - h2 : 0) : 0, j_hi = rv ? oh2 : (h2 - oy2 < oh2 ? h2 - oy2 : oh2);
+    if (!writer) { i_lo = i_hi = 0; j_lo = j_hi = 0; }
+    const int a1_lane = (rv ? y1last : y1a) * pitch1 + g * 8, p1_lane = rv ? -pitch1 : pitch1;
+    const int a2_lane = (rv ? oy2 + oh2 - 1 : oy2) * pitch2 + g * 4, p2_lane = rv ? -pitch2 : pitch2;
     auto level1 = [&](const uint4& a0, const uint4& a1, const uint4& a2, const uint4& a3, const uint4& a4, int i, auto odd) {
         const uint2 px = vgroup8b(a0, a1, a2, a3, a4);
         if constexpr (REV) {
-            const int y1 = rev ? y1last - i : y1a + i;
-            if (writer && y1 >= 2 * oy2 && y1 < 2 * oy2 + 2 * oh2 && y1 < h1)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, y1 * pitch1 + g * 8, 0, 0);
+            if (i >= i_lo && i < i_hi)
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, a1_lane + __mul24(i, p1_lane), 0, 0);
         } else {
             const int y1 = y1a + i;
             if (writer && i >= 2 && i < 2 * oh2 + 2 && y1 < h1)
@@ -168,8 +180,10 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         // reflect level 1 (pixel -2 = 2, -1 = 1; pixel w1 = w1 - 2)
         uint32_t pm = (uint32_t)__builtin_amdgcn_mov_dpp((int)px.y, 0x111, 0xf, 0xf, true);
         uint32_t nx = (uint32_t)__builtin_amdgcn_mov_dpp((int)px.x, 0x101, 0xf, 0xf, true);
-        pm = left_edge ? __builtin_amdgcn_perm(px.x, px.x, 0x01020000u) : pm;
-        nx = right_edge ? (px.y >> 16) : nx;
+        if constexpr (LR) {
+            pm = left_edge ? __builtin_amdgcn_perm(px.x, px.x, 0x01020000u) : pm;
+            nx = right_edge ? (px.y >> 16) : nx;
+        }
         return hgroup4b<decltype(odd)::value>(px.x, px.y, pm, nx);
     };
 #pragma unroll
@@ -204,7 +218,6 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
                 // up1 <- dn1; below the last row dn1 <- up1, dn2 <- c (one row out) or up2 (two rows out)
                 const int yc = 2 * row2;
                 const bool top = yc == 0, b1 = yc + 2 == h1, b2 = yc + 1 == h1;
-                const bool rv = REV && rev;
                 const uint2 up2 = rv ? K4 : K0, up1 = rv ? K3 : K1, dn1 = rv ? K1 : K3, dn2 = rv ? K0 : K4;
                 E0.x = top ? dn2.x : up2.x; E0.y = top ? dn2.y : up2.y;
                 E1.x = top ? dn1.x : up1.x; E1.y = top ? dn1.y : up1.y;
@@ -212,7 +225,7 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
                 E4.x = b1 ? K2.x : (b2 ? up2.x : dn2.x); E4.y = b1 ? K2.y : (b2 ? up2.y : dn2.y);
             }
             const uint32_t o = vgroup4b(E0, E1, K2, E3, E4);
-            if constexpr (REV) { if (writer && row2 < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, row2 * pitch2 + g * 4, 0, 0); }
+            if constexpr (REV) { if (j >= j_lo && j < j_hi) __builtin_amdgcn_raw_buffer_store_b32(o, r2, a2_lane + __mul24(j, p2_lane), 0, 0); }
             else if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, 0);
             K0 = K2; K1 = K3; K2 = K4;
         }
@@ -228,12 +241,17 @@ __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPy
     const int tid = threadIdx.x, q = tid & 15;
     const int G = A0.sw >> 4, ncol = (G + TILE_GROUPS - 1) / TILE_GROUPS, oh2 = A0.pad;
     const int nstrip = (A1.dh + oh2 - 1) / oh2, units = nstrip * ncol;
+    // Unit order: column tile fastest -- the four units of a wave are (mostly) four ADJACENT COLUMN TILES of one strip, 896 contiguous
+    // bytes of every row.  Round 5 measured the other order (a wave = four consecutive strips of one column tile: strips that share
+    // halo rows in lockstep, and only the waves of the first / last column tile carrying the image-edge selects -- 43 instead of 50
+    // VALU per row): the pass alone 19.4-20.8 -> 21.6-22.1 us, the pipelined cold-pair step 46.5-47.5 -> 55.1-55.9 us.  Four
+    // 256-byte row segments 51 KB apart per wave instruction are the worse memory pattern by far (profiles/r05_experiments.md).
     const int u = blk * UNITS_PER_BLOCK + (tid >> 4);
     const bool uvalid = u < units;
     const int s = uvalid ? u / ncol : 0, c = uvalid ? u - s * ncol : 0;
     const int g = c * TILE_GROUPS - 1 + q;
     const bool lane_on = uvalid && g >= 0 && g < G;
-    const int oy2 = s * oh2;
+    const int oy2 = (uvalid ? s : 0) * oh2;
     const int y0 = 4 * oy2 - 6;
     // EDGE: some level-0 row of the strip is outside the image, or some level-1 row its level-2 rows use is
     const bool edge = uvalid && (y0 < 0 || y0 + 4 * oh2 + 8 > A0.sh - 1 || 2 * (oy2 + oh2 - 1) + 2 > A0.dh - 1);
@@ -243,8 +261,10 @@ __device__ __forceinline__ void pyr_roll2_body(const AgtPyrArgs& A0, const AgtPy
     const auto rc = __builtin_amdgcn_make_buffer_rsrc(COPY ? copy : out2, 0, COPY ? A0.sh * cpitch : 0, 0x00020000);
     if (__builtin_amdgcn_ballot_w64(uvalid) == 0) return;
     const bool rev = REV && (s & 1) && A0.rsv_ == 0;              // odd strips bottom-up
-    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true, COPY, REV>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
-    else pyr_roll2_rows<false, COPY, REV>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
+    const bool lr = __builtin_amdgcn_ballot_w64(lane_on && (g == 0 || g == G - 1)) != 0;
+    if (__builtin_amdgcn_ballot_w64(edge) != 0) pyr_roll2_rows<true, COPY, REV, true>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
+    else if (lr) pyr_roll2_rows<false, COPY, REV, true>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
+    else pyr_roll2_rows<false, COPY, REV, false>(A0, A1, rs, r1, r2, rc, cpitch, oy2, g, q, G, lane_on, rev);
 }
 
 __host__ __device__ inline int roll2_blocks(int sw, int h2, int oh2)

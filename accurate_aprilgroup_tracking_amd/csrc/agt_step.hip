@@ -352,34 +352,23 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
 // wave 0 alone with four points per lane -- the DLT initialisation is one-wave code.  A chained wait (not used by the split
 // launches of today, kept so the tables mean the same everywhere) is polled by one lane and its outcome shared through LDS.
 constexpr int PNP_COOP = agt_pnp::MAX_PPL;
-// (a real call: inlined next to the cooperative body the two solvers were register-allocated as one function and spilled)
-__device__ __noinline__ void pnp_one_wave_lds(const AgtPnpParams& P, int blk, agt_pnp::PnpShared& sh, const void* img, const uint8_t* mask,
-                                              double* so, int xf)
-{
-    agt_pnp::pnp_body<float, agt_pnp::MAX_PPL, agt_pnp::PnpNoHook, true>(P, blk, sh, img, mask, so, xf);
-}
 __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
 {
+    // Round 5: the solver bodies of the stand-alone pnp_coop_kernel / lk_pnp_coop_kernel -- tracker state in GLOBAL
+    // memory (P.track[blk]), read by every wave at the head of a frame and written by wave 0 at its end -- instead of the
+    // LDS-resident state of rounds 3-4 (154 VGPR spills, 1,600 B of scratch: one function with the one-wave solver, 512 registers
+    // were not enough).  A frame costs the stream 376 B of state traffic and two barriers more; 129 spills / 376 B of scratch are
+    // left (the cooperative loop ALONE needs 365 registers: it is the PPL = 4 one-wave body beside it, inside a loop, that does
+    // not fit -- two separate loops for the two solvers spill the same).  Frame k's pointers come straight from the kernel arguments.
     const int tid = (int)threadIdx.x, wave = tid >> 6;
-    if (S.pnp_nf > 1)
-        for (unsigned i = tid; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE * PNP_COOP)
-            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
-    if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(&sh.ts)[tid] = reinterpret_cast<const double*>(S.pnp.track + blk)[tid];
-    // Which body solves frame k (four cooperating waves from a guess / wave 0 alone without one) must be the SAME decision in
-    // every wave, and wave 0 rewrites ts.has_guess in its state update while the others may not have looked yet: wave 0
-    // latches the decision for frame k + 1 into coop[(k + 1) & 1] after its update of frame k; the slot read in frame k is not
-    // written again before the barrier at the top of frame k + 2, which every wave reaches only after its read.
-    __syncthreads();
-    if (tid == 0) *(volatile int*)&sh.coop[0] = sh.ts.has_guess;
     int late = 0;
+#pragma nounroll
     for (int k = 0; k < S.pnp_nf; k++) {
-        __syncthreads();            // tables and state are in LDS / wave 0 has finished frame k - 1's state update and latched coop[k & 1]
-        const void* img = T.pnp.img[0]; const uint8_t* mask = T.pnp.mask[0]; double* so = T.pnp.so[0];
-        const unsigned* wait = T.pnp.wait[0]; unsigned target = (unsigned)T.pnp.target[0];
-        if (k) {
-            img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
-            wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
-        }
+        // frame k - 1's state update (wave 0, global stores) is complete and visible to the other waves of the workgroup: the
+        // barrier orders it, the acquire below drops this CU's cached copy of the lines
+        __syncthreads();
+        const void* img = (const void*)KT->pnp.img[k]; const uint8_t* mask = KT->pnp.mask[k]; double* so = KT->pnp.so[k];
+        const unsigned* wait = KT->pnp.wait[k]; const unsigned target = (unsigned)KT->pnp.target[k];
         if (wait) {
             if (!late) {
                 if (tid == 0) {
@@ -395,20 +384,18 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
                 __syncthreads();
                 late = agt_uniform(*(volatile int*)&sh.late);
             }
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
         }
-        const bool guess = agt_uniform(*(volatile int*)&sh.coop[k & 1]) != 0 && S.pnp.enhance_ape;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        const bool guess = agt_uniform(__hip_atomic_load(&S.pnp.track[blk].has_guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 && S.pnp.enhance_ape;
+        __syncthreads();        // every wave has read the decision before wave 0 (alone, without a guess) may rewrite has_guess
         const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
-        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, true, PNP_COOP>(S.pnp, blk, sh, img, mask, so, xf);
-        else if (wave == 0) pnp_one_wave_lds(S.pnp, blk, sh, img, mask, so, xf);
-        if (wave == 0) {            // (wave 0 ran the state update of frame k in either body: its own LDS accesses are in program order)
-            agt_pnp::pnp_sync();
-            if (tid == 0) *(volatile int*)&sh.coop[(k + 1) & 1] = *(volatile int*)&sh.ts.has_guess;
+        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, false, PNP_COOP>(S.pnp, blk, sh, img, mask, so, xf);
+        else if (wave == 0) agt_pnp::pnp_body<float, agt_pnp::MAX_PPL>(S.pnp, blk, sh, img, mask, so, xf);
+        if (wave == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the state (and the record) of frame k are written before the next frame's barrier lets anybody read them
             if (S.pnp.host_seq && blk == 0 && k == S.pnp_nf - 1) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, tid == 0);
         }
     }
-    __syncthreads();
-    if (tid < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(S.pnp.track + blk)[tid] = reinterpret_cast<const double*>(&sh.ts)[tid];
 }
 
 // One heterogeneous launch: block ranges [LK | PnP | pyr stage 0 | stage 1 | ..].
@@ -592,13 +579,34 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 {
     constexpr int CPB = STEP_THREADS / (AGT_WAVE * NW);
     AgtStepParams P = S;
-    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift; P.lk.rsv_ = 0;
+    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift;
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) P.pyr[s].xshift = P.xshift;
     if (roles == AGT_STEP_PNP) {
         if (P.n_pnp <= 0) return hipSuccess;
-        if (P.pnp.n <= AGT_WAVE) hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T);
-        else hipLaunchKernelGGL(pnp_group_coop_kernel, dim3(P.n_pnp), dim3(AGT_WAVE * PNP_COOP), 0, stream, P, T);
-        return hipGetLastError();
+        if (P.pnp.n <= AGT_WAVE) { hipLaunchKernelGGL((pnp_group_kernel<1>), dim3(P.n_pnp), dim3(AGT_WAVE), 0, stream, P, T); return hipGetLastError(); }
+        // 64 < n <= 256 (the four-wave solver): the group's frames inside ONE launch (pnp_group_coop_kernel).  With the frame loop around
+        // both solver bodies the function needs more than its 512 registers: 154 VGPR spills / 1,600 B of scratch with the LDS-resident
+        // state of rounds 3-4, 129 / 376 B with the state in global memory (round 5, shipped).  The spill-free alternative -- the
+        // stand-alone pnp_coop_kernel once per frame (419 registers, no scratch) -- was measured and loses: 240 corners, 16 frames per
+        // group, us per step group / per frame: 2 streams 28.5 / 36.9, 4: 37.6 / 44.4, 8: 45.4 / 52.5 (the host enqueues one more launch
+        // per frame; profiles/r05_experiments.md).  Zero scratch needs the guess-less initialisation (DLT / homography, one-wave code
+        // with four points per lane) in cooperative form, so that no PPL = 4 body sits beside the cooperative one: open.
+        // The knobs build can take the per-frame path (AGT_PNP_COOP_GROUP=0).
+        bool group = true;
+#ifdef AGT_DEBUG_KNOBS
+        { static const int f = [] { const char* e = getenv("AGT_PNP_COOP_GROUP"); return e ? atoi(e) : 1; }(); group = f != 0; }
+#endif
+        if (group) { hipLaunchKernelGGL(pnp_group_coop_kernel, dim3(P.n_pnp), dim3(AGT_WAVE * PNP_COOP), 0, stream, P, T); return hipGetLastError(); }
+        for (int k = 0; k < P.pnp_nf; k++) {
+            if (T.pnp.wait[k]) return hipErrorInvalidValue;          // (split launches are ordered by events: no in-kernel wait to honour)
+            AgtPnpParams q = P.pnp;
+            q.img = T.pnp.img[k]; q.mask = T.pnp.mask[k]; q.state_out = T.pnp.so[k];
+            q.host_seq = (k == P.pnp_nf - 1) ? P.pnp.host_seq : nullptr;
+            q.host_seq_base = P.pnp.host_seq_base + (unsigned long long)k;
+            const hipError_t e = agt_launch_pnp(stream, q, P.n_pnp);
+            if (e != hipSuccess) return e;
+        }
+        return hipSuccess;
     }
     if (!(roles & AGT_STEP_PNP)) { P.n_pnp = 0; P.pnp_nf = 0; }
     if (!(roles & AGT_STEP_LK)) { P.n_lk = 0; P.lk_nf = 0; }
@@ -665,9 +673,19 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     // launch is only used while <= 256 corners are in flight (agt_step_fits).  Round 2 also shipped an OCC = 2 build for 257-2048
     // corners (registers capped at 256: ~500 VGPR spills, 1 KB of scratch in the PnP role); round 3's split mode with the LK role
     // as one group launch beats it at every stream count (profiles/r03_stream_sweep.txt), so it is gone.
+#ifndef AGT_DEBUG_KNOBS
+    // (the fused launch needs <= 256 corners in flight -- agt_step_fits -- and <= 1024 corners are always tracked by four waves each
+    // -- agt_lk_wide --, so step_kernel<21, 1, *> was unreachable object code: 476 VGPRs, scratch.  Only the knobs build, whose
+    // AGT_LK_WIDE_MAX can force the one-wave body on small batches, still instantiates it: VERDICT r4 #4)
+    if constexpr (NW == 1) return hipErrorInvalidValue;
+    else {
+#endif
     if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
     return hipGetLastError();
+#ifndef AGT_DEBUG_KNOBS
+    }
+#endif
 }
 
 }  // namespace
@@ -702,7 +720,7 @@ hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, cons
     if (!chain) { P.n_pnp = 0; P.pnp_nf = 0; }
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
     const long corners = (long)P.lk.n * P.lk_B;
-    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift; P.lk.rsv_ = 0;
+    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift;
     const unsigned grid8 = agt_xcd_grid(corners, P.xshift);
     P.n_lk = (int)grid8;
     agt_dense::DenseParams D;
