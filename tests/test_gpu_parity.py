@@ -211,6 +211,34 @@ def test_lk_edge_cases_single_wave_path(torch_cuda, cvh, oracle, seq640):
                 _assert_lk_equal(o, (nx[bb].reshape(-1, 1, 2), st[bb].reshape(-1, 1), er[bb].reshape(-1, 1)))
 
 
+def test_lk_occupancy_cap_changes_no_bit(torch_cuda, cvh, oracle, seq640):
+    """agt_lk_occupancy (round 5: fewer resident LK waves per SIMD for contexts that share the device): the cap is enforced with
+    extra LDS per workgroup and must not change a bit of the one-wave kernel's output -- caps 1, 2, 3 against no cap and the oracle"""
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    torch = torch_cuda
+    a, b = seq640.frame(0), seq640.frame(1)
+    h, w = a.shape
+    pts = seq640.corners(0)
+    n = pts.shape[0]
+    B = 1024 // n + 3
+    fa = torch.from_numpy(np.stack([a] * B)).cuda().contiguous(); fb = torch.from_numpy(np.stack([b] * B)).cuda().contiguous()
+    pg = torch.from_numpy(np.stack([pts] * B)).cuda().contiguous()
+    ctx = cvh.Context(w, h, max_level=2, max_points=n, max_streams=B)
+    ctx.pyramid_build(0, fa); ctx.pyramid_build(1, fb)
+    o = oracle.calcOpticalFlowPyrLK(a, b, pts, maxLevel=2)
+    ref = None
+    for cap in (0, 1, 2, 3, 0):
+        H.check(ctx.L.agt_lk_occupancy(ctx.h, cap), "agt_lk_occupancy")
+        nx, st, er = ctx.lk_track(0, 1, pg, None)
+        got = (nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy())
+        _assert_lk_equal(o, (got[0][B - 1].reshape(-1, 1, 2), got[1][B - 1].reshape(-1, 1), got[2][B - 1].reshape(-1, 1)))
+        if ref is None:
+            ref = got
+        else:
+            assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(ref, got)), "cap %d" % cap
+    assert ctx.L.agt_lk_occupancy(ctx.h, -1) == -1 and ctx.L.agt_lk_occupancy(ctx.h, 9) == -1
+
+
 def test_project_points(cvh, oracle, seq640_dist):
     s = seq640_dist
     for dt in (np.float64, np.float32):
