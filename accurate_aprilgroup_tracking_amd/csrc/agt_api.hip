@@ -466,6 +466,7 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     double eps = (crit_type & AGT_TERM_EPS) ? (crit_eps < 0. ? 0. : crit_eps > 10. ? 10. : crit_eps) : 0.01;
     p.eps2 = eps * eps;
     p.flags = flags;
+    p.lds_pad = c->lk_lds_pad;
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
     if (b0) {

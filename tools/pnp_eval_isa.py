@@ -101,6 +101,33 @@ def dests_sources(op, ops):
     return d, srcs
 
 
+def hot_path(lines):
+    """the lines of a region without its COLD block: a forward conditional branch whose skipped span holds v_trig_preop_f64 -- the
+    inline copy of the library's general-argument sincos (Payne-Hanek reduction), entered for rotation angles >= 2^20 only
+    (agt_device.h agt_sincos) -- is assumed taken"""
+    addr = []
+    for ln in lines:
+        m = re.search(r"//\s*([0-9A-Fa-f]{6,16}):", ln)
+        addr.append(int(m.group(1), 16) if m else None)
+    out, i = [], 0
+    while i < len(lines):
+        ln = lines[i]
+        out.append(ln)
+        m = re.match(r"\s*s_cbranch_\w+\s+\d+\s*//.*<.*\+0x([0-9a-fA-F]+)>", ln)
+        if m and addr[i] is not None:
+            tgt_off = int(m.group(1), 16)
+            # target line: first line at or past the target offset (offsets are relative to the kernel's first instruction)
+            base = hot_path.base
+            j = i + 1
+            while j < len(lines) and (addr[j] is None or addr[j] - base < tgt_off):
+                j += 1
+            if j <= len(lines) and any("v_trig_preop_f64" in x for x in lines[i + 1:j]):
+                i = j
+                continue
+        i += 1
+    return out
+
+
 def region_stats(lines):
     counts, chain, valu, n = {}, {}, 0, 0
     longest = 0
@@ -154,6 +181,12 @@ def main():
         except ValueError:
             continue
         runs.append((a, b, c, d))
+    m0 = None
+    for ln in body:
+        m0 = re.search(r"//\s*([0-9A-Fa-f]{6,16}):", ln)
+        if m0:
+            break
+    hot_path.base = int(m0.group(1), 16) if m0 else 0
     print("# One Levenberg-Marquardt evaluation of the pose solver, instruction by instruction (`pnp_kernel<float, 1>`, diagnostic library)\n")
     print("`tools/pnp_eval_isa.py`: the code between the in-kernel stamps 48 | 49 | 50 | 51 of `agt_pnp_body.h evaluate_t` (mode 2: the")
     print("evaluation that also leaves J^T J / J^T e for the next iteration).  One point per lane, 48 of 64 lanes active, one wave per problem.")
@@ -165,9 +198,13 @@ def main():
         print("|---|---|---|---|" + "---|" * len(CLASSES))
         tot = [0, 0, 0]
         for nm, (lo, hi) in zip(names, ((a, b), (b, c), (c, d))):
-            n, valu, counts, longest = region_stats(body[lo + 1:hi])
+            reg = body[lo + 1:hi]
+            hot = hot_path(reg)
+            n, valu, counts, longest = region_stats(hot)
             tot[0] += n; tot[1] += valu; tot[2] += longest
-            print("| %s | %d | %d | %d | " % (nm, n, valu, longest) + " | ".join(str(counts.get(cn, 0)) for cn, _ in CLASSES) + " |")
+            cold = len([1 for x in reg if parse(x)]) - n
+            print("| %s%s | %d | %d | %d | " % (nm, (" -- %d more instructions in cold blocks, not counted" % cold) if cold else "", n, valu, longest) +
+                  " | ".join(str(counts.get(cn, 0)) for cn, _ in CLASSES) + " |")
         print("| **whole evaluation** | %d | %d | %d (sum of the parts: they are sequential) | |\n" % tuple(tot))
 
 
