@@ -36,6 +36,8 @@ struct agt_ctx {
     int ring;                                // allocated ring entries: >= (L + 2) * group
     float* corners[AGT_RING_MAX];            // [B][n][2]
     uint8_t* status[AGT_RING_MAX];           // [B][n]
+    uint8_t* lk_iters[AGT_RING_MAX];         // [B][n] iterations every corner took in the frame of the ring entry (hybrid LK launch: a hint, never a result)
+    int lk_slow_thr;                         // agt_lk_hybrid: corners at or above it in the previous frame are tracked by four waves (0 = off)
     double* so_ring[AGT_RING_MAX];           // caller's state_out of the frames in flight
     int pipeline;                            // 1 = software-pipelined fused step (agt_step.hip)
     int group;                               // frames per fused launch (1..AGT_MAX_GROUP)
@@ -132,6 +134,8 @@ int ensure_ring(agt_ctx* c, int want)
         ok = ok && hipMalloc((void**)&c->corners[s], B * N * 2 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void**)&c->status[s], B * N) == hipSuccess;
         ok = ok && hipMemsetAsync(c->status[s], 1, B * N, c->stream) == hipSuccess;
+        ok = ok && hipMalloc((void**)&c->lk_iters[s], B * N) == hipSuccess;
+        ok = ok && hipMemsetAsync(c->lk_iters[s], 0, B * N, c->stream) == hipSuccess;
         if (!ok) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }      // partial entry is freed by agt_destroy
         c->ring = s + 1;
     }
@@ -288,6 +292,9 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
+#ifdef AGT_DEBUG_KNOBS
+    { const char* e = getenv("AGT_LK_HYBRID"); if (e) c->lk_slow_thr = atoi(e); }
+#endif
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: fixed iteration counts (AGT_LK_MAX_COUNT=n AGT_LK_EPS=0) separate the per-iteration
     // cost of the LK role from its per-frame cost
     { const char* e = getenv("AGT_LK_MAX_COUNT"); if (e) c->lk_max_count = atoi(e); }
@@ -305,6 +312,7 @@ int agt_destroy(agt_ctx* c)
         for (int l = 1; l < AGT_MAX_LEVELS; l++) if (c->lmem[s][l]) (void)hipFree(c->lmem[s][l]);
         if (c->corners[s]) (void)hipFree(c->corners[s]);
         if (c->status[s]) (void)hipFree(c->status[s]);
+        if (c->lk_iters[s]) (void)hipFree(c->lk_iters[s]);
     }
     if (c->ms_ready) {
         for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->ms_stream[i]);
@@ -447,7 +455,7 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
                        int n, int B, int crit_type, int crit_max_count, double crit_eps,
-                       int flags, double min_eig_threshold, int b0 = 0, int waves = 0)
+                       int flags, double min_eig_threshold, int b0 = 0, int waves = 0, bool hybrid = false)
 {
     // b0: first stream of the launch (streams b0 .. b0 + B - 1 of the slots and of the point arrays); waves: see agt_launch_lk
     if (!c || !d_prev_pts || !d_next_pts || !d_status) return AGT_ERR_ARG;
@@ -474,6 +482,18 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
         p.prev_pts += (size_t)b0 * n * 2; p.next_pts += (size_t)b0 * n * 2; p.status += (size_t)b0 * n;
         if (p.prev_status) p.prev_status += (size_t)b0 * n;
         if (p.err) p.err += (size_t)b0 * n;
+    }
+    // HYBRID launch, MEASURED AND NOT SHIPPED (round 5; knobs build: AGT_LK_HYBRID=<iterations>): corners that took >= that
+    // many iterations in the previous frame tracked by four waves, the rest by one, in one launch of two workgroup roles
+    // (agt_lk.hip lk_hybrid_kernel).  Bit-identical records; 64 streams: 40.2 us per step without, 49.5 with the launch form alone
+    // (threshold 200: nobody on four waves), 49.8 / 51.9 / 61.6 / 75.2 at thresholds 14 / 12 / 10 / 8 -- the chip is as much
+    // throughput- as latency-bound there, and a four-wave corner costs 3 x the wave-time of a one-wave corner (profiles/r05_experiments.md).
+    if (hybrid && c->lk_slow_thr > 0 && c->cfg.win == 21 && c->eff_max_level < 3 && !p.err && flags == 0 &&
+        (size_t)(b0 + B) * n <= (size_t)c->cfg.max_streams * c->cfg.max_points) {
+        p.iters_prev = c->lk_iters[prev_slot] + (size_t)b0 * n; p.iters_out = c->lk_iters[next_slot] + (size_t)b0 * n;
+        p.slow_thr = c->lk_slow_thr;
+        hipError_t e = agt_launch_lk_hybrid(stream, p, B);
+        return e == hipSuccess ? AGT_OK : hip_fail(c, e);
     }
     hipError_t e = agt_launch_lk(stream, p, c->cfg.win, B, c->cfg.win == 21 ? waves : 0);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
@@ -554,6 +574,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
     for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
+    for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->lk_iters[s], 0, (size_t)B * n, c->stream);
     // arrival counters of the chained launches: a run counts n corners per stream-frame, the next run may have other n / B
     if (e == hipSuccess) e = hipMemsetAsync(c->lk_done, 0, (size_t)AGT_RING_MAX * c->cfg.max_streams * sizeof(unsigned), c->stream);
     memset(c->lk_target, 0, sizeof(c->lk_target));
@@ -615,6 +636,7 @@ static void ring_move(agt_ctx* c, long f, int old_ring, int new_ring)
     for (int l = 1; l < AGT_MAX_LEVELS; l++) { uint8_t* t = c->lmem[a][l]; c->lmem[a][l] = c->lmem[b][l]; c->lmem[b][l] = t; }
     { float* t = c->corners[a]; c->corners[a] = c->corners[b]; c->corners[b] = t; }
     { uint8_t* t = c->status[a]; c->status[a] = c->status[b]; c->status[b] = t; }
+    { uint8_t* t = c->lk_iters[a]; c->lk_iters[a] = c->lk_iters[b]; c->lk_iters[b] = t; }
     c->l0_ptr[b] = c->l0_ptr[a]; c->l0_pitch[b] = c->l0_pitch[a]; c->l0_bstride[b] = c->l0_bstride[a];
     c->built_B[b] = c->built_B[a]; c->built_B[a] = 0;
 }
@@ -743,7 +765,9 @@ static int launch_group(agt_ctx* c, int B)
             A1.B = B; A1.src = nullptr; A1.dst = nullptr;
             uintptr_t d2_align = 0;
             for (long k = 0; k < cnt; k++) d2_align |= (uintptr_t)c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
-            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (int)cnt);
+            // (fused step: agt_step_fits, <= 256 corners in flight -- its kernel carries the tiled two-level pass only: plan as ONE frame, which
+            // keeps the launch below the rolling form's 16 images)
+            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, agt_step_fits(c->trk_n, B) ? 1 : (int)cnt);
             if (!fused && A0.pad != 0 && c->n_stage[1] == c->n_stage[0]) fused = true;       // big batch, rolling form, no backlog
             if (fused) {
                 A = A0; S.pyr[1] = A1;
@@ -906,11 +930,13 @@ static int launch_group(agt_ctx* c, int B)
         for (int k = 1; k <= S.lk_nf && !lk_group; k++) {
             const int ps = (int)((lk_f0 + k - 1) % M), sl = (int)((lk_f0 + k) % M);
             // (waves = 1: a half is sized by the whole batch's kernel choice, not by its own corner count)
+            // (hybrid: only the one-wave launches of big batches -- a batch that the four-wave kernel takes whole has nothing to gain)
+            const bool hyb = !agt_lk_wide(c->trk_n, B);
             rc = lk_track_on(c, sL, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B1,
-                             AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, 0, two ? 1 : 0);
+                             AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, 0, two ? 1 : 0, hyb);
             if (rc == AGT_OK && two)
                 rc = lk_track_on(c, sL2, ps, sl, c->corners[ps], c->status[ps], c->corners[sl], c->status[sl], nullptr, c->trk_n, B - B1,
-                                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, B1, 1);
+                                 AGT_TERM_COUNT | AGT_TERM_EPS, c->lk_max_count, c->lk_eps, 0, c->lk_min_eig, B1, 1, hyb);
             if (rc) return rc;
         }
         e = hipEventRecord(evL[slot_ev], sL);

@@ -59,6 +59,14 @@ struct AgtLkParams {
     float* err;               // [B][n] or null
     int xshift;               // XCD-aware corner order (agt_xcd_order); set by the launchers
     int lds_pad;              // host side only: extra dynamic LDS per one-wave workgroup = an occupancy cap (agt_lk_occupancy); 0 = none
+    // HYBRID launch of big batches (round 5, agt_lk.hip lk_hybrid_kernel): a corner that took >= slow_thr iterations (all levels) in the
+    // PREVIOUS frame is tracked by FOUR waves (0.5 us per iteration, 5.8 us fixed), the others by one wave each (0.8 / 6.8 us) -- a
+    // per-frame launch lasts as long as its slowest corner, and the corners that iterate long do so in every frame.  The two bodies
+    // compute the same bits, so the choice never shows in the results.
+    uint8_t* iters_out;       // [B][n] iterations of this frame per corner (saturated at 255), or null
+    const uint8_t* iters_prev;    // [B][n] of the previous frame, or null (= every corner on one wave)
+    int slow_thr;             // 0 = no hybrid launch
+    int rsv2_;
 };
 
 struct AgtCameraHost {
@@ -194,6 +202,7 @@ hipError_t agt_launch_pyr_down(hipStream_t stream, const uint8_t* src, int sw, i
                                uint8_t* dst, long dpitch, long dbatch, int B);
 // waves: 0 = by batch size (agt_lk_wide), 1 / 4 = that many waves per corner (win 21 only)
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p, int win, int B, int waves = 0);
+hipError_t agt_launch_lk_hybrid(hipStream_t stream, const AgtLkParams& p, int B);      // win 21, <= 3 levels, p.iters_prev / slow_thr set (agt_lk.hip)
 // ride != null (two argument blocks of agt_pyr2_args): the two-level pyramid pass of another frame as extra workgroups of the
 // launch; only where agt_pnp_can_ride(n) (the four-wave kernel of n > 64)
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B, const AgtPyrArgs* ride = nullptr);

@@ -35,6 +35,52 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     agt_lk::lk_body<WIN, NW, NLEV>(&P, bX, bY, lds, io, ox, oy, ost);
 }
 
+#ifdef AGT_DEBUG_KNOBS      // measured and not shipped: agt_api.hip lk_track_on
+// HYBRID launch (round 5, win 21, big batches): 256-thread workgroups in two roles.  Workgroups [0, n4) are the FOUR-WAVE role, one
+// per corner (XCD-aware order): the corner is tracked here if it took >= slow_thr iterations in the previous frame, else the
+// workgroup exits at once.  Workgroups [n4, n4 + nquad) are the ONE-WAVE role: wave w tracks corner 4 q + w (q in XCD-aware order:
+// the four corners of a tag share a workgroup, their overlapping tiles one CU's L1) unless the four-wave role has it.  The slow
+// corners are dispatched first -- they are the launch's critical path.  Register budget of four waves per SIMD (the one-wave
+// body's 128; the four-wave bodies need 67).
+template <int NLEV>
+__global__ __launch_bounds__(AGT_WAVE * 4) __attribute__((amdgpu_waves_per_eu(4))) void lk_hybrid_kernel(const AgtLkParams P, const int total, const int n4,
+                                                                                                           const int nquad, const int per_wave_lds)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int bid = (int)blockIdx.x;
+    const bool four = bid < n4;
+    int cidx;
+    uint8_t* my = lds;
+    if (four) cidx = agt_xcd_order(bid, n4, P.xshift);
+    else {
+        const int wave = agt_uniform((int)threadIdx.x >> 6);          // (scalar: the wave's LDS base stays out of the vector registers)
+        cidx = agt_xcd_order(bid - n4, nquad, P.xshift) * 4 + wave;
+        my = lds + wave * per_wave_lds;
+    }
+    if (cidx >= total) return;
+    const float ppx = P.prev_pts[(long)cidx * 2], ppy = P.prev_pts[(long)cidx * 2 + 1];
+    const int pst = P.prev_status ? P.prev_status[cidx] : 1;
+    const bool rs = agt_uniform((int)(pst != 0 && !(P.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h))) != 0;
+    // four waves only for corners whose windows stay inside the image (the row-segment body); a slow corner at the image border keeps
+    // its one wave and the general body -- three tracker bodies in this kernel instead of four (with four, 14 VGPRs spilled)
+    const bool slow = rs && agt_uniform((int)(P.iters_prev[cidx] >= P.slow_thr)) != 0;
+    if (slow != four) return;
+    const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
+    agt_lk::LkFrameIo<NLEV> io;
+    io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
+    io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
+    io.iters_out = P.iters_out;
+    float ox, oy; int ost;
+    if (four) {
+        agt_lk::lk_body_rs<4, NLEV>(&P, bX, bY, my, io, ppx, ppy, ox, oy, ost);
+    } else {
+        if (rs) agt_lk::lk_body_rs<1, NLEV>(&P, bX, bY, my, io, ppx, ppy, ox, oy, ost);
+        else agt_lk::lk_body<21, 1, NLEV>(&P, bX, bY, my, io, ox, oy, ost);
+    }
+}
+
+#endif
+
 template <int WIN, int NW>
 hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p_in, int B)
 {
@@ -72,6 +118,25 @@ bool agt_lk_wide(int n, int B)
 #endif
     return (long)n * B <= cap;
 }
+
+#ifdef AGT_DEBUG_KNOBS
+hipError_t agt_launch_lk_hybrid(hipStream_t stream, const AgtLkParams& p_in, int B)
+{
+    AgtLkParams p = p_in;
+    if (!p.iters_prev || p.slow_thr <= 0 || p.max_level >= 3 || p.err) return hipErrorInvalidValue;
+    p.xshift = agt_chip_current().xshift;
+    const long total = (long)p.n * B;
+    if (total <= 0 || total > (1L << 28)) return hipErrorInvalidValue;
+    const size_t lds1 = agt_lk::lk_lds_bytes<21, 1>(p.max_level + 1), lds4 = agt_lk::lk_lds_bytes<21, 4>(p.max_level + 1);
+    const size_t per = (lds1 + 15) & ~(size_t)15;
+    size_t lds = 4 * per > lds4 ? 4 * per : lds4;
+    const unsigned n4 = agt_xcd_grid(total, p.xshift), nquad = agt_xcd_grid((total + 3) / 4, p.xshift);
+    hipLaunchKernelGGL((lk_hybrid_kernel<3>), dim3(n4 + nquad), dim3(AGT_WAVE * 4), lds, stream, p, (int)total, (int)n4, (int)nquad, (int)per);
+    return hipGetLastError();
+}
+#else
+hipError_t agt_launch_lk_hybrid(hipStream_t, const AgtLkParams&, int) { return hipErrorInvalidValue; }
+#endif
 
 hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, int B, int waves)
 {

@@ -266,6 +266,7 @@ struct LkFrameIo {
     const float* prev_pts; float* next_pts; uint8_t* status; float* err;
     bool have_pos; float px, py; int pst;       // pst: the corner's status after the previous frame (with have_pos)
     unsigned* done = nullptr;                   // chained launch (agt_step.hip): arrival counters of this frame, [B]; see lk_publish
+    uint8_t* iters_out = nullptr;               // stand-alone launches of big batches: iterations the corner took, [B][n] (AgtLkParams::iters_out)
 };
 
 // The frame's result for one corner (called by one lane).  In a chained launch the PnP role of the SAME launch picks the
@@ -335,6 +336,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     if (NW == 4 && tid < 24) reinterpret_cast<int*>(slots)[tid] = 0;       // block_sum_exact's accumulators (a barrier precedes the first sum)
     const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
     const long pidx = (long)b * P->n + pt;
+    int nit = 0;                    // iterations over all levels (only kept where io.iters_out is set)
 
     // window pixels of this thread, as byte / element offsets into the three LDS tiles (computed once;
     // threads without a k-th pixel point at offset 0 and are masked arithmetically, not by branches)
@@ -515,6 +517,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
             }
         };
         for (int j = 0; j < P->max_count; j++) {
+            nit++;
             if (j == 1) STAMP(39);
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
@@ -569,6 +572,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
 
     STAMP(3);
     if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
+    if (tid == 0 && io.iters_out) io.iters_out[pidx] = (uint8_t)(nit > 255 ? 255 : nit);
     ox = outx; oy = outy; ost = st;
 }
 

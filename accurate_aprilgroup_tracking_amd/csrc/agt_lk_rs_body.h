@@ -180,6 +180,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     long long* slots = reinterpret_cast<long long*>(lds + (P->max_level + 1) * C::LEVEL_LDS + ((C::DW * C::DW + 3) & ~3) * sizeof(int));
     if (NW == 4 && tid < 24) reinterpret_cast<int*>(slots)[tid] = 0;       // block_sum_exact's accumulators (a barrier precedes the first sum)
     int phase = 0;
+    int nit = 0;                    // iterations over all levels (only kept where io.iters_out is set)
 
     float outx = 0.f, outy = 0.f;
     if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
@@ -497,6 +498,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         set_box();
         int slow = agt_uniform((int)!(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1));
         for (int j = 0; j < P->max_count; j++) {
+            nit++;
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
             if (slow) {
                 if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
@@ -571,6 +573,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
 
     STAMP(3);
     if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
+    if (tid == 0 && io.iters_out) io.iters_out[pidx] = (uint8_t)(nit > 255 ? 255 : nit);
     ox = outx; oy = outy; ost = st;
 }
 

@@ -199,6 +199,9 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
 // ---- pyramid role: workgroup `blk` of the role (all stages concatenated); `base` = launch-wide index of the role's first
 // workgroup (decides which XCD a workgroup sits on).  Everything is read from the kernel-argument segment (scalar loads):
 // a reference to the by-value argument would make the compiler copy the whole structure to scratch.
+// ROLL2: the register-rolling two-level pass may be planned (split pipeline: pyr_group_kernel); the fused step kernel is planned with
+// the tiled two-level pass only (agt_api.hip launch_group) and does not carry the rolling body -- it sits on the edge of its registers
+template <bool ROLL2>
 __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int base, uint8_t* lds)
 {
 #pragma unroll
@@ -227,7 +230,7 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
                 A1.spitch = KS->pyr[1].spitch; A1.sbatch = KS->pyr[1].sbatch; A1.dpitch = KS->pyr[1].dpitch; A1.dbatch = KS->pyr[1].dbatch;
                 A1.sw = KS->pyr[1].sw; A1.sh = KS->pyr[1].sh; A1.dw = KS->pyr[1].dw; A1.dh = KS->pyr[1].dh;
                 A1.gx = A.gx; A1.gy = A.gy; A1.B = A.B;
-                if (A.pad) {      // register-rolling form, alternating strip directions (agt_pyramid.hip agt_pyr2_plan): bx = workgroup of the image, no LDS
+                if (ROLL2 && A.pad) {      // register-rolling form, alternating strip directions (agt_pyramid.hip agt_pyr2_plan): bx = workgroup of the image, no LDS
                     A.rsv_ = KS->pyr[0].rsv_;
                     agt_pyr4::pyr_roll2_body(A, A1, bx, KT->pyr_src[0][fr] + (long)st * A.sbatch, KT->pyr_dst[0][fr] + (long)st * A.dbatch,
                                              KT->pyr_dst[1][fr] + (long)st * A1.dbatch);
@@ -435,7 +438,7 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
         return;
     }
     if (PNP) blk -= S.n_pnp;
-    pyr_role(KS, KT, blk, (PNP ? S.n_pnp : 0) + S.n_lk, lds);
+    pyr_role<false>(KS, KT, blk, (PNP ? S.n_pnp : 0) + S.n_lk, lds);
     SSTAMP_MAX(5);
 }
 
@@ -554,7 +557,7 @@ __global__ __launch_bounds__(AGT_WAVE * 4) void lk_pnp_coop_kernel(const AgtStep
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    pyr_role(kernarg_params(), kernarg_tables(), blockIdx.x, 0, lds);
+    pyr_role<true>(kernarg_params(), kernarg_tables(), blockIdx.x, 0, lds);
 }
 
 // PPL: points per lane (n <= 64 * PPL)
