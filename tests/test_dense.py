@@ -300,34 +300,52 @@ def test_dense_clip_submission_equals_single_calls(oracle, n_tags, reseed):
 
 
 @pytest.mark.gpu
-def test_dense_clip_with_rejected_and_lost_frames_equals_single_calls(oracle):
-    """The clip form's launches (include/agt_hip.h agt_track_frames_dense: final update + re-seed as the next LK launch's prologue, LK and
-    the four-wave PnP in one chained launch) on two DIFFERENT streams of which one sees a frame from elsewhere in its sequence (the
-    gate rejects: done word set, no refinement, no re-seed) and later a blank frame (LK loses every corner for good): records,
-    corner sets and LK status bitwise those of agt_track_frame_dense called frame by frame, whatever the clip cuts."""
+@pytest.mark.parametrize("case", [("B2_240_reseed_prologue", 60, 2), ("B2_96_chained", 24, 2), ("B2_120_chained", 30, 2), ("B1_240_chained", 60, 1)],
+                         ids=lambda c: c[0])
+def test_dense_clip_with_rejected_and_lost_frames_equals_single_calls(oracle, case):
+    """The clip form's launches (include/agt_hip.h agt_track_frames_dense) against agt_track_frame_dense called frame by frame, on
+    streams of which one sees a frame of another sequence (the gate rejects: done word set, no refinement, no re-seed)
+    and later a blank frame (LK loses every corner for good): records, corner sets and LK status bitwise equal, whatever the cuts.
+    WHICH launch form a case reaches (the 240-corner B = 2 case of round 4 never reached the chained kernel --
+    2 x 240 + 2 workgroups do not fit the chip at one per CU):
+      B2_240  lk_reseed_kernel: the previous frame's final update + re-seed as the LK launch's prologue, PnP a launch of its own;
+      B2_96 / B2_120 / B1_240  lk_pnp_coop_kernel: LK and the four-wave PnP CHAINED in one launch (64 < n <= 256 corners and
+              n B + B <= 256 workgroups) -- per-stream indexing of the solver workgroups (b = blockIdx.x - n_lk, wait[0] + b,
+              track[b], the riding pyramid tiles' stream index) with two DISTINCT streams, gate-rejected frames and frames in
+              which every corner is lost, in the chained kernel itself."""
+    import ctypes as C
     import torch
     from accurate_aprilgroup_tracking_amd import hiplib as H
     from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
-    seqs = [syn.Sequence(1280, 720, n_tags=60, n_frames=8, seed=8 + i, supersample=2, group_seed=8) for i in range(2)]
+    _, n_tags, B = case
+    seqs = [syn.Sequence(1280, 720, n_tags=n_tags, n_frames=8, seed=8 + i, supersample=2, group_seed=8) for i in range(2)]
     s = seqs[0]
+    n = s.obj.shape[0]
     mx = syn.model_samples(s.group, 16)
     T = _template(s, mx, 0)
     fr = [sq.frames() for sq in seqs]
     order0 = [1, 2, 3, 4, 5, 6, 7, 6, 5, 4]
-    order1 = [1, 2, 7, 3, 4, 5, -1, 6, 7, 6]          # stream 1: frame 7 after frame 2 (a jump), later a blank frame
+    order1 = [1, 2, 7, 3, 4, 5, -1, 6, 7, 6]          # the disturbed stream: entry 2 is replaced below, entry 6 is a blank frame
     K = len(order0)
     blank = np.full((720, 1280), 128, np.uint8)
-    clip = np.stack([np.stack([fr[0][order0[k]], blank if order1[k] < 0 else fr[1][order1[k]]]) for k in range(K)])
-    clip = torch.from_numpy(clip).cuda().contiguous()                    # [K, 2, H, W]
-    first = torch.from_numpy(np.stack([fr[0][0], fr[1][0]])).cuda().contiguous()
-    c0 = torch.from_numpy(np.stack([seqs[0].corners(0), seqs[1].corners(0)])).cuda().contiguous()
+    dist_frames = [blank if order1[k] < 0 else fr[1][order1[k]] for k in range(K)]
+    dist_frames[2] = fr[0][4]                         # a frame of the OTHER sequence: LK lands ~9 px off any pose of the model (CPU oracle: mean error 8.6-9.7 px), the gate rejects
+    if B == 2:
+        clip = np.stack([np.stack([fr[0][order0[k]], dist_frames[k]]) for k in range(K)])
+        first = np.stack([fr[0][0], fr[1][0]]); c0 = np.stack([seqs[0].corners(0), seqs[1].corners(0)])
+    else:
+        clip = np.stack([dist_frames[k][None] for k in range(K)])
+        first = fr[1][0][None]; c0 = seqs[1].corners(0)[None]
+    clip = torch.from_numpy(clip).cuda().contiguous()                    # [K, B, H, W]
+    first = torch.from_numpy(first).cuda().contiguous()
+    c0 = torch.from_numpy(c0).cuda().contiguous()
     outs = []
     for cuts in (None, [K], [3, 1, 6], [2, 0, 5, 0, 1]):
-        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=2)
+        trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
         trk.dense_model(torch.from_numpy(mx).cuda(), torch.from_numpy(T).cuda(), iters=3, photo_weight=0.05, reseed=True)
         trk.reset(first, c0)
         so = trk.new_state_buffer(K)
-        do = torch.zeros((K, 2, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
+        do = torch.zeros((K, B, H.DENSE_STRIDE), dtype=torch.float64, device="cuda")
         if cuts is None:
             for k in range(K):
                 trk.step_dense(clip[k], so[k], do[k])
@@ -340,15 +358,19 @@ def test_dense_clip_with_rejected_and_lost_frames_equals_single_calls(oracle):
                     trk.step_many_dense(clip[k:k + m], so[k:k + m], do[k:k + m]); k += m
             assert k == K
         torch.cuda.synchronize()
-        import ctypes as C
         cp, sp = trk.corners()                                           # device addresses of the newest frame's corner set / LK status
-        pts, status = np.zeros((2, 240, 2), np.float32), np.zeros((2, 240), np.uint8)
+        pts, status = np.zeros((B, n, 2), np.float32), np.zeros((B, n), np.uint8)
         H.check(trk.ctx.L.agt_download(trk.ctx.h, pts.ctypes.data_as(C.c_void_p), C.c_void_p(cp), pts.nbytes), "agt_download")
         H.check(trk.ctx.L.agt_download(trk.ctx.h, status.ctypes.data_as(C.c_void_p), C.c_void_p(sp), status.nbytes), "agt_download")
         outs.append((so.cpu().numpy().copy(), do.cpu().numpy().copy(), pts, status))
     st0, dn0, p0, u0 = outs[0]
-    assert st0[:, 0, H.ST_OK].all() and (dn0[:, 0, H.DN_REFINED] == 1.0).all()              # the undisturbed stream
-    assert not st0[6:, 1, H.ST_OK].any() and (dn0[6:, 1, H.DN_REFINED] == 0.0).all()          # from the blank frame on: nothing tracked, nothing refined
+    d = B - 1                                                            # index of the disturbed stream
+    if B == 2:
+        assert st0[:, 0, H.ST_OK].all() and (dn0[:, 0, H.DN_REFINED] == 1.0).all()          # the undisturbed stream
+    assert st0[:2, d, H.ST_OK].all() and not st0[2, d, H.ST_OK], "the jump frame's pose is rejected by the gate"
+    assert dn0[2, d, H.DN_REFINED] == 0.0
+    assert not st0[6:, d, H.ST_OK].any() and (dn0[6:, d, H.DN_REFINED] == 0.0).all()        # from the blank frame on: nothing tracked, nothing refined
+    assert (st0[7:, d, H.ST_NTRACK] == 0).all()           # (the frame AFTER the blank one: its previous patches are flat)
     for st, dn, p, u in outs[1:]:
         assert np.array_equal(st.view(np.uint64), st0.view(np.uint64)) and np.array_equal(dn.view(np.uint64), dn0.view(np.uint64))
         assert np.array_equal(p.view(np.uint32), p0.view(np.uint32)) and np.array_equal(u, u0)
