@@ -130,8 +130,8 @@ def raw_entry(run, prefix, name, label, alg=None):
                              "note": "mean over every dispatch of the kernel in the run; FETCH_SIZE doubled (MI355X_MICROARCH.md, HBM section)"}
             return
 raw_entry("c5", "dense_accum_kernel", "dense_accum_kernel", "c5: 61,440 samples + 240 corners, one Gauss-Newton launch (update prologue + accumulate)", 61440 * 28)
-raw_entry("c3pairs", "pyr_roll_kernel", "pyr_roll_kernel c3pairs", "c3pairs: pyrDown (register-rolling kernel) over 64 cold 720p frames, mean of the L0->L1 and L1->L2 launches; "
-          "algorithmic bytes = 64 x W*H*1.3125 / 2 launches (SURVEY 8d)", int(64 * 1280 * 720 * 1.3125 / 2))
+raw_entry("c3pairs", "pyr_roll2_kernel", "pyr_roll2_kernel c3pairs", "c3pairs: two pyrDown levels per pass (register-rolling, alternating strip directions) over 64 cold 720p frames, "
+          "one launch per pyramid build; algorithmic bytes = 64 x W*H*1.3125 (SURVEY 8d: level 0 read once, levels 1 and 2 written once)", int(64 * 1280 * 720 * 1.3125))
 raw_entry("c3pairs", "lk_kernel<21, 1, 3", "lk_kernel<21,1,3> c3pairs", "c3pairs: 3072 corners, one wave per corner", 64 * (48 * 3 * 1600 + 48 * 21))
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({r: {k: v for k, v in d["kernels"].items()} for r, d in durations.items()}, indent=1)[:6000])
