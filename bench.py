@@ -486,10 +486,12 @@ def main():
         if "drop_in_frame_latency_us" in extras:
             out["drop_in_frame_us_median"] = extras["drop_in_frame_latency_us"]["gray_pinned"]["median"]
         if cpu:
+            best = cpu.get("best_of_curve") or {"cores": 1, "value": cpu["value"]}
             out["vs_cpu_baseline"] = {"x_1_core": round(fps / cpu["value"], 1),
-                                      "x_%d_threads" % cpu["all_cores"]["cores"] if cpu.get("all_cores") else "x_all": round(fps / cpu["all_cores"]["value"], 1) if cpu.get("all_cores") else None,
-                                      "note": "CPU port on %s of this host's %d cores; a reported ratio, not the target (the roofline fraction is)"
-                                              % (("1 and %d" % cpu["all_cores"]["cores"]) if cpu.get("all_cores") else "1", os.cpu_count())}
+                                      "x_best_of_thread_curve": {"threads": best["cores"], "x": round(fps / best["value"], 1)},
+                                      "note": "CPU port at 1 thread and at the best point of its thread curve (1 / 4 / 16 / 64 / every core listed: cpu_baseline.threads_curve; "
+                                              "the boxes grant a job ~16 cores' worth of time, past that the OpenMP teams oversubscribe and collapse); "
+                                              "a reported ratio, not the target (the roofline fraction is)"}
         out["rccl_ranks"] = world
         out["dist_backend"] = D.backend_name()
         if world > 1:
@@ -679,6 +681,21 @@ def cpu_available():
         return os.cpu_count() or 1
 
 
+def cpu_quota():
+    """CPU time the container may use, in cores (cgroup v2 cpu.max / v1 cfs quota), or None: the GPU boxes list every core of the host in
+    the affinity mask but grant a job about 16 cores' worth of time, which is why the thread curve collapses past 16 threads there"""
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        return None if q == "max" else round(int(q) / int(p), 2)
+    except (OSError, ValueError):
+        pass
+    try:
+        q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read()); p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        return None if q <= 0 else round(q / p, 2)
+    except (OSError, ValueError):
+        return None
+
+
 def cpu_thread_counts():
     """1, 4, 16, 64, ... up to every core available to the process (SURVEY 8d's os.cpu_count() leg; the last entry)"""
     top = max(1, cpu_available())
@@ -846,7 +863,7 @@ def cpu_baseline(seq, frames, gpu_state, Wm, K, NF):
            "cpu_model": cpu_model(), "build": flags,
            "all_cores": {"value": top["value"], "cores": top["cores"],
                          "sample": "%s; pyrDown / Scharr in %d bands of rows, LK over points (OpenMP); every core available to the process" % (top.get("sample", ""), top["cores"])} if len(curve) > 1 else None,
-           "threads_curve": curve}
+           "threads_curve": curve, "best_of_curve": max(curve, key=lambda e_: e_["value"]), "cgroup_cpu_quota_cores": cpu_quota()}
     return cpu, pose_gap_vs_cpu_chain(seq, frames, gpu_state, NF, 60)
 
 

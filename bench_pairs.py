@@ -215,4 +215,4 @@ def cpu_baseline_pairs(seqs, NF):
                       % (n1, dt1, os.cpu_count(), B_.cpu_available()),
             "cpu_model": B_.cpu_model(), "build": flags,
             "all_cores": {"value": top["value"], "cores": top["cores"], "sample": top.get("sample", "")} if len(curve) > 1 else None,
-            "threads_curve": curve}
+            "threads_curve": curve, "best_of_curve": max(curve, key=lambda e_: e_["value"]), "cgroup_cpu_quota_cores": B_.cpu_quota()}
