@@ -196,8 +196,14 @@ const AgtChip* agt_chip_of(int device)
     return g_chip_state[device] == 1 ? &g_chip[device] : nullptr;
 }
 
+// (every launcher asks this once or twice per launch: while the process has only ever created contexts on ONE device -- the usual
+// case -- the answer is that device's entry, without a runtime call)
+static const AgtChip* g_chip_only = nullptr;
+static int g_chip_devices = 0;
+
 const AgtChip& agt_chip_current(void)
 {
+    if (g_chip_devices == 1 && g_chip_only) return *g_chip_only;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return g_chip_default; }
     const AgtChip* c = agt_chip_of(dev);
@@ -260,6 +266,7 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
     c->chip = *chip;
+    if (g_chip_only != chip) { g_chip_only = chip; g_chip_devices = g_chip_devices == 0 ? 1 : 2; }
     c->stream = (hipStream_t)hip_stream;
     // buildOpticalFlowPyramid level geometry + early stop
     int w = cfg->width, h = cfg->height;
@@ -1153,9 +1160,9 @@ static int step_serial(agt_ctx* c, const uint8_t* d_frames, size_t pitch, size_t
     // frame's arrival count (agt_step.hip lk_pnp_coop_kernel); the next frame's pyramid pass then rides in that launch as well
     // (while trackers + solvers are co-resident at the one workgroup per CU the solver's registers leave: more streams keep the LK
     // launch of its own, whose 78 registers put several workgroups on a CU)
-    // (the LK role's grid is rounded up to a multiple of the XCD count; the device's CU count, not a literal: ADVICE r4)
+    // (the LK role's grid is rounded up to a multiple of 8; the device's CU count, not a literal: ADVICE r4)
     const bool chain_pnp = lk_role_launch && d_dense_out && c->dn_iters > 0 && !pev && agt_pnp_can_ride(c->trk_n) && dense_defer_on() > 1 &&
-                           (long)agt_xcd_grid((long)c->trk_n * B, c->chip.xshift) + B <= c->chip.cus;
+                           (long)agt_xcd_grid((long)c->trk_n * B, 3) + B <= c->chip.cus;
     const bool ride_pnp = ride && agt_pnp_can_ride(c->trk_n) && !chain_pnp;
     if (ride) {
         // (what pyramid_build_on registers for a frame, for frame t + 1 in its ring entry)

@@ -215,7 +215,10 @@ __device__ __forceinline__ void pyr_role(KParams KS, KTables KT, int blk, int ba
             A.gx = KS->pyr[s].gx; A.gy = KS->pyr[s].gy; A.B = KS->pyr[s].B; A.pad = KS->pyr[s].pad;
             // XCD-aware tile order (see agt_pyramid.hip): workgroup index % X is the XCD (X = 2^xshift XCDs); the stage's
             // workgroups on XCD j take a contiguous run of tiles, runs laid out in XCD order.
-            const int xs = KS->xshift, xm = (1 << xs) - 1;
+            // (the fused step kernel keeps the LITERAL 8-way deal of rounds 1-4 -- a correct order on every device, the tuned one on a whole
+            // MI355X: read from the arguments, the shift cost the chained launches 0.5-1.7 % (c4 82.4 -> 81.5 k frames/s; the kernel sits on
+            // the edge of its register allocation); the group launch of the split pipeline follows the device's XCD count)
+            const int xs = ROLL2 ? KS->xshift : 3, xm = (1 << xs) - 1;
             const int j = (blk + base) & xm;
             int tile = (blk - ((j - base) & xm)) >> xs;
             for (int q = 0; q < j; q++) tile += (n - ((q - base) & xm) + xm) >> xs;
@@ -464,7 +467,7 @@ __device__ __forceinline__ void lk_reseed_role(const AgtStepParams& S, const Agt
                                                int bid, int nblk, uint8_t* lds)
 {
     static_assert(sizeof(agt_dense::DenseShared) <= agt_lk::lk_chain_lds_bytes<NLEV>(), "the prologue's LDS fits the tracker's");
-    const int blk = agt_xcd_order(bid, nblk, KS->xshift);      // XCD-aware corner order (lk_role); nblk is a multiple of the XCD count
+    const int blk = agt_xcd_order(bid, nblk, 3);      // XCD-aware corner order, the literal 8-way deal (see pyr_role); nblk is a multiple of 8
     if (blk >= S.lk.n * S.lk_B) return;
     const int b = blk / S.lk.n, pt = blk - b * S.lk.n;
     const long pidx = (long)b * S.lk.n + pt;
@@ -724,7 +727,7 @@ hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, cons
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
     const long corners = (long)P.lk.n * P.lk_B;
     P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift;
-    const unsigned grid8 = agt_xcd_grid(corners, P.xshift);
+    const unsigned grid8 = agt_xcd_grid(corners, 3);              // (lk_reseed_role deals 8 ways on every device)
     P.n_lk = (int)grid8;
     agt_dense::DenseParams D;
     static_assert(sizeof(D) <= sizeof(F->bytes), "AgtDenseFinal holds a DenseParams");
