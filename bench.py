@@ -448,6 +448,7 @@ def main():
             ring = bench.ring; bench.ring = None
             extras["batch64_hbm"] = batch_extra(torch, D, HL, args, rank, dev)
             extras["pairs64_hbm"] = pairs_extra(args)
+            extras["c5_dense240"] = c5_extra(args)
             bench.ring = ring
             bench.trk.pipeline(depth)
             extras["h2d_inclusive"] = h2d_inclusive(torch, bench, K)
@@ -668,6 +669,26 @@ def pairs_extra(args):
     keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "timing", "roofline", "max_abs_pose_err_vs_truth", "tracked_frac")
     res = {k: out[k] for k in keep}
     res["note"] = "child process of this command (python bench.py --workload c3pairs --steps 128 --warmup 16 --blocks 7 --no-cpu-baseline)"
+    return res
+
+
+def c5_extra(args):
+    """BASELINE.json configs[4] on the driver-timed line (c5 was builder-run only): 1280x720, 60 tags / 240 corners,
+    LK + PnP + dense photometric refinement (61,440 samples, 5 Gauss-Newton iterations) + corner re-seed per frame -- the c5 workload's
+    own default measurement (15 blocks of 400 steps), as a child process of this command (its own context and streams, like pairs64_hbm)."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AGT_DIST_BACKEND")}
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c5", "--no-cpu-baseline"]
+    try:
+        p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
+        line = [l for l in p.stdout.splitlines() if l.startswith("{")]
+        if p.returncode or not line:
+            return {"error": "child exited %d: %s" % (p.returncode, p.stderr[-300:])}
+        out = json.loads(line[-1])
+    except (subprocess.TimeoutExpired, OSError, ValueError) as e:
+        return {"error": repr(e)}
+    keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "timing", "roofline", "accepted_frac", "refined_frac", "tracked_corners_mean", "max_abs_pose_err_vs_truth")
+    res = {k: out[k] for k in keep if k in out}
+    res["note"] = "child process of this command (python bench.py --workload c5 --no-cpu-baseline)"
     return res
 
 
