@@ -247,6 +247,8 @@ class Bench:
         self.render_s = time.time() - t_r
         sq0 = self.seqs[0]
         self.trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
+        if getattr(args, "stream_lk_occupancy", 0):
+            self.trk.ctx.L.agt_lk_occupancy(self.trk.ctx.h, int(args.stream_lk_occupancy))
         self._views = {}
         self.pos = 0            # ring index of the newest frame handed to the tracker
         self.clips = not args.per_step_calls
@@ -360,6 +362,7 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
+    ap.add_argument("--stream-lk-occupancy", type=int, default=0, help="stream workloads (c2..c5): agt_lk_occupancy of the tracker's context (experiment; 0 = none)")
     ap.add_argument("--lk-occupancy", type=int, default=2, help="c3pairs: cap of the LK kernel's resident waves per SIMD in every context (agt_lk_occupancy; 0 = none)")
     ap.add_argument("--pair-contexts", type=int, default=4, help="c3pairs: contexts / streams the independent batches are pipelined over (1 = serial)")
     ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
