@@ -236,7 +236,9 @@ __device__ void smallest_eigvec(double* A, int n, double* v, double* tmp)
 
 // Cholesky solve of the symmetric positive definite n x n system A x = b (A row-major in LDS, overwritten by its factor);
 // inv_diag != null: the diagonal of A^-1 instead / as well.  Serial: call from ONE lane.  false = not positive definite.
-__device__ bool spd_solve(double* A, int n, const double* b, double* x, double* inv_diag)
+// (Always expanded in place: n is a constant at both call sites and `col` then lives in registers; as a function of its own --
+// the inliner's choice in a translation unit with few callers -- it indexes `col` dynamically and brings 112 B of scratch.)
+__device__ __forceinline__ bool spd_solve(double* A, int n, const double* b, double* x, double* inv_diag)
 {
     for (int j = 0; j < n; j++) {
         double d = A[j * n + j];
@@ -489,14 +491,19 @@ struct PnpNoHook { __device__ __forceinline__ void operator()() const {} };
 // wave with four points per lane: a quarter of the FP64 chain per evaluation for one barrier + 4 x 28 LDS reads
 // (240 corners: 21.3 -> ~11 us).  Every wave of the workgroup must call, with identical arguments; the caller guarantees a
 // guess (the DLT initialisation is one-wave code: COOP callers route guess-less solves to the PPL = 4 body on wave 0).
-template <typename T, int PPL, typename Hook = PnpNoHook, bool LDS_STATE = false, int COOP = 1>
+// OPAQUE (a caller that runs the body inside a FRAME LOOP): the thread index goes through an empty volatile asm, so that nothing
+// derived from it is loop-invariant to the compiler -- hoisted out of the loop those values (lane-selected constants, addresses)
+// stay alive across both solver bodies and spill.
+template <typename T, int PPL, typename Hook = PnpNoHook, bool LDS_STATE = false, int COOP = 1, bool OPAQUE = false>
 __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared& sh, const void* img_p, const uint8_t* mask_p,
                                          double* so_p, int extra_flags = 0, Hook before_state = Hook())
 {
     using TS = typename std::conditional<LDS_STATE, AgtTrackStateLds, AgtTrackState>::type;
     static_assert(COOP == 1 || (PPL == 1 && COOP * 32 * 3 <= NACC * SLAB), "cooperating waves hold one point per lane; slabs live in sh.part");
-    const int lane = (int)(threadIdx.x & (AGT_WAVE - 1));
-    const int wave = COOP > 1 ? (int)(threadIdx.x >> 6) : 0;
+    int tid_ = (int)threadIdx.x;
+    if constexpr (OPAQUE) asm volatile("" : "+v"(tid_));
+    const int lane = tid_ & (AGT_WAVE - 1);
+    const int wave = COOP > 1 ? agt_uniform(tid_ >> 6) : 0;
     const bool master = wave == 0;
     const bool writer = lane == 0 && master;
     const int n = P.n;

@@ -18,16 +18,7 @@
 #undef AGT_LK_STAMPS
 #endif
 #undef AGT_PNP_STAMPS
-#include <cstdlib>
-#include <cstring>
-#include <cstddef>
-#include "agt_pyramid2_body.h"
-#include "agt_pyramid3_body.h"
-#include "agt_pyramid4_body.h"
-#include "agt_lk_rs_body.h"
-#include "agt_lk_chain_body.h"
-#include "agt_pnp_body.h"
-#include "agt_dense_body.h"
+#include "agt_step_args.h"
 
 // Role timeline of the fused step (diagnostic build only, -DAGT_STEP_STAMPS; tools/stepstamps.py): s_memtime at entry and
 // exit of the PnP block, of the first LK block and the latest exit of any LK / pyramid block.
@@ -63,32 +54,6 @@ extern "C" int agt_debug_role_stamps(unsigned long long* host) { return (int)hip
 #endif
 
 namespace {
-
-constexpr int STEP_THREADS = 256;
-// chained launch: polls of an arrival counter before the waiting wave gives up (each poll is a device-scope load + s_sleep, >= 0.5 us)
-constexpr unsigned AGT_CHAIN_POLLS = 1u << 16;
-
-typedef const __attribute__((address_space(4))) AgtStepParams* KParams;
-typedef const __attribute__((address_space(4))) AgtStepTables* KTables;
-
-// The per-frame tables (second kernel argument) are indexed with run-time frame numbers; they are read straight
-// from the kernel-argument segment -- indexing a by-value argument dynamically forces a copy into scratch.
-__device__ __forceinline__ KParams kernarg_params() { return (KParams)__builtin_amdgcn_kernarg_segment_ptr(); }
-__device__ __forceinline__ KTables kernarg_tables()
-{
-    static_assert(alignof(AgtStepTables) == 8 && alignof(AgtStepParams) == 8, "kernel-argument layout");
-    return (KTables)((const __attribute__((address_space(4))) char*)__builtin_amdgcn_kernarg_segment_ptr() + ((sizeof(AgtStepParams) + 7) & ~(size_t)7));
-}
-
-// LDS of one corner of the LK role: the tracker's tiles (general body, or the frame-chained body where that one applies)
-// and, behind them, the copy of the per-frame tables
-template <int WIN, int NW, int NLEV>
-__host__ __device__ constexpr size_t lk_role_lds(int levels)
-{
-    size_t body = agt_lk::lk_lds_bytes<WIN, NW>(levels);
-    if (WIN == 21 && NW == 4 && agt_lk::lk_chain_lds_bytes<NLEV>() > body) body = agt_lk::lk_chain_lds_bytes<NLEV>();
-    return (body + sizeof(AgtLkTables) + 15) & ~(size_t)15;
-}
 
 // ---- LK role: workgroup `blk` of the role, THREADS threads.  NW = 4: the workgroup is one corner; NW = 1: each wave is
 // its own corner.  Consecutive frames of a corner are tracked in-kernel (position carried in registers).
@@ -357,7 +322,6 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
 // the head of each frame hands it to the others.  A frame without a guess (first frame, after a gate rejection) is solved by
 // wave 0 alone with four points per lane -- the DLT initialisation is one-wave code.  A chained wait (not used by the split
 // launches of today, kept so the tables mean the same everywhere) is polled by one lane and its outcome shared through LDS.
-constexpr int PNP_COOP = agt_pnp::MAX_PPL;
 __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtStepTables& T, KTables KT, int blk, agt_pnp::PnpShared& sh)
 {
     // Round 5: the solver bodies of the stand-alone pnp_coop_kernel / lk_pnp_coop_kernel -- tracker state in GLOBAL
@@ -395,8 +359,16 @@ __device__ __forceinline__ void pnp_role_coop(const AgtStepParams& S, const AgtS
         const bool guess = agt_uniform(__hip_atomic_load(&S.pnp.track[blk].has_guess, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) != 0 && S.pnp.enhance_ape;
         __syncthreads();        // every wave has read the decision before wave 0 (alone, without a guess) may rewrite has_guess
         const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
-        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, false, PNP_COOP>(S.pnp, blk, sh, img, mask, so, xf);
-        else if (wave == 0) agt_pnp::pnp_body<float, agt_pnp::MAX_PPL>(S.pnp, blk, sh, img, mask, so, xf);
+        // The solver sees the parameters and its thread index through values the compiler cannot follow across frames (an empty
+        // volatile asm on the kernel-argument pointer, the stream index and -- inside the body -- the thread index): everything it derives
+        // from them is computed per frame.  Hoisted out of the frame loop those values (reciprocals of the camera constants, lane-selected
+        // polynomial coefficients, addresses) were alive across BOTH solver bodies: 129 VGPRs spilled, 376 B of scratch.
+        KParams KF = kernarg_params();
+        int bk = blk;
+        asm volatile("" : "+s"(KF), "+s"(bk));
+        const AgtPnpParams& PF = *(const AgtPnpParams*)&KF->pnp;
+        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, false, PNP_COOP, true>(PF, bk, sh, img, mask, so, xf);
+        else if (wave == 0) agt_pnp::pnp_body<float, agt_pnp::MAX_PPL, agt_pnp::PnpNoHook, false, 1, true>(PF, bk, sh, img, mask, so, xf);
         if (wave == 0) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");          // the state (and the record) of frame k are written before the next frame's barrier lets anybody read them
             if (S.pnp.host_seq && blk == 0 && k == S.pnp_nf - 1) agt_host_seq_store(S.pnp.host_seq, S.pnp.host_seq_base + (unsigned long long)k, tid == 0);
@@ -454,107 +426,6 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     lk_role<WIN, NW, NLEV, AGT_WAVE * NW, true>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
-}
-
-// Clip submission of the tracker's dense stage (agt_track_frames_dense): the LK launch of frame t + 1 first finishes the dense stage
-// of frame t.  Every workgroup (one corner, four waves) derives the last Gauss-Newton update from the block rows itself
-// (agt_dense_body.h dense_finish: same rows, same order, same bits in every workgroup -- the scheme of the accumulate launches'
-// prologue), projects ITS corner at the refined pose (the re-seed) and tracks it from there; the workgroup of a stream's corner 0
-// also publishes pose / statistics / record.  Replaces dense_final_kernel, a one-workgroup launch of 5.5 us in the frame's serial
-// chain, by ~2.5 us at the head of this launch.  The stream's done word is read, never written here (the other corners read it).
-template <int NLEV>
-__device__ __forceinline__ void lk_reseed_role(const AgtStepParams& S, const AgtStepTables& T, KParams KS, const agt_dense::DenseParams& F, bool has_final,
-                                               int bid, int nblk, uint8_t* lds)
-{
-    static_assert(sizeof(agt_dense::DenseShared) <= agt_lk::lk_chain_lds_bytes<NLEV>(), "the prologue's LDS fits the tracker's");
-    const int blk = agt_xcd_order(bid, nblk, 3);      // XCD-aware corner order, the literal 8-way deal (see pyr_role); nblk is a multiple of 8
-    if (blk >= S.lk.n * S.lk_B) return;
-    const int b = blk / S.lk.n, pt = blk - b * S.lk.n;
-    const long pidx = (long)b * S.lk.n + pt;
-    // the corner as the previous frame's LK / PnP left it: requested first, used when the stage did not refine the pose
-    float px = S.lk.prev_pts[pidx * 2], py = S.lk.prev_pts[pidx * 2 + 1];
-    int pst = S.lk.prev_status ? (int)S.lk.prev_status[pidx] : 1;
-    if (has_final) {
-        const float X = F.obj[pt * 3], Y = F.obj[pt * 3 + 1], Z = F.obj[pt * 3 + 2];
-        agt_dense::DenseShared& sh = *reinterpret_cast<agt_dense::DenseShared*>(lds);
-        double param[6];
-        const bool refined = agt_dense::dense_finish(F, sh, b, S.lk_B, pt == 0, false, param);
-        if (F.seed_pts && F.rec && refined) {
-            AgtCamera cam;
-            agt_pnp::load_cam<float>(F.cam, cam);
-            double R[9], G[9];
-            agt_rodrigues<false>(param, R, G);
-            double u, v;
-            agt_project<false>(cam, R, G, param + 3, (double)X, (double)Y, (double)Z, u, v, nullptr, nullptr);
-            px = (float)u; py = (float)v; pst = 1;
-            if (threadIdx.x == 0) { F.seed_pts[pidx * 2] = px; F.seed_pts[pidx * 2 + 1] = py; F.seed_status[pidx] = 1; }
-        }
-        __syncthreads();                // the prologue's LDS is the tracker's from here on
-    }
-    auto frame = [&](int) {
-        agt_lk::LkFrameIo<NLEV> io;
-        io.grouped = true; io.prev_pts = S.lk.prev_pts; io.err = nullptr; io.have_pos = true; io.px = px; io.py = py; io.pst = pst;
-#pragma unroll
-        for (int l = 0; l < NLEV; l++) { io.imgI[l] = T.lk.img[0][l]; io.imgJ[l] = T.lk.img[1][l]; }
-        io.next_pts = T.lk.next[0]; io.status = T.lk.status[0]; io.done = T.lk.done[0];
-        return io;
-    };
-    agt_lk::lk_frames_w4<NLEV>(&KS->lk, pt, b, lds, 1, frame);
-}
-
-template <int NLEV>
-__global__ __launch_bounds__(AGT_WAVE * 4) void lk_reseed_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    lk_reseed_role<NLEV>(S, T, kernarg_params(), F, true, (int)blockIdx.x, (int)gridDim.x, lds);
-}
-
-// ... and the frame's pose solve chained to it in the SAME launch (n > 64 corners: the four-wave cooperative solver, one workgroup
-// per stream behind the S.n_lk tracker workgroups), waiting for the frame's arrival count as the pose role of the fused step does:
-// the launch boundary between LK and PnP (~2 us at the end of a 25 us launch) and the solver's start-up leave the serial chain.
-// has_final == 0: no dense stage is pending (first frame of a clip).
-// Behind the solver's workgroups: the two-level pyramid pass of the NEXT frame (clip submission; n_pyr tiles per stream, Y0 / Y1 as in
-// pnp_coop_kernel) -- the kernel's registers allow one workgroup per CU, the trackers and the solver hold 241 of the 256, the tiles
-// take the rest and the CUs the trackers leave.
-template <int NLEV>
-__global__ __launch_bounds__(AGT_WAVE * 4) void lk_pnp_coop_kernel(const AgtStepParams S, const AgtStepTables T, const agt_dense::DenseParams F, const int has_final,
-                                                                   const AgtPyrArgs Y0, const AgtPyrArgs Y1, const int n_pyr)
-{
-    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
-    if ((int)blockIdx.x >= S.n_lk + S.n_pnp) {
-        const int t = (int)blockIdx.x - S.n_lk - S.n_pnp;
-        const int st = t / n_pyr, tile = t - st * n_pyr;
-        const int by = tile / Y0.gx, bx = tile - by * Y0.gx;
-        agt_pyr2::pyr_down2_body(Y0, Y1, bx, by, Y0.src + (long)st * Y0.sbatch, Y0.dst + (long)st * Y0.dbatch, Y1.dst + (long)st * Y1.dbatch, lds);
-        return;
-    }
-    if ((int)blockIdx.x >= S.n_lk) {
-        // the solve as the stand-alone pnp_coop_kernel runs it (tracker state in global memory: the role form of the group launches,
-        // pnp_role_coop, keeps it in LDS across frames and spills 236 registers for it), behind the wait of a chained launch
-        agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        const int b = (int)blockIdx.x - S.n_lk;
-        if (threadIdx.x == 0) {
-            const int* fault = &S.pnp.track[b].chain_fault;
-            const unsigned target = (unsigned)T.pnp.target[0];
-            unsigned polls = 0;
-            int timed_out = 0;
-            while ((int)(__hip_atomic_load(T.pnp.wait[0] + b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) {
-                __builtin_amdgcn_s_sleep(4);
-                if (++polls > AGT_CHAIN_POLLS || ((polls & 15) == 1 && __hip_atomic_load(fault, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT))) { timed_out = 1; break; }
-            }
-            *(volatile int*)&sh.late = timed_out;
-        }
-        __syncthreads();
-        const int late = agt_uniform(*(volatile int*)&sh.late);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-        const bool guess = agt_uniform(S.pnp.track[b].has_guess) && S.pnp.enhance_ape;
-        __syncthreads();        // every wave has read the decision before wave 0 (alone, without a guess) may rewrite has_guess
-        const int xf = late ? AGT_TRK_CHAIN_TIMEOUT : 0;
-        if (guess) agt_pnp::pnp_body<float, 1, agt_pnp::PnpNoHook, false, PNP_COOP>(S.pnp, b, sh, T.pnp.img[0], T.pnp.mask[0], T.pnp.so[0], xf);
-        else if (threadIdx.x < AGT_WAVE) agt_pnp::pnp_body<float, agt_pnp::MAX_PPL>(S.pnp, b, sh, T.pnp.img[0], T.pnp.mask[0], T.pnp.so[0], xf);
-        return;
-    }
-    lk_reseed_role<NLEV>(S, T, kernarg_params(), F, has_final != 0, (int)blockIdx.x, S.n_lk, lds);
 }
 
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
@@ -711,46 +582,6 @@ bool agt_step_fits(int n, int B)
     { static const long f = [] { const char* e = getenv("AGT_STEP_MAX_CORNERS"); return e ? atol(e) : 0L; }(); if (f > 0) cap = f; }
 #endif
     return n <= AGT_WAVE && (long)n * B <= cap;
-}
-
-// the one-frame LK role launch of step_serial with the previous frame's dense stage finished in its prologue (lk_reseed_kernel; F
-// null: nothing pending), and, with S.n_pnp > 0, the frame's cooperative pose solve chained to it in the same launch (lk_pnp_coop_kernel)
-hipError_t agt_launch_lk_reseed(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, const AgtDenseFinal* F, const AgtPyrArgs* ride)
-{
-    if (ride && S.n_pnp <= 0) return hipErrorInvalidValue;          // (the pyramid tiles ride in the chained form only)
-    if (win != 21 || S.n_lk <= 0 || S.lk_nf != 1 || !agt_lk_wide(S.lk.n, S.lk_B) || S.lk.flags != 0 || S.lk.err != nullptr) return hipErrorInvalidValue;
-    const bool chain = S.n_pnp > 0;
-    if (!chain && !F) return hipErrorInvalidValue;
-    if (chain && (S.pnp_nf != 1 || S.pnp.n <= AGT_WAVE || S.pnp.n > AGT_WAVE * PNP_COOP || !T.pnp.wait[0] || !T.lk.done[0])) return hipErrorInvalidValue;
-    AgtStepParams P = S;
-    if (!chain) { P.n_pnp = 0; P.pnp_nf = 0; }
-    for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) { P.n_pyr[s] = 0; P.pyr_nf[s] = 0; }
-    const long corners = (long)P.lk.n * P.lk_B;
-    P.xshift = agt_chip_current().xshift; P.rsv_ = 0; P.lk.xshift = P.xshift;
-    const unsigned grid8 = agt_xcd_grid(corners, 3);              // (lk_reseed_role deals 8 ways on every device)
-    P.n_lk = (int)grid8;
-    agt_dense::DenseParams D;
-    static_assert(sizeof(D) <= sizeof(F->bytes), "AgtDenseFinal holds a DenseParams");
-    memset(&D, 0, sizeof(D));
-    if (F) {
-        memcpy(&D, F->bytes, sizeof(D));
-        if (D.N != P.lk.n || (D.seed_pts && D.seed_pts != P.lk.prev_pts)) return hipErrorInvalidValue;      // (a re-seeded corner set IS this launch's start)
-    }
-    const bool small = P.lk.max_level < 3;
-    size_t per = small ? lk_role_lds<21, 4, 3>(P.lk.max_level + 1) : lk_role_lds<21, 4, AGT_MAX_LEVELS>(P.lk.max_level + 1);
-    if (!chain) {
-        if (small) hipLaunchKernelGGL((lk_reseed_kernel<3>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
-        else hipLaunchKernelGGL((lk_reseed_kernel<AGT_MAX_LEVELS>), dim3(grid8), dim3(AGT_WAVE * 4), per, stream, P, T, D);
-        return hipGetLastError();
-    }
-    if (per < sizeof(agt_pnp::PnpShared)) per = sizeof(agt_pnp::PnpShared);
-    const AgtPyrArgs none = AgtPyrArgs();
-    const int n_pyr = ride ? ride[0].gx * ride[0].gy : 0;
-    if (ride && per < (size_t)agt_pyr2::PYR2_LDS_BYTES) per = (size_t)agt_pyr2::PYR2_LDS_BYTES;
-    const unsigned grid = grid8 + (unsigned)P.n_pnp + (unsigned)(n_pyr * P.lk_B);
-    if (small) hipLaunchKernelGGL((lk_pnp_coop_kernel<3>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0, ride ? ride[0] : none, ride ? ride[1] : none, n_pyr > 0 ? n_pyr : 1);
-    else hipLaunchKernelGGL((lk_pnp_coop_kernel<AGT_MAX_LEVELS>), dim3(grid), dim3(AGT_WAVE * 4), per, stream, P, T, D, F ? 1 : 0, ride ? ride[0] : none, ride ? ride[1] : none, n_pyr > 0 ? n_pyr : 1);
-    return hipGetLastError();
 }
 
 hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const AgtStepTables& T, int win, int roles)
