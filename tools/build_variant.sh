@@ -7,7 +7,7 @@ cd "$(dirname "$0")/../accurate_aprilgroup_tracking_amd/csrc"
 make -s -j8 knobs
 mkdir -p ../../tools/_exp/$name
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAGT_DEBUG_KNOBS $extra"
-STEPFLAGS="-mllvm -disable-machine-licm"     # (as the Makefile: agt_step.hip only)
+STEPFLAGS="${STEPFLAGS--mllvm -disable-machine-licm}"     # (as the Makefile: agt_step.hip only)
 objs=""
 for f in agt_api agt_pyramid agt_lk agt_pnp agt_step agt_step_dense agt_preproc agt_dense; do
   if [[ " $* " == *" $f.hip "* ]]; then
