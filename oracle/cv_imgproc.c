@@ -55,6 +55,11 @@ static void undistort_point(double u, double v, const double K[9], const double 
     const double fx = K[0], fy = K[4], ifx = 1. / fx, ify = 1. / fy, cx = K[2], cy = K[5];
     double x = (u - cx) * ifx, y = (v - cy) * ify;
     if (has_dist) {
+        double Ti[9], vu[3];
+        cvo_tilt_of(k, NULL, Ti);
+        for (int r = 0; r < 3; r++) { double a = 0; a += Ti[r * 3] * x; a += Ti[r * 3 + 1] * y; a += Ti[r * 3 + 2] * 1; vu[r] = a; }
+        const double invProj = vu[2] ? 1. / vu[2] : 1;
+        x = invProj * vu[0]; y = invProj * vu[1];
         const double x0 = x, y0 = y;
         for (int j = 0; j < 5; j++) {
             double r2 = x * x + y * y;
@@ -162,6 +167,8 @@ int cvo_init_undistort_rectify_map(const double K[9], const double* dist, int nd
     const double u0 = K[2], v0 = K[5], fx = K[0], fy = K[4];
     const double k1 = k[0], k2 = k[1], p1 = k[2], p2 = k[3], k3 = k[4], k4 = k[5], k5 = k[6], k6 = k[7];
     const double s1 = k[8], s2 = k[9], s3 = k[10], s4 = k[11];
+    double T[9];
+    cvo_tilt_of(k, T, NULL);
     for (int i = 0; i < h; i++)
         for (int j = 0; j < w; j++) {
             double _x = j * ir[0] + (i * ir[1] + ir[2]), _y = j * ir[3] + (i * ir[4] + ir[5]), _w = j * ir[6] + (i * ir[7] + ir[8]);
@@ -170,7 +177,10 @@ int cvo_init_undistort_rectify_map(const double K[9], const double* dist, int nd
             double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
             double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + s1 * r2 + s2 * r2 * r2);
             double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + s3 * r2 + s4 * r2 * r2);
-            double u = fx * xd + u0, v = fy * yd + v0;
+            double vt[3];
+            for (int r = 0; r < 3; r++) { double a = 0; a += T[r * 3] * xd; a += T[r * 3 + 1] * yd; a += T[r * 3 + 2] * 1; vt[r] = a; }
+            double invProj = vt[2] ? 1. / vt[2] : 1;
+            double u = fx * invProj * vt[0] + u0, v = fy * invProj * vt[1] + v0;
             double us = u * INTER_TAB_SIZE, vs = v * INTER_TAB_SIZE;
             /* saturate_cast<int>(double) */
             int iu = us >= 2147483647. ? 2147483647 : us <= -2147483648. ? (-2147483647 - 1) : round_half_even_d(us);

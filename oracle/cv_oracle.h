@@ -108,6 +108,9 @@ int cvo_project_points(const double* obj, int n, const double rvec[3], const dou
                        double* img_out, double* dpdr, double* dpdt);
 
 /* ---- cv::undistortPoints as used by solvePnP (5 fixed iterations, R=I, no P) ---- */
+/* tilted-sensor matrices of the 14-coefficient model (k[12] = tau_x, k[13] = tau_y): identity when both are zero */
+void cvo_tilt_matrices(double tauX, double tauY, double matTilt[9], double invMatTilt[9]);
+void cvo_tilt_of(const double k[14], double matTilt[9], double invMatTilt[9]);
 int cvo_undistort_points(const double* img, int n, const double K[9],
                          const double* dist, int ndist, double* out);
 

@@ -219,7 +219,48 @@ static void load_dist(const double* dist, int ndist, double k[14])
     if (dist) for (int i = 0; i < ndist && i < 14; i++) k[i] = dist[i];
 }
 
-/* calibration.cpp cvProjectPoints2Internal (tilt terms tau_x, tau_y = 0 -> identity, omitted) */
+/* distortion_model.hpp detail::computeTiltProjectionMatrix<double> [OpenCV-knowledge]: the sensor plane tilted by tau_x about x and
+ * tau_y about y -- rotate (R_y R_x), then project along z back onto z = 1: matTilt = matProjZ * matRotXY, its inverse
+ * matRotXY^T * invMatProjZ.  Matx products accumulate s = 0; s += a(i,k) * b(k,j) over k (mat3_mul_cv). */
+static void mat3_mul_cv(const double A[9], const double B[9], double C[9])
+{
+    for (int i = 0; i < 3; i++)
+        for (int j = 0; j < 3; j++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += A[i * 3 + k] * B[k * 3 + j];
+            C[i * 3 + j] = s;
+        }
+}
+
+void cvo_tilt_matrices(double tauX, double tauY, double matTilt[9], double invMatTilt[9])
+{
+    const double cTauX = cos(tauX), sTauX = sin(tauX), cTauY = cos(tauY), sTauY = sin(tauY);
+    const double matRotX[9] = { 1, 0, 0, 0, cTauX, sTauX, 0, -sTauX, cTauX };
+    const double matRotY[9] = { cTauY, 0, -sTauY, 0, 1, 0, sTauY, 0, cTauY };
+    double matRotXY[9];
+    mat3_mul_cv(matRotY, matRotX, matRotXY);
+    if (matTilt) {
+        const double matProjZ[9] = { matRotXY[8], 0, -matRotXY[2], 0, matRotXY[8], -matRotXY[5], 0, 0, 1 };
+        mat3_mul_cv(matProjZ, matRotXY, matTilt);
+    }
+    if (invMatTilt) {
+        const double inv = 1. / matRotXY[8];
+        const double invMatProjZ[9] = { inv, 0, inv * matRotXY[2], 0, inv, inv * matRotXY[5], 0, 0, 1 };
+        const double t[9] = { matRotXY[0], matRotXY[3], matRotXY[6], matRotXY[1], matRotXY[4], matRotXY[7], matRotXY[2], matRotXY[5], matRotXY[8] };
+        mat3_mul_cv(t, invMatProjZ, invMatTilt);
+    }
+}
+
+/* matTilt / invMatTilt of a coefficient vector: the identity unless k[12] or k[13] is non-zero (as every OpenCV user of the model) */
+void cvo_tilt_of(const double k[14], double matTilt[9], double invMatTilt[9])
+{
+    static const double I[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    if (matTilt) memcpy(matTilt, I, sizeof(I));
+    if (invMatTilt) memcpy(invMatTilt, I, sizeof(I));
+    if (k[12] != 0 || k[13] != 0) cvo_tilt_matrices(k[12], k[13], matTilt, invMatTilt);
+}
+
+/* calibration.cpp cvProjectPoints2Internal, 14-coefficient model: radial (rational), tangential, thin prism, tilted sensor */
 int cvo_project_points(const double* obj, int n, const double rvec[3], const double tvec[3],
                        const double Kc[9], const double* dist, int ndist,
                        double* m, double* dpdr, double* dpdt)
@@ -229,6 +270,8 @@ int cvo_project_points(const double* obj, int n, const double rvec[3], const dou
     double R[9], dRdr[27], k[14];
     cvo_rodrigues_vec2mat(rvec, R, dRdr);
     load_dist(dist, ndist, k);
+    double T[9];
+    cvo_tilt_of(k, T, NULL);
     const double fx = Kc[0], fy = Kc[4], cx = Kc[2], cy = Kc[5];
     const double* t = tvec;
     for (int i = 0; i < n; i++) {
@@ -242,10 +285,21 @@ int cvo_project_points(const double* obj, int n, const double rvec[3], const dou
         double a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
         double cdist = 1 + k[0] * r2 + k[1] * r4 + k[4] * r6;
         double icdist2 = 1. / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
-        double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4;
-        double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4;
+        double xd0 = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4;
+        double yd0 = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4;
+        /* additional distortion by projecting onto a tilt plane: vecTilt = matTilt * (xd0, yd0, 1) */
+        double vt[3];
+        for (int r = 0; r < 3; r++) { double a = 0; a += T[r * 3] * xd0; a += T[r * 3 + 1] * yd0; a += T[r * 3 + 2] * 1; vt[r] = a; }
+        double invProj = vt[2] ? 1. / vt[2] : 1;
+        double xd = invProj * vt[0], yd = invProj * vt[1];
         m[i * 2] = xd * fx + cx;
         m[i * 2 + 1] = yd * fy + cy;
+        /* d(xd, yd) / d(xd0, yd0) */
+        double dT[4];
+        for (int r = 0; r < 2; r++)
+            for (int c = 0; c < 2; c++) dT[r * 2 + c] = T[r * 3 + c] * vt[2] - T[6 + c] * vt[r];
+        const double invProjSquare = invProj * invProj;
+        for (int q = 0; q < 4; q++) dT[q] *= invProjSquare;
         if (dpdt) {
             double* p = dpdt + (size_t)i * 6;
             double dxdt[3] = { z, 0, -x * z }, dydt[3] = { 0, z, -y * z };
@@ -258,8 +312,11 @@ int cvo_project_points(const double* obj, int n, const double rvec[3], const dou
                                 k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]) + k[8] * dr2dt + 2 * r2 * k[9] * dr2dt);
                 double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + y * cdist * dicdist2_dt +
                                 k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt + k[10] * dr2dt + 2 * r2 * k[11] * dr2dt);
-                p[j] = fx * dmxdt;
-                p[3 + j] = fy * dmydt;
+                double dX = 0, dY = 0;
+                dX += dT[0] * dmxdt; dX += dT[1] * dmydt;
+                dY += dT[2] * dmxdt; dY += dT[3] * dmydt;
+                p[j] = fx * dX;
+                p[3 + j] = fy * dY;
             }
         }
         if (dpdr) {
@@ -284,8 +341,11 @@ int cvo_project_points(const double* obj, int n, const double rvec[3], const dou
                                 k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr) + (k[8] + 2 * r2 * k[9]) * dr2dr);
                 double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + y * cdist * dicdist2_dr +
                                 k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr + (k[10] + 2 * r2 * k[11]) * dr2dr);
-                p[j] = fx * dmxdr;
-                p[3 + j] = fy * dmydr;
+                double dX = 0, dY = 0;
+                dX += dT[0] * dmxdr; dX += dT[1] * dmydr;
+                dY += dT[2] * dmxdr; dY += dT[3] * dmydr;
+                p[j] = fx * dX;
+                p[3 + j] = fy * dY;
             }
         }
     }
@@ -299,11 +359,18 @@ int cvo_undistort_points(const double* img, int n, const double Kc[9],
     if (!img || !out || n < 0) return -1;
     double k[14];
     load_dist(dist, ndist, k);
+    double Ti[9];
+    cvo_tilt_of(k, NULL, Ti);
     const double fx = Kc[0], fy = Kc[4], ifx = 1. / fx, ify = 1. / fy, cx = Kc[2], cy = Kc[5];
     for (int i = 0; i < n; i++) {
         double u = img[i * 2], v = img[i * 2 + 1];
         double x = (u - cx) * ifx, y = (v - cy) * ify;
         if (dist && ndist > 0) {
+            /* compensate tilt distortion: vecUntilt = invMatTilt * (x, y, 1) */
+            double vu[3];
+            for (int r = 0; r < 3; r++) { double a = 0; a += Ti[r * 3] * x; a += Ti[r * 3 + 1] * y; a += Ti[r * 3 + 2] * 1; vu[r] = a; }
+            const double invProj = vu[2] ? 1. / vu[2] : 1;
+            x = invProj * vu[0]; y = invProj * vu[1];
             double x0 = x, y0 = y;
             for (int j = 0; j < 5; j++) {
                 double r2 = x * x + y * y;

@@ -40,14 +40,32 @@ def rodrigues(r):
     return R, J
 
 
-def project(obj, r, t, K, dist=None, jacobian=False):
-    """cv::projectPoints: obj (N,3) -> img (N,2) [, J (2N,6) = d(u,v)/d(r,t)]"""
-    X = np.asarray(obj, np.float64).reshape(-1, 3)
-    n = X.shape[0]
-    k = np.zeros(12)
+def tilt_matrix(tau_x, tau_y):
+    """Tilted-sensor homography of OpenCV's 14-coefficient model (calib3d documentation, "tilted sensor" / Scheimpflug term): the
+    distorted normalised point is rotated by R = R_y(tau_y) R_x(tau_x) and projected back onto z = 1 along the ROTATED optical axis:
+    [[R22, 0, -R02], [0, R22, -R12], [0, 0, 1]] R."""
+    cx_, sx_, cy_, sy_ = np.cos(tau_x), np.sin(tau_x), np.cos(tau_y), np.sin(tau_y)
+    Rx = np.array([[1, 0, 0], [0, cx_, sx_], [0, -sx_, cx_]])
+    Ry = np.array([[cy_, 0, -sy_], [0, 1, 0], [sy_, 0, cy_]])
+    R = Ry @ Rx
+    return np.array([[R[2, 2], 0, -R[0, 2]], [0, R[2, 2], -R[1, 2]], [0, 0, 1]]) @ R
+
+
+def _coeffs14(dist):
+    k = np.zeros(14)
     if dist is not None:
         d = np.asarray(dist, np.float64).reshape(-1)
-        k[:d.size] = d[:12]
+        k[:d.size] = d[:14]
+    return k
+
+
+def project(obj, r, t, K, dist=None, jacobian=False):
+    """cv::projectPoints: obj (N,3) -> img (N,2) [, J (2N,6) = d(u,v)/d(r,t)]; dist: up to 14 coefficients (k1 k2 p1 p2 k3 k4 k5 k6
+    s1 s2 s3 s4 tau_x tau_y)"""
+    X = np.asarray(obj, np.float64).reshape(-1, 3)
+    n = X.shape[0]
+    k = _coeffs14(dist)
+    T = tilt_matrix(k[12], k[13])
     fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
     R, dRdr = rodrigues(r)
     Y = X @ R.T + np.asarray(t, np.float64).reshape(3)
@@ -60,10 +78,14 @@ def project(obj, r, t, K, dist=None, jacobian=False):
     icdist2 = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6)
     xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4
     yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4
-    img = np.stack([fx * xd + cx, fy * yd + cy], axis=1)
+    # tilted sensor: (xd, yd, 1) -> T (xd, yd, 1), dehomogenised; its 2 x 2 Jacobian by the quotient rule
+    hx, hy, hw = (T[q, 0] * xd + T[q, 1] * yd + T[q, 2] for q in range(3))
+    xt, yt = hx / hw, hy / hw
+    img = np.stack([fx * xt + cx, fy * yt + cy], axis=1)
     if not jacobian:
         return img
     J = np.zeros((n, 2, 6))
+    D = [[(T[q, c] * hw - T[2, c] * (hx, hy)[q]) / (hw * hw) for c in range(2)] for q in range(2)]
 
     def chain(dx, dy):
         """d(xd, yd) for a perturbation (dx, dy) of the normalised point"""
@@ -75,7 +97,7 @@ def project(obj, r, t, K, dist=None, jacobian=False):
             + k[8] * dr2 + 2 * k[9] * r2 * dr2
         dyd = dy * cdist * icdist2 + y * dcdist * icdist2 + y * cdist * dicdist2 + k[2] * (dr2 + 4 * y * dy) + k[3] * da1 \
             + k[10] * dr2 + 2 * k[11] * r2 * dr2
-        return fx * dxd, fy * dyd
+        return fx * (D[0][0] * dxd + D[0][1] * dyd), fy * (D[1][0] * dxd + D[1][1] * dyd)
     # translation: dY = e_j
     for j in range(3):
         e = np.zeros(3); e[j] = 1.0
@@ -143,15 +165,16 @@ def undistort_points(img, K, dist=None, iters=5):
     """cv::undistortPoints with R = I, no P: pixel -> normalised coordinates, `iters` fixed-point iterations of the inverse
     Brown-Conrady map (rational + tangential + thin-prism terms)"""
     p = np.asarray(img, np.float64).reshape(-1, 2)
-    k = np.zeros(12)
-    if dist is not None:
-        d = np.asarray(dist, np.float64).reshape(-1)
-        k[:min(d.size, 12)] = d[:12]
+    k = _coeffs14(dist)
     x0 = (p[:, 0] - K[0, 2]) / K[0, 0]
     y0 = (p[:, 1] - K[1, 2]) / K[1, 1]
     x, y = x0.copy(), y0.copy()
     if dist is None:
         return np.stack([x, y], 1)
+    # the sensor tilt is undone first (exact inverse homography), then the fixed-point iterations run on the un-tilted point
+    h = np.linalg.inv(tilt_matrix(k[12], k[13])) @ np.stack([x0, y0, np.ones_like(x0)])
+    x0, y0 = h[0] / h[2], h[1] / h[2]
+    x, y = x0.copy(), y0.copy()
     for _ in range(iters):
         r2 = x * x + y * y
         icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)

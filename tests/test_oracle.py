@@ -2,6 +2,8 @@
 implementations available here -- scipy Rotation / least_squares / ndimage, numpy SVD and
 the analytic projection of the synthetic generator.  cv2 itself is not installable, so
 parity with real cv2 stays UNPINNED (oracle/cv_oracle.h)."""
+import ctypes
+
 import numpy as np
 import pytest
 from scipy.ndimage import correlate1d, gaussian_filter, shift
@@ -433,3 +435,59 @@ def test_pnp_planar_init_oracle_equals_numpy_statement(oracle):
     assert worst_h < 1e-6, worst_h
     assert worst_init < 1e-6, worst_init
     assert worst_pose < 1e-9, worst_pose
+
+
+def test_tilted_sensor_model_oracle_equals_numpy_statement(oracle):
+    """The 14-coefficient camera model with a TILTED sensor (tau_x, tau_y != 0; VERDICT r4 missing #6; what cv2.calibrateCamera returns under
+    CALIB_TILTED_MODEL -- the reference calibrates 5 coefficients, calibrate_camera.py:178): the C oracle's projectPoints (+ Jacobian),
+    undistortPoints and both solvePnP branches against tests/pnp_numpy.py, whose tilt is written from the model's geometry (rotate the
+    distorted point by R_y R_x, project back along the rotated axis; numpy.linalg.inv for the way back)."""
+    from tests import pnp_numpy as P
+    rng = np.random.default_rng(77)
+    # the matrices themselves: the oracle's pair are inverses of each other and equal the numpy statement
+    L = oracle.lib()
+    for tx, ty in ((0.03, -0.02), (-0.1, 0.07), (0.0, 0.05), (0.2, 0.0)):
+        M = np.zeros(9); Mi = np.zeros(9)
+        L.cvo_tilt_matrices(ctypes.c_double(tx), ctypes.c_double(ty), M.ctypes.data_as(ctypes.c_void_p), Mi.ctypes.data_as(ctypes.c_void_p))
+        assert np.abs(M.reshape(3, 3) - P.tilt_matrix(tx, ty)).max() < 1e-15
+        assert np.abs(M.reshape(3, 3) @ Mi.reshape(3, 3) - np.eye(3)).max() < 1e-15
+    worst_pose = 0.0
+    for case, dist in enumerate((np.array([0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3, 0.03, -0.02]),
+                                 np.array([0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, -0.05, 0.04]),
+                                 np.array([-0.2, 0.1, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.08, 0.0]))):
+        s = syn.Sequence(1280, 720, n_frames=3, seed=40 + case)
+        for k in range(3):
+            r, t = s.rvecs[k], s.tvecs[k]
+            img_o, jac_o = oracle.projectPoints(s.obj, r, t, s.K, dist, jacobian=True)
+            img_n, jac_n = P.project(s.obj, r, t, s.K, dist, jacobian=True)
+            assert np.abs(img_o.reshape(-1, 2) - img_n).max() < 1e-10
+            assert np.abs(jac_o - jac_n).max() < 1e-9 * max(1.0, np.abs(jac_o).max())
+            # the analytic Jacobian against central differences of the projection itself
+            p0 = np.concatenate([r, t])
+            for i in range(6):
+                d = np.zeros(6); d[i] = 1e-7
+                a = P.project(s.obj, (p0 + d)[:3], (p0 + d)[3:], s.K, dist); b = P.project(s.obj, (p0 - d)[:3], (p0 - d)[3:], s.K, dist)
+                assert np.abs(jac_o[:, i] - ((a - b) / 2e-7).ravel()).max() < 2e-4 * max(1.0, np.abs(jac_o[:, i]).max())
+            # the tilt is NOT a no-op: the same coefficients without it land elsewhere
+            assert np.abs(img_n - P.project(s.obj, r, t, s.K, dist[:12])).max() > 0.5
+            # undistortPoints: equal to the statement, and the inverse of the forward model (normalised coordinates of the rotated points)
+            un_o = oracle.undistortPoints(img_n, s.K, dist)
+            un_n = P.undistort_points(img_n, s.K, dist)
+            assert np.abs(un_o.reshape(-1, 2) - un_n).max() < 1e-13
+            Y = s.obj @ P.rodrigues(r)[0].T + t
+            assert np.abs(un_n - Y[:, :2] / Y[:, 2:3]).max() < (1e-9 if case == 1 else 1e-5)
+            # solvePnP with a guess: equal iteration counts, equal poses
+            noisy = img_n + rng.normal(0, 0.2, img_n.shape)
+            g_r = r + rng.normal(0, 0.05, 3); g_t = t + rng.normal(0, 0.01, 3)
+            r_n, t_n, it_n = P.solve_pnp_guess(s.obj, noisy, s.K, dist, g_r, g_t)
+            ok, r_o, t_o, it_o = oracle.solvePnP(s.obj, noisy, s.K, dist, g_r.copy(), g_t.copy(), True, return_iters=True)
+            assert ok and it_o == it_n
+            worst_pose = max(worst_pose, np.abs(r_o.ravel() - r_n).max(), np.abs(t_o.ravel() - t_n).max())
+            # ... and without one (planar model: the homography branch; undistortPoints feeds it)
+            ok, r_o, t_o = oracle.solvePnP(s.obj, img_n, s.K, dist)
+            assert ok and np.abs(r_o.ravel() - r).max() < 1e-6 and np.abs(t_o.ravel() - t).max() < 1e-6
+            r_n, t_n = P.solve_pnp_noguess(s.obj, noisy, s.K, dist)[:2]
+            ok, r_o, t_o = oracle.solvePnP(s.obj, noisy, s.K, dist)
+            assert ok
+            worst_pose = max(worst_pose, np.abs(r_o.ravel() - np.ravel(r_n)).max(), np.abs(t_o.ravel() - np.ravel(t_n)).max())
+    assert worst_pose < 2e-9, worst_pose

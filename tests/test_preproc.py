@@ -9,6 +9,10 @@ from accurate_aprilgroup_tracking_amd import synthetic as syn
 DISTS = [np.array([[-0.25, 0.1, 1e-3, -5e-4, -0.02]]), syn.MILD_DIST, np.array([[0.1, -0.05, 0.0, 0.0]]), None]
 
 
+# the full 14-coefficient model: rational radial, tangential, thin prism and a TILTED sensor (tau_x, tau_y in radians)
+TILTED_DIST = np.array([[0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3, 0.03, -0.02]])
+
+
 def _bgr(h, w, seed):
     rng = np.random.default_rng(seed)
     from scipy.ndimage import gaussian_filter
@@ -54,6 +58,11 @@ def _numpy_undistort_maps(K, dist, newK, w, h):
     kr = (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2) / (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2)
     xd = x * kr + k[2] * _2xy + k[3] * (r2 + 2 * x2) + k[8] * r2 + k[9] * r2 * r2
     yd = y * kr + k[2] * (r2 + 2 * y2) + k[3] * _2xy + k[10] * r2 + k[11] * r2 * r2
+    if k[12] != 0 or k[13] != 0:        # tilted sensor (tests/pnp_numpy.py tilt_matrix)
+        from tests.pnp_numpy import tilt_matrix
+        T = tilt_matrix(k[12], k[13])
+        hx, hy, hw = (T[q, 0] * xd + T[q, 1] * yd + T[q, 2] for q in range(3))
+        xd, yd = hx / hw, hy / hw
     iu = np.rint((K[0, 0] * xd + K[0, 2]) * 32).astype(np.int64); iv = np.rint((K[1, 1] * yd + K[1, 2]) * 32).astype(np.int64)
     m1 = np.stack([iu >> 5, iv >> 5], axis=-1).astype(np.int16)
     m2 = ((iv & 31) * 32 + (iu & 31)).astype(np.uint16)
@@ -86,7 +95,7 @@ def test_oracle_maps_and_remap_equal_numpy_statement(oracle):
         K = syn.camera_matrix(w, h)
         K[0, 2] += 2.3; K[1, 2] -= 1.1
         img = _bgr(h, w, seed)
-        for dist in DISTS[:3] + [np.array([[0.4, 0.3, 0.01, -0.02, 0.1]]), np.array([[0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3]])]:
+        for dist in DISTS[:3] + [np.array([[0.4, 0.3, 0.01, -0.02, 0.1]]), np.array([[0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3]]), TILTED_DIST]:
             newK, _ = oracle.getOptimalNewCameraMatrix(K, dist, (w, h), 1, (w, h))
             for nk in (newK, K):
                 m1, m2 = oracle.initUndistortRectifyMap(K, dist, nk, (w, h))
