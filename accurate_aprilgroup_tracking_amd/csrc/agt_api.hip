@@ -16,6 +16,7 @@
 // (3 per CU, eight barriers per tile) stream at 2.5 TB/s against 3.9 + 3.4 TB/s for two single-level passes (8 per CU): it is
 // used where the stage count matters (few streams), the two passes where throughput does (measured at 64 x 720p: 30.5 vs 25 us).
 #define AGT_PYR2_MAX_B 8
+#define AGT_TILT_SLOTS 8          // device table of tilted-sensor matrices: slot 0 the tracker's camera, 1.. the stateless calls'
 #define AGT_SPLIT_SLACK 2        // split mode: groups of extra ring entries (pyramid launches run that far ahead of LK)
 
 struct agt_ctx {
@@ -27,6 +28,7 @@ struct agt_ctx {
     int eff_max_level;                       // after OpenCV's early stop
     int lw[AGT_MAX_LEVELS], lh[AGT_MAX_LEVELS];
     long lpitch[AGT_MAX_LEVELS];             // levels >= 1 (context-owned)
+    double* d_tilt; double tilt_host[AGT_TILT_SLOTS][18]; int tilt_valid[AGT_TILT_SLOTS]; int tilt_next;   // tilted-sensor matrices (camera_on)
     uint8_t* lmem[AGT_RING_MAX][AGT_MAX_LEVELS];
     const uint8_t* l0_ptr[AGT_RING_MAX];
     long l0_pitch[AGT_RING_MAX], l0_bstride[AGT_RING_MAX];
@@ -109,16 +111,73 @@ int hip_fail(agt_ctx* c, hipError_t e)
     return AGT_ERR_HIP;
 }
 
-int fill_camera(const double* K, const double* dist, int ndist, AgtCameraHost* cam)
+// matTilt | invMatTilt of a coefficient vector (detail::computeTiltProjectionMatrix<double>, distortion_model.hpp; Matx products
+// accumulate s = 0; s += a * b): 14 coefficients = the 12 + the tilted-sensor angles (tau_x, tau_y), which cv2.calibrateCamera returns
+// non-zero only under CALIB_TILTED_MODEL -- the reference calibrates 5 coefficients, calibrate_camera.py:178
+void tilt_matrices(const double* dist, int ndist, AgtTiltHost* t)
+{
+    static const double I3[9] = { 1, 0, 0, 0, 1, 0, 0, 0, 1 };
+    memcpy(t->m, I3, sizeof(I3)); memcpy(t->m + 9, I3, sizeof(I3));
+    t->on = 0;
+    if (ndist != 14 || !dist || (dist[12] == 0.0 && dist[13] == 0.0)) return;
+    const double cX = cos(dist[12]), sX = sin(dist[12]), cY = cos(dist[13]), sY = sin(dist[13]);
+    const double rotX[9] = { 1, 0, 0, 0, cX, sX, 0, -sX, cX }, rotY[9] = { cY, 0, -sY, 0, 1, 0, sY, 0, cY };
+    auto mul = [](const double* A, const double* B, double* C) {
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) { double a = 0; for (int q = 0; q < 3; q++) a += A[i * 3 + q] * B[q * 3 + j]; C[i * 3 + j] = a; }
+    };
+    double rotXY[9];
+    mul(rotY, rotX, rotXY);
+    const double projZ[9] = { rotXY[8], 0, -rotXY[2], 0, rotXY[8], -rotXY[5], 0, 0, 1 };
+    mul(projZ, rotXY, t->m);
+    const double inv = 1. / rotXY[8];
+    const double invProjZ[9] = { inv, 0, inv * rotXY[2], 0, inv, inv * rotXY[5], 0, 0, 1 };
+    const double rt[9] = { rotXY[0], rotXY[3], rotXY[6], rotXY[1], rotXY[4], rotXY[7], rotXY[2], rotXY[5], rotXY[8] };
+    mul(rt, invProjZ, t->m + 9);
+    t->on = 1;
+}
+
+// camera of a call: intrinsics + the 12 polynomial coefficients by value; `tilt` (optional) receives the tilted-sensor matrices, the
+// struct's device pointer stays null (camera_on: the form with the matrices in the context's device table)
+int fill_camera(const double* K, const double* dist, int ndist, AgtCameraHost* cam, AgtTiltHost* tilt = nullptr)
 {
     if (!K) return AGT_ERR_ARG;
     if (!(ndist == 0 || ndist == 4 || ndist == 5 || ndist == 8 || ndist == 12 || ndist == 14)) return AGT_ERR_DIST;
     if (ndist > 0 && !dist) return AGT_ERR_ARG;
-    // 14 coefficients = the 12 + the tilted-sensor angles (tau_x, tau_y): accepted when the tilt is zero (what
-    // calibrateCamera returns unless CALIB_TILTED_MODEL is set); a tilted sensor model is not built
-    if (ndist == 14 && (dist[12] != 0.0 || dist[13] != 0.0)) return AGT_ERR_DIST;
     cam->fx = K[0]; cam->fy = K[4]; cam->cx = K[2]; cam->cy = K[5];
     for (int i = 0; i < 12; i++) cam->k[i] = i < ndist ? dist[i] : 0.0;
+    cam->tilt = nullptr;
+    if (tilt) tilt_matrices(dist, ndist, tilt);
+    return AGT_OK;
+}
+
+// ... for a launch of context c.  A tilted camera's matrices go to a slot of the context's device table (AGT_TILT_SLOTS x 18 doubles):
+// slot 0 belongs to the tracker (written at agt_tracker_init, behind a stream synchronisation: the tracker's internal streams read
+// it), slots 1.. serve the stateless calls round-robin -- a slot that already holds the same matrices is re-used without a copy, a new
+// camera's copy is ordered on the context's stream behind every launch that read the slot's previous content.
+int camera_on(agt_ctx* c, const double* K, const double* dist, int ndist, AgtCameraHost* cam, bool tracker = false)
+{
+    AgtTiltHost t;
+    int rc = fill_camera(K, dist, ndist, cam, &t);
+    if (rc || !t.on) return rc;
+    if (!c->d_tilt) {
+        if (hipMalloc((void**)&c->d_tilt, sizeof(double) * 18 * AGT_TILT_SLOTS) != hipSuccess) { (void)hipGetLastError(); return AGT_ERR_ALLOC; }
+        memset(c->tilt_valid, 0, sizeof(c->tilt_valid));
+    }
+    int slot = 0;
+    if (!tracker) {
+        slot = -1;
+        for (int i = 1; i < AGT_TILT_SLOTS; i++) if (c->tilt_valid[i] && !memcmp(c->tilt_host[i], t.m, sizeof(t.m))) { slot = i; break; }
+        if (slot < 0) { c->tilt_next = c->tilt_next % (AGT_TILT_SLOTS - 1) + 1; slot = c->tilt_next; c->tilt_valid[slot] = 0; }
+    }
+    if (!c->tilt_valid[slot] || memcmp(c->tilt_host[slot], t.m, sizeof(t.m))) {
+        memcpy(c->tilt_host[slot], t.m, sizeof(t.m));
+        hipError_t e = hipMemcpyAsync(c->d_tilt + 18 * slot, c->tilt_host[slot], sizeof(t.m), hipMemcpyHostToDevice, c->stream);
+        if (e == hipSuccess && tracker) e = hipStreamSynchronize(c->stream);
+        if (e != hipSuccess) return hip_fail(c, e);
+        c->tilt_valid[slot] = 1;
+    }
+    cam->tilt = c->d_tilt + 18 * slot;
     return AGT_OK;
 }
 
@@ -220,7 +279,7 @@ const char* agt_error_string(int code)
     case AGT_OK: return "ok";
     case AGT_ERR_ARG: return "invalid argument";
     case AGT_ERR_ALLOC: return "allocation failed";
-    case AGT_ERR_DIST: return "unsupported distortion coefficient count";
+    case AGT_ERR_DIST: return "unsupported distortion coefficient count (0, 4, 5, 8, 12 or 14)";
     case AGT_ERR_NPOINTS: return "bad point count";
     case AGT_ERR_HIP: return "HIP runtime error";
     case AGT_ERR_UNSUPPORTED: return "unsupported configuration";
@@ -334,6 +393,7 @@ int agt_destroy(agt_ctx* c)
     if (c->fault_host) (void)hipHostFree(c->fault_host);
     if (c->dense_partials) (void)hipFree(c->dense_partials);
     if (c->dense_done) (void)hipFree(c->dense_done);
+    if (c->d_tilt) (void)hipFree(c->d_tilt);
     if (c->map1) (void)hipFree(c->map1);
     if (c->map2) (void)hipFree(c->map2);
     if (c->prof_ev) {
@@ -527,7 +587,7 @@ int agt_solve_pnp(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, const 
     if (!use_guess && n < 4) return AGT_ERR_NPOINTS;
     AgtPnpParams p;
     memset(&p, 0, sizeof(p));
-    int rc = fill_camera(K, dist, ndist, &p.cam);
+    int rc = camera_on(c, K, dist, ndist, &p.cam);
     if (rc) return rc;
     p.obj = d_obj; p.obj_bstride = (long)obj_batch_stride; p.img = d_img; p.mask = d_mask; p.dtype = dtype;
     p.n = n; p.use_guess = use_guess ? 1 : 0; p.pose = d_pose; p.info = d_info; p.err = d_err;
@@ -544,7 +604,7 @@ int agt_project_points(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, i
     if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
     AgtProjParams p;
     memset(&p, 0, sizeof(p));
-    int rc = fill_camera(K, dist, ndist, &p.cam);
+    int rc = camera_on(c, K, dist, ndist, &p.cam);
     if (rc) return rc;
     p.obj = d_obj; p.obj_bstride = (long)obj_batch_stride; p.dtype = dtype; p.n = n; p.pose = d_pose;
     p.img_out = d_img_out; p.jac = d_jac;
@@ -568,7 +628,7 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
         if (es != hipSuccess) return hip_fail(c, es);
         *(volatile int*)c->fault_host = 0;
     }
-    rc = fill_camera(K, dist, ndist, &c->cam);
+    rc = camera_on(c, K, dist, ndist, &c->cam, true);
     if (rc) return rc;
     hipError_t e = hipSuccess;
     // the tracker's frame 0 lives in ring entry 0: adopt the caller's slot as pyramid slot 0
@@ -1490,12 +1550,20 @@ int agt_tracker_buffers(const agt_ctx* c, const float** d_corners, const uint8_t
 namespace {
 
 // cvUndistortPointsInternal for one point, R = I, optional new camera matrix P, 5 fixed iterations
-void undistort_point_host(double u, double v, const double* K, const double* k, bool has_dist, const double* P,
+void undistort_point_host(double u, double v, const double* K, const AgtCameraHost& cam, const AgtTiltHost& tilt, bool has_dist, const double* P,
                           double* ox, double* oy)
 {
+    const double* k = cam.k;
     const double ifx = 1. / K[0], ify = 1. / K[4], cx = K[2], cy = K[5];
     double x = (u - cx) * ifx, y = (v - cy) * ify;
     if (has_dist) {
+        if (tilt.on) {          // compensate tilt distortion: invMatTilt (x, y, 1), dehomogenised
+            const double* M = tilt.m + 9;
+            double t[3];
+            for (int r = 0; r < 3; r++) { double a = 0; a += M[r * 3] * x; a += M[r * 3 + 1] * y; a += M[r * 3 + 2] * 1; t[r] = a; }
+            const double ip = t[2] ? 1. / t[2] : 1;
+            x = ip * t[0]; y = ip * t[1];
+        }
         const double x0 = x, y0 = y;
         for (int it = 0; it < 5; it++) {
             const double r2 = x * x + y * y;
@@ -1516,7 +1584,7 @@ void undistort_point_host(double u, double v, const double* K, const double* k, 
 
 // calibration.cpp icvGetRectangles: inscribed / circumscribed rectangles of the undistorted 9x9 grid (float)
 struct RectF { float x, y, w, h; };
-void grid_rectangles(const double* K, const double* k, bool has_dist, const double* P, int w, int h, RectF* inner, RectF* outer)
+void grid_rectangles(const double* K, const AgtCameraHost& cam, const AgtTiltHost& tilt, bool has_dist, const double* P, int w, int h, RectF* inner, RectF* outer)
 {
     const int N = 9;
     float in_l = -FLT_MAX, in_r = FLT_MAX, in_t = -FLT_MAX, in_b = FLT_MAX;
@@ -1525,7 +1593,7 @@ void grid_rectangles(const double* K, const double* k, bool has_dist, const doub
         for (int gx = 0; gx < N; gx++) {
             const float px = (float)gx * w / (N - 1), py = (float)gy * h / (N - 1);
             double ux, uy;
-            undistort_point_host((double)px, (double)py, K, k, has_dist, P, &ux, &uy);
+            undistort_point_host((double)px, (double)py, K, cam, tilt, has_dist, P, &ux, &uy);
             const float qx = (float)ux, qy = (float)uy;
             out_l = qx < out_l ? qx : out_l; out_r = qx > out_r ? qx : out_r;
             out_t = qy < out_t ? qy : out_t; out_b = qy > out_b ? qy : out_b;
@@ -1558,13 +1626,14 @@ int agt_get_optimal_new_camera_matrix(const double* K, const double* dist, int n
 {
     if (!K || !newK || w <= 0 || h <= 0) return AGT_ERR_ARG;
     AgtCameraHost cam;
-    int rc = fill_camera(K, dist, ndist, &cam);
+    AgtTiltHost tilt;
+    int rc = fill_camera(K, dist, ndist, &cam, &tilt);
     if (rc) return rc;
     const bool has_dist = dist != nullptr && ndist > 0;
     if ((long)new_w * new_h == 0) { new_w = w; new_h = h; }
     alpha = alpha < 0. ? 0. : alpha > 1. ? 1. : alpha;
     RectF inner, outer;
-    grid_rectangles(K, cam.k, has_dist, nullptr, w, h, &inner, &outer);
+    grid_rectangles(K, cam, tilt, has_dist, nullptr, w, h, &inner, &outer);
     const double fx0 = (new_w - 1) / inner.w, fy0 = (new_h - 1) / inner.h;     // int / float, as OpenCV
     const double cx0 = -fx0 * inner.x, cy0 = -fy0 * inner.y;
     const double fx1 = (new_w - 1) / outer.w, fy1 = (new_h - 1) / outer.h;
@@ -1575,7 +1644,7 @@ int agt_get_optimal_new_camera_matrix(const double* K, const double* dist, int n
     newK[2] = cx0 * (1 - alpha) + cx1 * alpha;
     newK[5] = cy0 * (1 - alpha) + cy1 * alpha;
     if (roi) {
-        grid_rectangles(K, cam.k, has_dist, newK, w, h, &inner, &outer);
+        grid_rectangles(K, cam, tilt, has_dist, newK, w, h, &inner, &outer);
         const int rx = (int)lrintf(inner.x), ry = (int)lrintf(inner.y), rw = (int)lrintf(inner.w), rh = (int)lrintf(inner.h);
         const int x1 = rx > 0 ? rx : 0, y1 = ry > 0 ? ry : 0;
         const int x2 = rx + rw < new_w ? rx + rw : new_w, y2 = ry + rh < new_h ? ry + rh : new_h;
@@ -1590,7 +1659,8 @@ int agt_undistort_init(agt_ctx* c, const double* K, const double* dist, int ndis
 {
     if (!c || !K || w <= 0 || h <= 0 || w > 32767 || h > 32767) return AGT_ERR_ARG;
     AgtCameraHost cam;
-    int rc = fill_camera(K, dist, ndist, &cam);
+    AgtTiltHost tilt;
+    int rc = fill_camera(K, dist, ndist, &cam, &tilt);
     if (rc) return rc;
     double ir[9];
     if (!invert3(newK ? newK : K, ir)) return AGT_ERR_ARG;
@@ -1607,7 +1677,7 @@ int agt_undistort_init(agt_ctx* c, const double* K, const double* dist, int ndis
         }
         c->map_w = w; c->map_h = h;
     }
-    hipError_t e = agt_launch_undistort_map(c->stream, K, cam.k, ir, w, h, c->map1, c->map2);
+    hipError_t e = agt_launch_undistort_map(c->stream, K, cam, tilt, ir, w, h, c->map1, c->map2);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
 }
 
@@ -1658,7 +1728,7 @@ int agt_dense_refine(agt_ctx* c, const uint8_t* d_img, size_t pitch, size_t batc
     if (M < 0 || N < 0 || (M > 0 && (!d_model_xyz || !d_model_t)) || (N > 0 && (!d_obj || !d_img_pts))) return AGT_ERR_ARG;
     if (M + N == 0 || pitch < (size_t)w || !(photo_weight >= 0.0)) return AGT_ERR_ARG;
     AgtCameraHost cam;
-    int rc = fill_camera(K, dist, ndist, &cam);
+    int rc = camera_on(c, K, dist, ndist, &cam);
     if (rc) return rc;
     rc = dense_scratch(c, agt_dense_doubles(M, B), B);
     if (rc) return rc;

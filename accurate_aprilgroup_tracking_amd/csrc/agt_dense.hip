@@ -101,6 +101,7 @@ __global__ __launch_bounds__(256) void dense_accum_kernel(const DenseParams P)
     bool has_dist = false;
 #pragma unroll
     for (int k = 0; k < 12; k++) has_dist |= cam.k[k] != 0.0;
+    has_dist |= cam.tilt != nullptr;
     double R[9], G[9];
     agt_rodrigues<true>(param, R, G);
     DSTAMP(2);

@@ -176,7 +176,27 @@ __device__ __forceinline__ void agt_rodrigues(const double r_in[3], double R[9],
 struct AgtCamera {
     double fx, fy, cx, cy;
     double k[12];     // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+    // tilted sensor (tau_x, tau_y != 0): where matTilt / invMatTilt live (row-major, 9 + 9 doubles, uniform); null = no tilt.  Read only
+    // inside the `if (cam.tilt)` branches of the distortion paths, so a camera without tilt costs a scalar compare per projection.
+    const double* tilt;
 };
+
+// vecTilt = M (x, y, 1) dehomogenised, in OpenCV's accumulation order (s = 0; s += m * v); d: optional 2 x 2 Jacobian
+__device__ __forceinline__ void agt_tilt_apply(const double* M, double x, double y, double& xo, double& yo, double* d)
+{
+    double v[3];
+#pragma unroll
+    for (int r = 0; r < 3; r++) { double a = 0.0; a += M[r * 3] * x; a += M[r * 3 + 1] * y; a += M[r * 3 + 2] * 1.0; v[r] = a; }
+    const double ip = v[2] != 0.0 ? 1.0 / v[2] : 1.0;
+    xo = ip * v[0]; yo = ip * v[1];
+    if (d) {
+        const double ip2 = ip * ip;
+#pragma unroll
+        for (int r = 0; r < 2; r++)
+#pragma unroll
+            for (int c = 0; c < 2; c++) d[r * 2 + c] = (M[r * 3 + c] * v[2] - M[6 + c] * v[r]) * ip2;
+    }
+}
 
 // cvProjectPoints2Internal for one point.  jr/jt: rows (du/d., dv/d.) x 3.
 // DIST = false is the exact specialisation for all-zero distortion coefficients (every term it
@@ -220,6 +240,10 @@ __device__ __forceinline__ void agt_project(const AgtCamera& cam, const double R
     double icdist2 = 1.0 / (1 + k[5] * r2 + k[6] * r4 + k[7] * r6);
     double xd = x * cdist * icdist2 + k[2] * a1 + k[3] * a2 + k[8] * r2 + k[9] * r4;
     double yd = y * cdist * icdist2 + k[2] * a3 + k[3] * a1 + k[10] * r2 + k[11] * r4;
+    // additional distortion by projecting onto a tilt plane (cvProjectPoints2Internal); dT = d(xd, yd)_tilted / d(xd, yd)
+    double dT[4] = { 1.0, 0.0, 0.0, 1.0 };
+    const bool tilted = cam.tilt != nullptr;
+    if (tilted) agt_tilt_apply(cam.tilt, xd, yd, xd, yd, JAC ? dT : nullptr);
     u = xd * cam.fx + cam.cx;
     v = yd * cam.fy + cam.cy;
     if (JAC) {
@@ -234,6 +258,7 @@ __device__ __forceinline__ void agt_project(const AgtCamera& cam, const double R
                             k[2] * da1dt + k[3] * (dr2dt + 4 * x * dxdt[j]) + k[8] * dr2dt + 2 * r2 * k[9] * dr2dt);
             double dmydt = (dydt[j] * cdist * icdist2 + y * dcdist_dt * icdist2 + y * cdist * dicdist2_dt +
                             k[2] * (dr2dt + 4 * y * dydt[j]) + k[3] * da1dt + k[10] * dr2dt + 2 * r2 * k[11] * dr2dt);
+            if (tilted) { const double a = dmxdt, b = dmydt; dmxdt = (0.0 + dT[0] * a) + dT[1] * b; dmydt = (0.0 + dT[2] * a) + dT[3] * b; }
             jt[j] = cam.fx * dmxdt;
             jt[3 + j] = cam.fy * dmydt;
         }
@@ -257,6 +282,7 @@ __device__ __forceinline__ void agt_project(const AgtCamera& cam, const double R
                             k[2] * da1dr + k[3] * (dr2dr + 4 * x * dxdr) + (k[8] + 2 * r2 * k[9]) * dr2dr);
             double dmydr = (dydr * cdist * icdist2 + y * dcdist_dr * icdist2 + y * cdist * dicdist2_dr +
                             k[2] * (dr2dr + 4 * y * dydr) + k[3] * da1dr + (k[10] + 2 * r2 * k[11]) * dr2dr);
+            if (tilted) { const double a = dmxdr, b = dmydr; dmxdr = (0.0 + dT[0] * a) + dT[1] * b; dmydr = (0.0 + dT[2] * a) + dT[3] * b; }
             jr[j] = cam.fx * dmxdr;
             jr[3 + j] = cam.fy * dmydr;
         }

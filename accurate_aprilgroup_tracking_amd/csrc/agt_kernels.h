@@ -72,7 +72,14 @@ struct AgtLkParams {
 struct AgtCameraHost {
     double fx, fy, cx, cy;
     double k[12];
+    // tilted sensor (coefficients 13, 14 = tau_x, tau_y; round 5): DEVICE pointer to matTilt | invMatTilt (2 x 9 doubles, row-major, as
+    // detail::computeTiltProjectionMatrix builds them), null without tilt.  In global memory, not in this by-value struct: loads from the
+    // kernel-argument segment are speculated in front of the `if (tilt)` branches and the 36 scalar registers they fill cost the fused
+    // step kernel 86 more spilled SGPRs (measured); a load through a pointer that may be null stays inside its branch.
+    const double* tilt;
 };
+// the same matrices on the host (agt_api.hip fill_camera): m = matTilt | invMatTilt, on = 0: identities
+struct AgtTiltHost { double m[18]; int on; };
 
 struct AgtPnpParams {
     const void* obj;          // n x 3, f32 or f64
@@ -208,7 +215,7 @@ hipError_t agt_launch_lk_hybrid(hipStream_t stream, const AgtLkParams& p, int B)
 hipError_t agt_launch_pnp(hipStream_t stream, const AgtPnpParams& p, int B, const AgtPyrArgs* ride = nullptr);
 bool agt_pnp_can_ride(int n);
 hipError_t agt_launch_project(hipStream_t stream, const AgtProjParams& p, int B);
-hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,
+hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const AgtCameraHost& cam, const AgtTiltHost& tilt, const double* ir,
                                     int w, int h, short2* map1, unsigned short* map2);
 hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long spitch, long sbatch, int sw, int sh,
                                  const short2* map1, const unsigned short* map2, int mw,
@@ -216,7 +223,7 @@ hipError_t agt_launch_preprocess(hipStream_t stream, const uint8_t* src, long sp
                                  int undistort, int gray, int B);
 // The dense stage's last step (final Gauss-Newton update + corner re-seed) handed on to the LK launch of the NEXT frame instead of
 // being launched: the stage's parameter block as agt_dense.hip fills it (opaque here; agt_step.hip agt_launch_lk_reseed reads it)
-struct AgtDenseFinal { alignas(8) unsigned char bytes[768]; };
+struct AgtDenseFinal { alignas(8) unsigned char bytes[776]; };
 hipError_t agt_launch_lk_reseed(hipStream_t stream, const struct AgtStepParams& S, const struct AgtStepTables& T, int win, const AgtDenseFinal* F, const struct AgtPyrArgs* ride = nullptr);
 hipError_t agt_launch_dense_final(hipStream_t stream, const AgtDenseFinal& F, int B);      // the deferred step as its own launch after all
 hipError_t agt_launch_dense(hipStream_t stream, const uint8_t* img, long pitch, long ibatch, int w, int h,

@@ -174,6 +174,7 @@ __device__ __forceinline__ void load_cam(const AgtCameraHost& h, AgtCamera& c)
     c.fx = h.fx; c.fy = h.fy; c.cx = h.cx; c.cy = h.cy;
 #pragma unroll
     for (int i = 0; i < 12; i++) c.k[i] = h.k[i];
+    c.tilt = h.tilt;
 }
 
 // cvUndistortPointsInternal, criteria (COUNT, 5), R = I, no P
@@ -181,11 +182,13 @@ __device__ __forceinline__ void undistort5(const AgtCamera& cam, double u, doubl
 {
     const double* k = cam.k;
     double x = (u - cam.cx) * (1.0 / cam.fx), y = (v - cam.cy) * (1.0 / cam.fy);
+    const double xr = x, yr = y;
+    if (cam.tilt) agt_tilt_apply(cam.tilt + 9, x, y, x, y, nullptr);       // compensate tilt distortion (invMatTilt)
     const double x0 = x, y0 = y;
     for (int j = 0; j < 5; j++) {
         double r2 = x * x + y * y;
         double icdist = (1 + ((k[7] * r2 + k[6]) * r2 + k[5]) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2);
-        if (icdist < 0) { x = x0; y = y0; break; }
+        if (icdist < 0) { x = xr; y = yr; break; }
         double deltaX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x) + k[8] * r2 + k[9] * r2 * r2;
         double deltaY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y + k[10] * r2 + k[11] * r2 * r2;
         x = (x0 - deltaX) * icdist;
@@ -1012,6 +1015,7 @@ __device__ __forceinline__ void pnp_body(const AgtPnpParams& P, int b, PnpShared
     bool has_dist = false;
 #pragma unroll
     for (int i = 0; i < 12; i++) has_dist |= cam.k[i] != 0.0;
+    has_dist |= cam.tilt != nullptr;
     double rex[PPL], rey[PPL];       // residuals of the most recent evaluation (re-used by the epilogue)
 #pragma unroll
     for (int q = 0; q < PPL; q++) { rex[q] = 0.0; rey[q] = 0.0; }

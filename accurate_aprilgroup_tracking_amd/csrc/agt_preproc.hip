@@ -24,6 +24,8 @@ struct MapParams {
     double ir[9];                 // inverse of the new camera matrix
     double fx, fy, u0, v0;        // original camera
     double k[12];                 // k1 k2 p1 p2 k3 k4 k5 k6 s1 s2 s3 s4
+    double tilt[9];               // matTilt (tilted sensor, coefficients 13 / 14); read when has_tilt
+    int has_tilt, rsv_;
     int w, h;
     short2* map1;
     unsigned short* map2;
@@ -42,7 +44,16 @@ __global__ __launch_bounds__(256) void undistort_map_kernel(const MapParams P)
     const double kr = (1 + ((k3 * r2 + k2) * r2 + k1) * r2) / (1 + ((k6 * r2 + k5) * r2 + k4) * r2);
     const double xd = (x * kr + p1 * _2xy + p2 * (r2 + 2 * x2) + P.k[8] * r2 + P.k[9] * r2 * r2);
     const double yd = (y * kr + p1 * (r2 + 2 * y2) + p2 * _2xy + P.k[10] * r2 + P.k[11] * r2 * r2);
-    const double us = (P.fx * xd + P.u0) * INTER_TAB, vs = (P.fy * yd + P.v0) * INTER_TAB;
+    double u = P.fx * xd + P.u0, v = P.fy * yd + P.v0;
+    if (P.has_tilt) {
+        // vecTilt = matTilt (xd, yd, 1); u = fx * invProj * vecTilt(0) + u0 (initUndistortRectifyMap's own order of operations)
+        double t[3];
+#pragma unroll
+        for (int r = 0; r < 3; r++) { double a = 0.0; a += P.tilt[r * 3] * xd; a += P.tilt[r * 3 + 1] * yd; a += P.tilt[r * 3 + 2] * 1.0; t[r] = a; }
+        const double ip = t[2] != 0.0 ? 1. / t[2] : 1.0;
+        u = P.fx * ip * t[0] + P.u0; v = P.fy * ip * t[1] + P.v0;
+    }
+    const double us = u * INTER_TAB, vs = v * INTER_TAB;
     const int iu = us >= 2147483647. ? 2147483647 : us <= -2147483648. ? (-2147483647 - 1) : __double2int_rn(us);
     const int iv = vs >= 2147483647. ? 2147483647 : vs <= -2147483648. ? (-2147483647 - 1) : __double2int_rn(vs);
     const long o = (long)i * P.w + j;
@@ -231,13 +242,15 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const RemapParams P)
 
 }  // namespace
 
-hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const double* k12, const double* ir,
+hipError_t agt_launch_undistort_map(hipStream_t stream, const double* K, const AgtCameraHost& cam, const AgtTiltHost& tilt, const double* ir,
                                     int w, int h, short2* map1, unsigned short* map2)
 {
     MapParams P;
     for (int i = 0; i < 9; i++) P.ir[i] = ir[i];
     P.fx = K[0]; P.fy = K[4]; P.u0 = K[2]; P.v0 = K[5];
-    for (int i = 0; i < 12; i++) P.k[i] = k12[i];
+    for (int i = 0; i < 12; i++) P.k[i] = cam.k[i];
+    for (int i = 0; i < 9; i++) P.tilt[i] = tilt.m[i];
+    P.has_tilt = tilt.on; P.rsv_ = 0;
     P.w = w; P.h = h; P.map1 = map1; P.map2 = map2;
     hipLaunchKernelGGL(undistort_map_kernel, dim3((w + 255) / 256, h), dim3(256), 0, stream, P);
     return hipGetLastError();

@@ -53,6 +53,10 @@ extern "C" int agt_debug_role_stamps(unsigned long long* host) { return (int)hip
 #define AGT_LKG_OCC 4            // waves per SIMD the one-wave-per-corner LK group kernel is register-allocated for (4: 128 VGPRs)
 #endif
 
+// (defined in the translation unit compiled without MachineLICM: see pnp_group_coop_kernel below)
+hipError_t agt_launch_pnp_group_coop(hipStream_t stream, const AgtStepParams& P, const AgtStepTables& T);
+hipError_t agt_launch_step_deep(hipStream_t stream, const AgtStepParams& P, const AgtStepTables& T, int nw, int blocks, size_t lds);
+
 namespace {
 
 // ---- LK role: workgroup `blk` of the role, THREADS threads.  NW = 4: the workgroup is one corner; NW = 1: each wave is
@@ -428,11 +432,13 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     lk_role<WIN, NW, NLEV, AGT_WAVE * NW, true>(S, T, kernarg_params(), kernarg_tables(), blockIdx.x, lds);
 }
 
+#ifndef AGT_STEP_NOLICM_TU
 __global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     pyr_role<true>(kernarg_params(), kernarg_tables(), blockIdx.x, 0, lds);
 }
+#endif
 
 // PPL: points per lane (n <= 64 * PPL)
 template <int PPL>
@@ -442,12 +448,21 @@ __global__ __launch_bounds__(AGT_WAVE) void pnp_group_kernel(const AgtStepParams
     pnp_role<PPL>(S, T, kernarg_tables(), blockIdx.x, sh);
 }
 
+// ---- The two kernels of this file that are compiled WITHOUT the machine-level loop-invariant code motion (agt_step_nolicm.hip
+// includes this file with AGT_STEP_NOLICM_TU defined; Makefile: -mllvm -disable-machine-licm): both run a FRAME loop around whole
+// solver / tracker bodies, and the FP64 constants (register PAIRS: not rematerialisable) and addresses MachineLICM hoists in front
+// of that loop stay alive across everything inside it -- pnp_group_coop_kernel 512 VGPRs + 376 B of scratch -> 382 / none (with the
+// per-frame opaque inputs of pnp_role_coop), step_kernel<21,4,6> 501 VGPRs / 16 B -> 408 / none.  Everything else keeps the pass:
+// the 20-frame c2 blocks lose 0.5 % without it (67.8 k against 68.2 k frames/s, three same-box runs each; profiles/r05_experiments.md).
+#ifdef AGT_STEP_NOLICM_TU
 __global__ __launch_bounds__(AGT_WAVE * PNP_COOP) void pnp_group_coop_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     __shared__ agt_pnp::PnpShared sh;
     pnp_role_coop(S, T, kernarg_tables(), blockIdx.x, sh);
 }
+#endif
 
+#ifndef AGT_STEP_NOLICM_TU
 // roles: AGT_STEP_ALL = one fused launch; AGT_STEP_PYR / AGT_STEP_LK = that role alone, from the kernel compiled without
 // the FP64 PnP role (the one-wave-per-corner LK keeps its four waves per SIMD; each launch sizes its own LDS);
 // AGT_STEP_PNP = the PnP role alone
@@ -473,7 +488,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 #ifdef AGT_DEBUG_KNOBS
         { static const int f = [] { const char* e = getenv("AGT_PNP_COOP_GROUP"); return e ? atoi(e) : 1; }(); group = f != 0; }
 #endif
-        if (group) { hipLaunchKernelGGL(pnp_group_coop_kernel, dim3(P.n_pnp), dim3(AGT_WAVE * PNP_COOP), 0, stream, P, T); return hipGetLastError(); }
+        if (group) return agt_launch_pnp_group_coop(stream, P, T);
         for (int k = 0; k < P.pnp_nf; k++) {
             if (T.pnp.wait[k]) return hipErrorInvalidValue;          // (split launches are ordered by events: no in-kernel wait to honour)
             AgtPnpParams q = P.pnp;
@@ -558,14 +573,34 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
     else {
 #endif
     if (small) hipLaunchKernelGGL((step_kernel<WIN, NW, 3, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
-    else hipLaunchKernelGGL((step_kernel<WIN, NW, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    else return agt_launch_step_deep(stream, P, T, NW, blocks, lds);
     return hipGetLastError();
 #ifndef AGT_DEBUG_KNOBS
     }
 #endif
 }
+#endif      // !AGT_STEP_NOLICM_TU
 
 }  // namespace
+
+#ifdef AGT_STEP_NOLICM_TU
+hipError_t agt_launch_pnp_group_coop(hipStream_t stream, const AgtStepParams& P, const AgtStepTables& T)
+{
+    hipLaunchKernelGGL(pnp_group_coop_kernel, dim3(P.n_pnp), dim3(AGT_WAVE * PNP_COOP), 0, stream, P, T);
+    return hipGetLastError();
+}
+
+// the fused step of pyramids with more than three levels (cv2's default maxLevel = 3 is four)
+hipError_t agt_launch_step_deep(hipStream_t stream, const AgtStepParams& P, const AgtStepTables& T, int nw, int blocks, size_t lds)
+{
+#ifdef AGT_DEBUG_KNOBS      // (the one-wave-per-corner fused kernel: knobs build only, see launch_step_t)
+    if (nw == 1) { hipLaunchKernelGGL((step_kernel<21, 1, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T); return hipGetLastError(); }
+#endif
+    if (nw != 4) return hipErrorInvalidValue;
+    hipLaunchKernelGGL((step_kernel<21, 4, AGT_MAX_LEVELS, true, 1>), dim3(blocks), dim3(STEP_THREADS), lds, stream, P, T);
+    return hipGetLastError();
+}
+#else
 
 bool agt_step_supported(int win) { return win == 21; }
 // Fused launch (all roles in one kernel, PnP chained to LK through arrival counters) while <= 256 corners are in flight:
@@ -590,3 +625,4 @@ hipError_t agt_launch_step(hipStream_t stream, const AgtStepParams& S, const Agt
     const bool wide = S.n_lk > 0 ? agt_lk_wide(S.lk.n, S.lk_B) : true;
     return wide ? launch_step_t<21, 4>(stream, S, T, roles) : launch_step_t<21, 1>(stream, S, T, roles);
 }
+#endif      // !AGT_STEP_NOLICM_TU

@@ -39,7 +39,7 @@ extern "C" {
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
 #define AGT_ERR_ALLOC       (-2)
-#define AGT_ERR_DIST        (-3)   /* distortion count not in {0,4,5,8,12} */
+#define AGT_ERR_DIST        (-3)   /* distortion count not in {0,4,5,8,12,14} */
 #define AGT_ERR_NPOINTS     (-4)   /* too few / too many points */
 #define AGT_ERR_HIP         (-5)   /* a HIP runtime call failed; see agt_last_hip_error */
 #define AGT_ERR_UNSUPPORTED (-6)   /* e.g. LK window size not compiled in */
@@ -153,7 +153,9 @@ int agt_lk_track(agt_ctx* ctx, int prev_slot, int next_slot,
 /* d_obj: n x 3 (obj_batch_stride = 0: shared by all B) or [B][n][3] (stride in elements).
  * d_img: [B][n][2].  dtype: AGT_F32 / AGT_F64 for both arrays.
  * d_mask: [B][n] u8 (0 = skip the point, e.g. LK status) or NULL.
- * K: 9 host doubles row-major.  dist: ndist host doubles (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4 [tau_x tau_y = 0]]]]) or NULL.
+ * K: 9 host doubles row-major.  dist: ndist host doubles (k1 k2 p1 p2 [k3 [k4 k5 k6 [s1..s4 [tau_x tau_y]]]]) or NULL -- cv2's
+ * 4 / 5 / 8 / 12 / 14-coefficient models; tau_x, tau_y: the tilted-sensor term (what calibrateCamera returns under CALIB_TILTED_MODEL),
+ * applied wherever cv2 applies it: projectPoints and its Jacobian, undistortPoints, the undistortion maps, getOptimalNewCameraMatrix.
  * d_pose: [B][6] f64 (rvec, tvec): read when use_guess, always written on success
  * (cv2 overwrites the guess arrays in place too, detect_pose.py:487-490).
  * d_info: [B][4] i32 (AGT_INFO_*), d_err: [B] f64 mean reprojection error; either may be NULL. */

@@ -458,7 +458,7 @@ def test_solve_pnp_planar_two_minima(torch_cuda, cvh, oracle):
 
 
 def test_distortion_coefficient_counts(cvh, oracle):
-    """cv2 accepts 4, 5, 8, 12 or 14 coefficients; 14 = 12 + sensor tilt, accepted here with zero tilt"""
+    """cv2 accepts 4, 5, 8, 12 or 14 coefficients; 14 = 12 + sensor tilt (tau_x, tau_y)"""
     from accurate_aprilgroup_tracking_amd import synthetic as syn
     K = syn.camera_matrix(640, 480)
     rng = np.random.default_rng(2)
@@ -472,8 +472,9 @@ def test_distortion_coefficient_counts(cvh, oracle):
         assert np.abs(rv - ro).max() < 1e-8 and np.abs(tv - to).max() < 1e-8
     ok, rv, tv = cvh.solvePnP(obj, img, K, np.r_[d12, 0.0, 0.0])
     assert np.array_equal(rv, ref[1]) and np.array_equal(tv, ref[2])
-    with pytest.raises(ValueError):
-        cvh.solvePnP(obj, img, K, np.r_[d12, 0.01, 0.0])        # tilted sensor model: not built
+    ok, rv, tv = cvh.solvePnP(obj, img, K, np.r_[d12, 0.01, 0.0])        # tilted sensor: built in round 5 (tests/test_gpu_tilt.py)
+    _, ro, to = oracle.solvePnP(obj, img, K, np.r_[d12, 0.01, 0.0])
+    assert ok and np.abs(rv - ro).max() < 1e-8 and np.abs(tv - to).max() < 1e-8 and np.abs(rv - ref[1]).max() > 1e-4
     with pytest.raises(ValueError):
         cvh.solvePnP(obj, img, K, d12[:7])
 

@@ -7,11 +7,11 @@ cd "$(dirname "$0")/../accurate_aprilgroup_tracking_amd/csrc"
 make -s -j8 knobs
 mkdir -p ../../tools/_exp/$name
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=gfx950 -ffp-contract=off -fno-fast-math -Wall -Wno-unused-function -DAGT_DEBUG_KNOBS $extra"
-STEPFLAGS="${STEPFLAGS--mllvm -disable-machine-licm}"     # (as the Makefile: agt_step.hip only)
+STEPFLAGS="${STEPFLAGS--mllvm -disable-machine-licm}"     # (as the Makefile: agt_step_nolicm.hip only)
 objs=""
-for f in agt_api agt_pyramid agt_lk agt_pnp agt_step agt_step_dense agt_preproc agt_dense; do
+for f in agt_api agt_pyramid agt_lk agt_pnp agt_step agt_step_nolicm agt_step_dense agt_preproc agt_dense; do
   if [[ " $* " == *" $f.hip "* ]]; then
-    sf=""; [[ $f == agt_step ]] && sf=$STEPFLAGS
+    sf=""; [[ $f == agt_step_nolicm ]] && sf=$STEPFLAGS
     /opt/rocm/bin/hipcc $FLAGS $sf -c $f.hip -o ../../tools/_exp/$name/$f.o &
     objs="$objs ../../tools/_exp/$name/$f.o"
   else
