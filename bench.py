@@ -653,13 +653,14 @@ def batch_extra(torch, D, HL, args, rank, dev):
 def pairs_extra(args):
     """BASELINE.json configs[2] exactly as SURVEY.md 8d states it, on the driver-timed line: 64 COLD 1280x720 frame
     pairs per step, both pyramids built, 169,638,912 algorithmic bytes per batch, 4 rotated batches (450 MiB of frames) -- the
-    c3pairs workload's own measurement (bench_pairs.py), 15 blocks of 256 steps (0.2 s of GPU time: the stand-alone command's form), run as a CHILD PROCESS of this command: it
+    c3pairs workload's own measurement (bench_pairs.py), 15 blocks of 1,024 steps (0.7 s of GPU time; a block's fill, drain and gather
+    cost 1-3 % of a 256-step block: 45.5 against 44.2 us per step at 256 / 4,096 steps on one box), run as a CHILD PROCESS of this command: it
     pipelines its batches over four HIP streams and wants the process's four hardware queues to itself; in this process, whose
     64-stream extra has created three library streams by now (or would create them afterwards), either measurement slowed the
     other by 1.5-1.8x (82 instead of 56 us per step; 87-91 instead of 48 the other way round).  Its CPU baseline runs with
     --workload c3pairs."""
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "AGT_DIST_BACKEND")}
-    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c3pairs", "--steps", "256", "--warmup", "32", "--blocks", "15",
+    cmd = [sys.executable, os.path.abspath(__file__), "--workload", "c3pairs", "--steps", "1024", "--warmup", "32", "--blocks", "15",
            "--render-frames", str(args.render_frames), "--no-cpu-baseline"]
     try:
         p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=600, text=True)
@@ -671,7 +672,7 @@ def pairs_extra(args):
         return {"error": repr(e)}
     keep = ("metric", "value", "unit", "steps", "ms_per_step", "config", "timing", "roofline", "max_abs_pose_err_vs_truth", "tracked_frac")
     res = {k: out[k] for k in keep}
-    res["note"] = "child process of this command (python bench.py --workload c3pairs --steps 256 --warmup 32 --blocks 15 --no-cpu-baseline)"
+    res["note"] = "child process of this command (python bench.py --workload c3pairs --steps 1024 --warmup 32 --blocks 15 --no-cpu-baseline)"
     return res
 
 
