@@ -97,6 +97,31 @@ def test_pyramid_build_all_levels_bit_exact(torch_cuda, cvh, oracle, shape):
                 assert got.shape == ref.shape and np.array_equal(got, ref), "level %d, stream %d, pad %d" % (l, b, pad)
 
 
+@pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (1080, 1920), (270, 480), (101, 240), (99, 464), (96, 96), (135, 96), (100, 4112),
+                                   (301, 1360), (89, 112), (90, 96), (722, 1296), (150, 528)])
+def test_pyramid_build_rolling_pass_of_16_images_bit_exact(torch_cuda, cvh, oracle, shape):
+    """The SHIPPED form of the two-level register-rolling pass (round 5: launches of >= 16 images whose width and pitch are multiples
+    of 16; agt_pyramid.hip agt_pyr2_plan): strips walked in alternating directions, lean horizontal / vertical passes.  16 and 19
+    DIFFERENT images per launch, every level of every image against pyrDown applied level by level -- heights whose level 1 / 2 are
+    odd, fewer rows than one strip, one column tile, a last tile of one group, the widest row the 31-bit offsets allow."""
+    torch = torch_cuda
+    h, w = shape
+    rng = np.random.default_rng(h * 11 + w)
+    for B in (16, 19):
+        img = rng.integers(0, 256, size=(B, h, w), dtype=np.uint8)
+        d = torch.from_numpy(img).cuda().contiguous()
+        ctx = cvh.Context(w, h, max_level=3, max_points=8, max_streams=B)
+        ctx.pyramid_build(0, d)
+        L = ctx.eff_max_level
+        assert L >= 2
+        got = [ctx.pyramid_level(0, l) for l in range(1, L + 1)]
+        for b in range(B):
+            ref = img[b]
+            for l in range(1, L + 1):
+                ref = oracle.pyrDown(ref)
+                assert got[l - 1][b].shape == ref.shape and np.array_equal(got[l - 1][b], ref), "level %d, image %d of %d" % (l, b, B)
+
+
 def test_lk_bit_exact_640(cvh, oracle, seq640):
     for k in range(3):
         o, g = _lk_both(cvh, oracle, seq640.frame(k), seq640.frame(k + 1), seq640.corners(k), maxLevel=2)
