@@ -28,6 +28,7 @@ struct agt_ctx {
     int eff_max_level;                       // after OpenCV's early stop
     int lw[AGT_MAX_LEVELS], lh[AGT_MAX_LEVELS];
     long lpitch[AGT_MAX_LEVELS];             // levels >= 1 (context-owned)
+    char* hcall_host; char* hcall_dev; unsigned long long hcall_n;      // host-mapped staging of the synchronous host-array calls (agt_solve_pnp_host)
     double* d_tilt; double tilt_host[AGT_TILT_SLOTS][18]; int tilt_valid[AGT_TILT_SLOTS]; int tilt_next;   // tilted-sensor matrices (camera_on)
     uint8_t* lmem[AGT_RING_MAX][AGT_MAX_LEVELS];
     const uint8_t* l0_ptr[AGT_RING_MAX];
@@ -394,6 +395,7 @@ int agt_destroy(agt_ctx* c)
     if (c->dense_partials) (void)hipFree(c->dense_partials);
     if (c->dense_done) (void)hipFree(c->dense_done);
     if (c->d_tilt) (void)hipFree(c->d_tilt);
+    if (c->hcall_host) (void)hipHostFree(c->hcall_host);
     if (c->map1) (void)hipFree(c->map1);
     if (c->map2) (void)hipFree(c->map2);
     if (c->prof_ev) {
@@ -610,6 +612,114 @@ int agt_project_points(agt_ctx* c, const void* d_obj, size_t obj_batch_stride, i
     p.img_out = d_img_out; p.jac = d_jac;
     hipError_t e = agt_launch_project(c->stream, p, B);
     return e == hipSuccess ? AGT_OK : hip_fail(c, e);
+}
+
+// ---- the reference's per-frame calls as ONE synchronous call each, host arrays in and out (detect_pose.py:509-526 solvePnP,
+// :441-465 projectPoints).  No copies are enqueued: the arguments go into a host-mapped staging area of the
+// context, the kernel reads them and writes its results there over PCIe and stores a sequence word behind them (system scope), the
+// calling thread polls the word.  Against upload + launch + download + stream wait (44 / 28 us per call): see DESIGN.md section 6.
+namespace {
+constexpr size_t HC_SEQ = 0, HC_POSE = 64, HC_INFO = 128, HC_ERR = 144, HC_OBJ = 256, HC_IMG = HC_OBJ + 256 * 3 * 8,
+                 HC_JAC = HC_IMG + 256 * 2 * 8, HC_SIZE = HC_JAC + 2 * 256 * 6 * 8;
+
+int hcall_ready(agt_ctx* c)
+{
+    if (c->hcall_host) return AGT_OK;
+    if (hipHostMalloc((void**)&c->hcall_host, HC_SIZE, hipHostMallocMapped) != hipSuccess) { (void)hipGetLastError(); c->hcall_host = nullptr; return AGT_ERR_ALLOC; }
+    memset(c->hcall_host, 0, HC_SIZE);
+    if (hipHostGetDevicePointer((void**)&c->hcall_dev, c->hcall_host, 0) != hipSuccess) {
+        (void)hipGetLastError(); (void)hipHostFree(c->hcall_host); c->hcall_host = nullptr; return AGT_ERR_HIP;
+    }
+    c->hcall_n = 0;
+    return AGT_OK;
+}
+
+// poll the staging area's sequence word for `want`; after 2 s without it the stream is asked what happened
+int hcall_wait(agt_ctx* c, unsigned long long want)
+{
+    const volatile unsigned long long* seq = (const volatile unsigned long long*)(c->hcall_host + HC_SEQ);
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (unsigned long spins = 1; *seq < want; spins++) {
+#if defined(__x86_64__) || defined(__i386__)
+        __builtin_ia32_pause();
+#else
+        __asm__ __volatile__("" ::: "memory");
+#endif
+        if ((spins & 0xffff) == 0) {
+            timespec t1; clock_gettime(CLOCK_MONOTONIC, &t1);
+            if ((t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) * 1e-9 > 2.0) {
+                hipError_t e = hipStreamSynchronize(c->stream);
+                if (e != hipSuccess) return hip_fail(c, e);
+                if (*seq < want) return AGT_ERR_STATE;
+            }
+        }
+    }
+    __atomic_thread_fence(__ATOMIC_ACQUIRE);
+    return AGT_OK;
+}
+}  // namespace
+
+int agt_solve_pnp_host(agt_ctx* c, const void* h_obj, const void* h_img, int dtype, int n,
+                       const double* K, const double* dist, int ndist,
+                       double* h_pose, int use_guess, int32_t* h_info, double* h_err)
+{
+    if (!c || !h_obj || !h_img || !h_pose) return AGT_ERR_ARG;
+    if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
+    if (n < 3 || n > 256) return AGT_ERR_NPOINTS;
+    if (!use_guess && n < 4) return AGT_ERR_NPOINTS;
+    int rc = hcall_ready(c);
+    if (rc) return rc;
+    AgtPnpParams p;
+    memset(&p, 0, sizeof(p));
+    rc = camera_on(c, K, dist, ndist, &p.cam);
+    if (rc) return rc;
+    const size_t es = dtype == AGT_F32 ? 4 : 8;
+    memcpy(c->hcall_host + HC_OBJ, h_obj, (size_t)n * 3 * es);
+    memcpy(c->hcall_host + HC_IMG, h_img, (size_t)n * 2 * es);
+    double* pose = (double*)(c->hcall_host + HC_POSE);
+    if (use_guess) memcpy(pose, h_pose, 6 * sizeof(double)); else memset(pose, 0, 6 * sizeof(double));
+    p.obj = c->hcall_dev + HC_OBJ; p.obj_bstride = 0; p.img = c->hcall_dev + HC_IMG; p.mask = nullptr; p.dtype = dtype;
+    p.n = n; p.use_guess = use_guess ? 1 : 0; p.pose = (double*)(c->hcall_dev + HC_POSE);
+    p.info = (int32_t*)(c->hcall_dev + HC_INFO); p.err = (double*)(c->hcall_dev + HC_ERR);
+    p.gate_px = 2.0;
+    const unsigned long long want = ++c->hcall_n;
+    p.host_seq = (unsigned long long*)(c->hcall_dev + HC_SEQ); p.host_seq_base = want;
+    hipError_t e = agt_launch_pnp(c->stream, p, 1);
+    if (e != hipSuccess) return hip_fail(c, e);
+    rc = hcall_wait(c, want);
+    if (rc) return rc;
+    memcpy(h_pose, pose, 6 * sizeof(double));
+    if (h_info) memcpy(h_info, c->hcall_host + HC_INFO, 4 * sizeof(int32_t));
+    if (h_err) *h_err = *(const double*)(c->hcall_host + HC_ERR);
+    return AGT_OK;
+}
+
+int agt_project_points_host(agt_ctx* c, const void* h_obj, int dtype, int n, const double* h_pose,
+                            const double* K, const double* dist, int ndist, void* h_img_out, double* h_jac)
+{
+    if (!c || !h_obj || !h_pose || !h_img_out) return AGT_ERR_ARG;
+    if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
+    if (n <= 0 || n > 256) return AGT_ERR_NPOINTS;          // (one workgroup: the reference projects its 48 .. 240 model corners)
+    int rc = hcall_ready(c);
+    if (rc) return rc;
+    AgtProjParams p;
+    memset(&p, 0, sizeof(p));
+    rc = camera_on(c, K, dist, ndist, &p.cam);
+    if (rc) return rc;
+    const size_t es = dtype == AGT_F32 ? 4 : 8;
+    memcpy(c->hcall_host + HC_OBJ, h_obj, (size_t)n * 3 * es);
+    memcpy(c->hcall_host + HC_POSE, h_pose, 6 * sizeof(double));
+    p.obj = c->hcall_dev + HC_OBJ; p.obj_bstride = 0; p.dtype = dtype; p.n = n; p.pose = (const double*)(c->hcall_dev + HC_POSE);
+    p.img_out = c->hcall_dev + HC_IMG; p.jac = h_jac ? (double*)(c->hcall_dev + HC_JAC) : nullptr;
+    const unsigned long long want = ++c->hcall_n;
+    p.host_seq = (unsigned long long*)(c->hcall_dev + HC_SEQ); p.host_seq_base = want;
+    hipError_t e = agt_launch_project(c->stream, p, 1);
+    if (e != hipSuccess) return hip_fail(c, e);
+    rc = hcall_wait(c, want);
+    if (rc) return rc;
+    memcpy(h_img_out, c->hcall_host + HC_IMG, (size_t)n * 2 * es);
+    if (h_jac) memcpy(h_jac, c->hcall_host + HC_JAC, (size_t)n * 12 * sizeof(double));
+    return AGT_OK;
 }
 
 int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float* d_obj, int n, int B,

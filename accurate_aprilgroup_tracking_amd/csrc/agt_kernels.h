@@ -194,6 +194,9 @@ struct AgtProjParams {
     AgtCameraHost cam;
     void* img_out;            // [B][n][2]
     double* jac;              // [B][2n][6] or null
+    // agt_project_points_host (one block, B = 1): host-mapped sequence word stored behind the outputs (see AgtPnpParams::host_seq); null: off
+    unsigned long long* host_seq;
+    unsigned long long host_seq_base;
 };
 
 void agt_pyr_grid(int dw, int dh, int* gx, int* gy);

@@ -46,12 +46,10 @@ __global__ __launch_bounds__(AGT_WAVE * COOP_WAVES) void pnp_coop_kernel(const A
     if (P.host_seq && b == 0 && threadIdx.x < AGT_WAVE) agt_host_seq_store(P.host_seq, P.host_seq_base, threadIdx.x == 0);      // (wave 0 writes the record in both bodies)
 }
 
+// cv::projectPoints for point i of stream b
 template <typename T>
-__global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
+__device__ __forceinline__ void project_one(const AgtProjParams& P, int b, int i)
 {
-    const int b = blockIdx.y;
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= P.n) return;
     AgtCamera cam;
     load_cam<T>(P.cam, cam);
     double param[6];
@@ -72,6 +70,21 @@ __global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
         agt_project<false>(cam, R, G, param + 3, X, Y, Z, u, v, nullptr, nullptr);
     }
     out[i * 2] = (T)u; out[i * 2 + 1] = (T)v;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void project_kernel(const AgtProjParams P)
+{
+    const int b = blockIdx.y;
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < P.n) project_one<T>(P, b, i);
+    if (P.host_seq) {
+        // one-block launch of agt_project_points_host: every wave's outputs (host-mapped memory) are performed at system scope before the
+        // barrier, then one lane tells the polling host thread
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+        __syncthreads();
+        if (threadIdx.x < AGT_WAVE) agt_host_seq_store(P.host_seq, P.host_seq_base, threadIdx.x == 0);
+    }
 }
 
 template <typename T>

@@ -29,9 +29,30 @@ class error(ValueError):
     """stands in for cv2.error (argument / shape violations)"""
 
 
+_gpu_seen = False
+
+
 def _require_gpu():
+    global _gpu_seen
+    if _gpu_seen:
+        return
     if not torch.cuda.is_available():
         raise RuntimeError("accurate_aprilgroup_tracking_amd needs a ROCm GPU (no CPU fallback)")
+    _gpu_seen = True
+
+
+def _addr(a):
+    """address of a numpy array's first element as a ctypes pointer argument (ndarray.ctypes.data_as costs twice as much, and the
+    synchronous calls are short enough for that to show: bench.py per_call_latency_us)"""
+    return C.c_void_p(a.__array_interface__["data"][0])
+
+
+def _raw_stream(device):
+    """the HIP stream torch launches on (torch.cuda.current_stream(device).cuda_stream without building the Stream object)"""
+    try:
+        return torch._C._cuda_getCurrentRawStream(device)
+    except AttributeError:                      # (private torch API: fall back to the public one)
+        return torch.cuda.current_stream(device).cuda_stream
 
 
 def _ptr(t):
@@ -41,6 +62,8 @@ def _ptr(t):
 def _host_f64(a, n=None):
     if a is None:
         return None, 0
+    if type(a) is np.ndarray and a.dtype == np.float64 and a.flags.c_contiguous:
+        return a, a.size                        # (only the address is used: no reshape needed)
     a = np.ascontiguousarray(np.asarray(a, dtype=np.float64).reshape(-1))
     return a, a.size
 
@@ -63,7 +86,7 @@ class Context:
         # between callers, hold this lock from staging their inputs to reading their outputs (cv2's own functions are
         # re-entrant; two threads calling cv_hip.solvePnP must not see each other's staging buffer)
         self.lock = threading.RLock()
-        self._staging = None
+        self._stream_set = None
 
     def close(self):
         if getattr(self, "h", None) and self.h.value:
@@ -77,8 +100,10 @@ class Context:
             pass
 
     def use_current_stream(self):
-        stream = torch.cuda.current_stream(self.device).cuda_stream
-        H.check(self.L.agt_set_stream(self.h, C.c_void_p(stream)), "agt_set_stream")
+        stream = _raw_stream(self.device)
+        if stream != self._stream_set:          # (one foreign call less per cv2-shaped call while the stream stays the same)
+            H.check(self.L.agt_set_stream(self.h, C.c_void_p(stream)), "agt_set_stream")
+            self._stream_set = stream
 
     def synchronize(self):
         H.check(self.L.agt_synchronize(self.h), "agt_synchronize")
@@ -262,46 +287,6 @@ def _geom_context(n):
     return _context(64, 64, 0, 21, n)
 
 
-class _Staging:
-    """Pinned host buffer + device buffer of one geometry context: a cv2-shaped call packs all of its inputs into ONE
-    host-to-device copy and reads all of its outputs back with ONE device-to-host copy (round 1 issued a pageable copy per
-    array and a synchronising .cpu() per result: 129 us for solvePnP at N = 48; this path: bench.py per_call_latency_us)."""
-    OBJ, IMG = 0, 256 * 3 * 8
-    POSE = IMG + 256 * 2 * 8                 # pose (48 B) sits right in front of the outputs: one download covers both
-    OUT = POSE + 48                          # info (16 B) | projected points (n x 2) | Jacobian (2n x 6 f64)
-    PTS = OUT + 16
-    JAC = PTS + 256 * 2 * 8
-    SIZE = JAC + 2 * 256 * 6 * 8
-
-    def __init__(self, ctx):
-        self.ctx = ctx
-        self.host = torch.empty(self.SIZE, dtype=torch.uint8).pin_memory()
-        self.np = self.host.numpy()
-        self.hbase = self.host.data_ptr()
-        self.dev = torch.empty(self.SIZE, dtype=torch.uint8, device=torch.device("cuda", ctx.device))
-        self.base = self.dev.data_ptr()
-
-    def f64(self, off, n):
-        return self.np[off:off + 8 * n].view(np.float64)
-
-    def view(self, off, n, dt):
-        return self.np[off:off + np.dtype(dt).itemsize * n].view(dt)
-
-    def upload(self, off, nbytes):
-        H.check(self.ctx.L.agt_upload(self.ctx.h, C.c_void_p(self.base + off), C.c_void_p(self.hbase + off), nbytes), "agt_upload")
-
-    def download(self, off, nbytes):
-        H.check(self.ctx.L.agt_download(self.ctx.h, C.c_void_p(self.hbase + off), C.c_void_p(self.base + off), nbytes), "agt_download")
-
-
-def _stage(ctx):
-    """the context's staging buffers (kept ON the context: an id()-keyed table would hand a dead context's buffers to a new
-    context that happens to reuse the address); call with ctx.lock held"""
-    if ctx._staging is None:
-        ctx._staging = _Staging(ctx)
-    return ctx._staging
-
-
 def getOptimalNewCameraMatrix(cameraMatrix, distCoeffs, imageSize, alpha, newImgSize=(0, 0)):
     """cv2.getOptimalNewCameraMatrix -> (newCameraMatrix (3,3) f64, roi (x, y, w, h)).  Host arithmetic
     (81 grid points), done by the C-ABI library like every other cv2 replacement."""
@@ -423,26 +408,18 @@ def solvePnP(objectPoints, imagePoints, cameraMatrix, distCoeffs, rvec=None, tve
         raise error("solvePnP: useExtrinsicGuess needs 3-element rvec and tvec")
     with ctx.lock:
         ctx.use_current_stream()
-        # one pinned staging buffer: [obj | img | pose] up in one copy, [pose | info] down in one copy
-        st = _stage(ctx)
-        st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
-        st.view(st.IMG, n * 2, dt)[:] = img.reshape(-1)
-        g = st.f64(st.POSE, 6)
+        # ONE foreign call, host arrays in and out (agt_solve_pnp_host: no copy is enqueued -- the kernel reads a host-mapped staging
+        # area and the call polls for its result; rounds 1-4: upload + launch + download + stream wait, 44 us per call)
+        objc = np.ascontiguousarray(obj, dtype=dt); imgc = np.ascontiguousarray(img, dtype=dt)
+        p = np.zeros(6, np.float64)
         if useExtrinsicGuess:
-            g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
-        else:
-            g[:] = 0.0
-        st.upload(0, st.OUT)
+            p[:3] = np.asarray(rvec, np.float64).reshape(3); p[3:] = np.asarray(tvec, np.float64).reshape(3)
+        inf = np.zeros(4, np.int32)
         Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
-        base = st.base
-        rc = ctx.L.agt_solve_pnp(ctx.h, C.c_void_p(base + st.OBJ), 0, C.c_void_p(base + st.IMG), H.F32 if dt == np.float32 else H.F64,
-                                 None, n, 1, Kh.ctypes.data_as(C.c_void_p), dh.ctypes.data_as(C.c_void_p) if nd else None, nd,
-                                 C.c_void_p(base + st.POSE), 1 if useExtrinsicGuess else 0, C.c_void_p(base + st.OUT), None)
+        rc = ctx.L.agt_solve_pnp_host(ctx.h, _addr(objc), _addr(imgc), H.F32 if dt == np.float32 else H.F64, n,
+                                      _addr(Kh), _addr(dh) if nd else None, nd, _addr(p), 1 if useExtrinsicGuess else 0, _addr(inf), None)
         if rc:
-            raise error(str(H.AgtError(rc, "agt_solve_pnp")))
-        st.download(st.POSE, 64)                                   # pose | info
-        inf = st.view(st.OUT, 4, np.int32)
-        p = st.f64(st.POSE, 6).copy()
+            raise error(str(H.AgtError(rc, "agt_solve_pnp_host")))
         if not inf[H.INFO_OK]:
             raise error("solvePnP: not enough usable points (non-planar sets need 6 without a guess)")
         if useExtrinsicGuess and isinstance(rvec, np.ndarray) and isinstance(tvec, np.ndarray) \
@@ -464,22 +441,17 @@ def projectPoints(objectPoints, rvec, tvec, cameraMatrix, distCoeffs, jacobian=F
     with ctx.lock:
         ctx.use_current_stream()
         if n <= 256:
-            # staged path: [obj | pose] up in one copy, [points (| Jacobian)] down in one copy
-            st = _stage(ctx)
-            st.view(st.OBJ, n * 3, dt)[:] = obj.reshape(-1)
-            g = st.f64(st.POSE, 6)
+            # ONE foreign call, host arrays in and out (agt_project_points_host; rounds 1-4: upload + launch + download + wait, 28 us)
+            g = np.empty(6, np.float64)
             g[:3] = np.asarray(rvec, np.float64).reshape(3); g[3:] = np.asarray(tvec, np.float64).reshape(3)
-            st.upload(0, st.OUT)
+            pts = np.empty((n, 1, 2), dt)
+            jac = np.empty((2 * n, 6), np.float64) if jacobian else None
             Kh, _ = _host_f64(cameraMatrix); dh, nd = _host_f64(distCoeffs)
-            rc = ctx.L.agt_project_points(ctx.h, C.c_void_p(st.base + st.OBJ), 0, H.F32 if dt == np.float32 else H.F64, n, 1,
-                                          C.c_void_p(st.base + st.POSE), Kh.ctypes.data_as(C.c_void_p),
-                                          dh.ctypes.data_as(C.c_void_p) if nd else None, nd, C.c_void_p(st.base + st.PTS),
-                                          C.c_void_p(st.base + st.JAC) if jacobian else None)
+            rc = ctx.L.agt_project_points_host(ctx.h, _addr(obj), H.F32 if dt == np.float32 else H.F64, n, _addr(g), _addr(Kh),
+                                               _addr(dh) if nd else None, nd, _addr(pts), _addr(jac) if jacobian else None)
             if rc:
-                raise error(str(H.AgtError(rc, "agt_project_points")))
-            st.download(st.PTS, (st.JAC - st.PTS) + (2 * n * 6 * 8 if jacobian else 0) if jacobian else n * 2 * np.dtype(dt).itemsize)
-            pts = st.view(st.PTS, n * 2, dt).reshape(n, 1, 2).copy()
-            return pts, (st.f64(st.JAC, 2 * n * 6).reshape(2 * n, 6).copy() if jacobian else None)
+                raise error(str(H.AgtError(rc, "agt_project_points_host")))
+            return pts, jac
         dev = torch.device("cuda", ctx.device)
         g = np.concatenate([np.asarray(rvec, np.float64).reshape(3), np.asarray(tvec, np.float64).reshape(3)])
         pose = torch.from_numpy(g).to(dev).reshape(1, 6).contiguous()

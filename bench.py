@@ -826,7 +826,26 @@ def per_call_latency(bench):
             t0 = time.perf_counter(); fn(); ts.append(time.perf_counter() - t0)
         return round(float(np.median(ts)) * 1e6, 1)
     r0, t0_ = sq.rvecs[0].copy(), sq.tvecs[0].copy()
+    # the C-ABI calls alone (arguments prepared once: what a compiled host pays; the cv_hip figures add ~10 us of numpy / ctypes marshalling)
+    import ctypes as C
+    from accurate_aprilgroup_tracking_amd import hiplib as HL
+    ctx = cv_hip._geom_context(48)
+    Kh = np.ascontiguousarray(sq.K.reshape(-1)); imgf = np.ascontiguousarray(nx, np.float32)
+    pose = np.zeros(6); inf = np.zeros(4, np.int32); ptsf = np.empty((48, 2), np.float32)
+    vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
+    a_solve = (ctx.h, vp(obj), vp(imgf), HL.F32, 48, vp(Kh), None, 0, vp(pose), 1, vp(inf), None)
+    a_init = (ctx.h, vp(obj), vp(imgf), HL.F32, 48, vp(Kh), None, 0, vp(pose), 0, vp(inf), None)
+    a_proj = (ctx.h, vp(obj), HL.F32, 48, vp(pose), vp(Kh), None, 0, vp(ptsf), None)
+
+    def c_solve(args):
+        pose[:3] = r0; pose[3:] = t0_
+        ctx.L.agt_solve_pnp_host(*args)
+    with ctx.lock:
+        ctx.use_current_stream()
+        c_abi = {"agt_solve_pnp_host_guess_N48": med(lambda: c_solve(a_solve)), "agt_solve_pnp_host_noguess_N48": med(lambda: c_solve(a_init)),
+                 "agt_project_points_host_N48": med(lambda: ctx.L.agt_project_points_host(*a_proj))}
     out = {
+        "c_abi_call_only": c_abi,
         "solvePnP_guess_N48": {"hip": med(lambda: cv_hip.solvePnP(obj, nx, sq.K, None, r0.copy(), t0_.copy(), True)),
                                "cpu_oracle": med(lambda: cvo.solvePnP(obj, nx, sq.K, None, r0.copy(), t0_.copy(), True))},
         "solvePnP_noguess_N48": {"hip": med(lambda: cv_hip.solvePnP(obj, nx, sq.K, None)),

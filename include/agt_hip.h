@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 500
+#define AGT_VERSION 501
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -169,6 +169,19 @@ int agt_solve_pnp(agt_ctx* ctx, const void* d_obj, size_t obj_batch_stride, cons
 int agt_project_points(agt_ctx* ctx, const void* d_obj, size_t obj_batch_stride, int dtype, int n, int B,
                        const double* d_pose, const double* K, const double* dist, int ndist,
                        void* d_img_out, double* d_jac);
+
+/* ---- the same two calls SYNCHRONOUS, host arrays in and out: what the reference does once per frame (cv2.solvePnP at
+ * detect_pose.py:509-526, cv2.projectPoints at :441-465).  One launch each and no copy: the arguments are placed in a host-mapped
+ * staging area of the context, the kernel reads them and writes its results there, the calling thread polls a sequence word the
+ * kernel stores behind them.  h_obj: n x 3, h_img: n x 2 (dtype AGT_F32 / AGT_F64 for both), 3 <= n <= 256 (4 without a guess);
+ * h_pose: 6 doubles (rvec, tvec), read when use_guess, written on return; h_info: 4 int32 (AGT_INFO_*) or NULL; h_err: mean
+ * reprojection error or NULL.  agt_project_points_host: 1 <= n <= 256, h_img_out n x 2 of dtype, h_jac [2n][6] doubles or NULL.
+ * The calls are ordered on the context's stream like every other launch and return when THEIR result is there. */
+int agt_solve_pnp_host(agt_ctx* ctx, const void* h_obj, const void* h_img, int dtype, int n,
+                       const double* K, const double* dist, int ndist,
+                       double* h_pose, int use_guess, int32_t* h_info, double* h_err);
+int agt_project_points_host(agt_ctx* ctx, const void* h_obj, int dtype, int n, const double* h_pose,
+                            const double* K, const double* dist, int ndist, void* h_img_out, double* h_jac);
 
 /* ---- fused per-frame step (PoseDetector._estimate_pose with LK-tracked corners) ---- */
 /* Tracker state lives in the context, one record per stream: current corners, the
