@@ -75,10 +75,11 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
     constexpr size_t LKB = sizeof(AgtLkTables);
     const size_t per = lk_role_lds<WIN, NW, NLEV>(S.lk.max_level + 1);
     uint8_t* my = lds + (NW == 1 ? (size_t)wave * per : 0);
-    // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: the kernel-
-    // argument segment is host memory, a dependent scalar load from it in the middle of the chain costs a
-    // PCIe round trip.  The copy is requested here, before anything else, and lands while the first frame's
-    // corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
+    // Frames 2.. of the group take their image / output pointers from a copy of the tables in LDS: a dependent
+    // scalar load from the kernel-argument segment in the middle of the chain costs a memory round trip (device
+    // memory with this runtime's defaults, host memory across PCIe under HIP_FORCE_DEV_KERNARG=0: profiles/
+    // r05_experiments.md section 15).  The copy is requested here, before anything else, and lands while the first
+    // frame's corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
     AgtLkTables* tab = reinterpret_cast<AgtLkTables*>(my + per - LKB);
     {
         const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
