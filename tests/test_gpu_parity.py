@@ -556,3 +556,63 @@ def test_full_size_properties_without_the_oracle(cvh):
         assert ok and np.abs(rv.ravel() - r).max() < 1e-6 and np.abs(tv.ravel() - t).max() < 1e-7      # f32 object points
         ok, rv, tv = cvh.solvePnP(obj, img, K, None, rv, tv, True)
         assert np.abs(rv.ravel() - r).max() < 1e-8 and np.abs(tv.ravel() - t).max() < 1e-8
+
+
+def test_host_array_entry_points_equal_the_device_pointer_ones(torch_cuda, cvh, oracle):
+    """agt_solve_pnp_host / agt_project_points_host (round 5: one synchronous call, arguments and results through a host-mapped staging
+    area, polled) run the kernels of agt_solve_pnp / agt_project_points: results must be BIT-identical to the device-pointer calls on the
+    same inputs -- f32 and f64 points, with / without guess, with distortion (and a tilted sensor), n = 4, 48, 64 (one wave), 65, 240,
+    256 (four waves); info words and the mean error too; argument errors as error codes."""
+    import ctypes as C
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    torch = torch_cuda
+    rng = np.random.default_rng(12)
+    ctx = cvh.Context(64, 64, max_level=0, max_points=256, max_streams=1)
+    L = ctx.L
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)
+    K = syn.camera_matrix(1280, 720)
+    dists = [None, np.array([0.05, -0.1, 1e-3, -1e-3, 0.02]), np.array([0.05, -0.02, 1e-3, 2e-3, 0.01, 0.02, -0.01, 0.005, 1e-3, -2e-3, 5e-4, 1e-3, 0.03, -0.02])]
+    for n in (4, 48, 64, 65, 240, 256):
+        obj64 = np.concatenate([rng.uniform(-0.06, 0.06, (n, 2)), rng.uniform(-0.02, 0.02, (n, 1))], axis=1)
+        r = np.array([0.3, -0.2, 0.1]) + rng.normal(0, 0.05, 3); t = np.array([0.01, -0.02, 0.45])
+        for dist in dists:
+            img64 = oracle.projectPoints(obj64, r, t, K, dist)[0].reshape(-1, 2) + rng.normal(0, 0.2, (n, 2))
+            Kh = np.ascontiguousarray(K.reshape(-1)); dh = None if dist is None else np.ascontiguousarray(dist, np.float64)
+            nd = 0 if dist is None else dh.size
+            for dt, code in ((np.float32, H.F32), (np.float64, H.F64)):
+                obj = np.ascontiguousarray(obj64, dt); img = np.ascontiguousarray(img64, dt)
+                for use_guess in ((0, 1) if n >= 6 else (1,)):
+                    g = np.concatenate([r + 0.03, t + 0.004]) if use_guess else np.zeros(6)
+                    # device-pointer call
+                    pose_d, info_d, err_d = ctx.solve_pnp(torch.from_numpy(obj).cuda(), torch.from_numpy(img[None]).cuda().contiguous(), K, dist,
+                                                          pose=torch.from_numpy(g[None].copy()).cuda(), use_guess=bool(use_guess))
+                    # host-array call
+                    pose_h = g.copy(); info_h = np.zeros(4, np.int32); err_h = np.zeros(1)
+                    rc = L.agt_solve_pnp_host(ctx.h, vp(obj), vp(img), code, n, vp(Kh), vp(dh) if nd else None, nd, vp(pose_h), use_guess, vp(info_h), vp(err_h))
+                    assert rc == 0
+                    assert np.array_equal(info_h, info_d.cpu().numpy()[0]) and info_h[H.INFO_OK] == 1
+                    assert np.array_equal(pose_h.view(np.uint64), pose_d.cpu().numpy()[0].view(np.uint64)), (n, dt, use_guess)
+                    assert np.array_equal(err_h.view(np.uint64), err_d.cpu().numpy().view(np.uint64))
+                # projection (+ Jacobian) at the generating pose
+                pose = np.concatenate([r, t])
+                out_d, jac_d = ctx.project_points(torch.from_numpy(obj).cuda(), torch.from_numpy(pose[None].copy()).cuda(), K, dist, jacobian=True)
+                out_h = np.empty((n, 2), dt); jac_h = np.empty((2 * n, 6))
+                rc = L.agt_project_points_host(ctx.h, vp(obj), code, n, vp(pose), vp(Kh), vp(dh) if nd else None, nd, vp(out_h), vp(jac_h))
+                assert rc == 0 and np.array_equal(out_h, out_d.cpu().numpy()[0]) and np.array_equal(jac_h.view(np.uint64), jac_d.cpu().numpy()[0].view(np.uint64))
+                out_h2 = np.empty((n, 2), dt)
+                assert L.agt_project_points_host(ctx.h, vp(obj), code, n, vp(pose), vp(Kh), vp(dh) if nd else None, nd, vp(out_h2), None) == 0
+                assert np.array_equal(out_h2, out_h)
+    # argument errors
+    obj = np.zeros((300, 3)); img = np.zeros((300, 2)); pose = np.zeros(6); Kh = np.ascontiguousarray(K.reshape(-1))
+    assert L.agt_solve_pnp_host(ctx.h, vp(obj), vp(img), H.F64, 300, vp(Kh), None, 0, vp(pose), 0, None, None) == -4
+    assert L.agt_solve_pnp_host(ctx.h, vp(obj), vp(img), H.F64, 3, vp(Kh), None, 0, vp(pose), 0, None, None) == -4
+    assert L.agt_solve_pnp_host(ctx.h, None, vp(img), H.F64, 8, vp(Kh), None, 0, vp(pose), 0, None, None) == -1
+    assert L.agt_solve_pnp_host(ctx.h, vp(obj), vp(img), H.F64, 8, vp(Kh), vp(pose), 7, vp(pose), 0, None, None) == -3
+    assert L.agt_project_points_host(ctx.h, vp(obj), H.F64, 257, vp(pose), vp(Kh), None, 0, vp(img), None) == -4
+    assert L.agt_project_points_host(ctx.h, vp(obj), 99, 8, vp(pose), vp(Kh), None, 0, vp(img), None) == -1
+    # too few usable points: a planar set of 4 without a guess works, 5 non-planar points without a guess do not (6 needed)
+    objn = rng.uniform(-0.05, 0.05, (5, 3)); imgn = oracle.projectPoints(objn, np.array([0.1, 0.2, 0.3]), np.array([0, 0, 0.4]), K, None)[0].reshape(-1, 2)
+    info = np.zeros(4, np.int32)
+    assert L.agt_solve_pnp_host(ctx.h, vp(np.ascontiguousarray(objn)), vp(np.ascontiguousarray(imgn)), H.F64, 5, vp(Kh), None, 0, vp(pose), 0, vp(info), None) == 0
+    assert info[H.INFO_OK] == 0
