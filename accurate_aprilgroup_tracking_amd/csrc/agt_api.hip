@@ -905,6 +905,9 @@ static int launch_group(agt_ctx* c, int B)
     // register-rolling two-level pass), for big batches where the rolling form applies to every frame of the launch (decided below,
     // in the s = 0 trip) and stage 1 has no backlog from an earlier launch that ran the levels as two passes
     bool fused = L >= 2 && B <= AGT_PYR2_MAX_B;
+    // a launch that will carry pyramid work ONLY (the first one of a run: no frame is ready for the LK role, none for the pose role)
+    // goes out as the pyramid kernel proper (below), which has the register-rolling two-level pass -- the fused step kernel has not
+    const bool pyr_only = c->n_lk >= done_before[L] && c->n_pnp >= c->n_lk;
     for (int s = 0; s < L; s++) {
         if (fused && s == 1) continue;
         long cnt = done_before[s] - c->n_stage[s];
@@ -943,8 +946,9 @@ static int launch_group(agt_ctx* c, int B)
             uintptr_t d2_align = 0;
             for (long k = 0; k < cnt; k++) d2_align |= (uintptr_t)c->lmem[(int)((c->n_stage[0] + 1 + k) % M)][2];
             // (fused step: agt_step_fits, <= 256 corners in flight -- its kernel carries the tiled two-level pass only: plan as ONE frame, which
-            // keeps the launch below the rolling form's 16 images)
-            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, agt_step_fits(c->trk_n, B) ? 1 : (int)cnt);
+            // keeps the launch below the rolling form's 16 images.  Round 5: except the pyramid-only launch at the head of a run, which is
+            // pyr_group_kernel -- 20 frames of 1280x720, the driver's block: 15.1 us tiled, see DESIGN.md section 6 for the rolling figure)
+            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (agt_step_fits(c->trk_n, B) && !pyr_only) ? 1 : (int)cnt);
             if (!fused && A0.pad != 0 && c->n_stage[1] == c->n_stage[0]) fused = true;       // big batch, rolling form, no backlog
             if (fused) {
                 A = A0; S.pyr[1] = A1;
