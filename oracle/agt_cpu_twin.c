@@ -200,3 +200,26 @@ int agt_cpu_project_points(agt_cpu_ctx* c, const void* d_obj, size_t obj_batch_s
     free(obj); free(jbuf);
     return AGT_OK;
 }
+
+/* twins of the synchronous host-array entry points (round 5): the same calls, already on host pointers */
+int agt_cpu_solve_pnp_host(agt_cpu_ctx* c, const void* h_obj, const void* h_img, int dtype, int n,
+                           const double* K, const double* dist, int ndist,
+                           double* h_pose, int use_guess, int32_t* h_info, double* h_err)
+{
+    if (!c || !h_obj || !h_img || !h_pose) return AGT_ERR_ARG;
+    if (!use_guess && n < 4) return AGT_ERR_NPOINTS;
+    double pose[6] = { 0, 0, 0, 0, 0, 0 };
+    if (use_guess) memcpy(pose, h_pose, sizeof(pose));
+    int rc = agt_cpu_solve_pnp(c, h_obj, 0, h_img, dtype, NULL, n, 1, K, dist, ndist, pose, use_guess, h_info, h_err);
+    if (rc == AGT_OK) memcpy(h_pose, pose, sizeof(pose));
+    return rc;
+}
+
+int agt_cpu_project_points_host(agt_cpu_ctx* c, const void* h_obj, int dtype, int n, const double* h_pose,
+                                const double* K, const double* dist, int ndist, void* h_img_out, double* h_jac)
+{
+    if (!c || !h_obj || !h_pose || !h_img_out) return AGT_ERR_ARG;
+    if (dtype != AGT_F32 && dtype != AGT_F64) return AGT_ERR_ARG;
+    if (n <= 0 || n > 256) return AGT_ERR_NPOINTS;
+    return agt_cpu_project_points(c, h_obj, 0, dtype, n, 1, h_pose, K, dist, ndist, h_img_out, h_jac);
+}

@@ -15,7 +15,8 @@ import numpy as np
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TWINS = ["create", "destroy", "pyr_down_u8", "pyramid_build", "pyramid_level", "pyramid_max_level", "lk_track", "solve_pnp", "project_points"]
+TWINS = ["create", "destroy", "pyr_down_u8", "pyramid_build", "pyramid_level", "pyramid_max_level", "lk_track", "solve_pnp", "project_points",
+         "solve_pnp_host", "project_points_host"]
 
 
 def _protos(text, prefix):
@@ -52,6 +53,8 @@ def _twin_lib(oracle):
     L.agt_cpu_lk_track.argtypes = [vp, i32, i32, vp, vp, vp, vp, i32, i32, i32, i32, f64, i32, f64]
     L.agt_cpu_solve_pnp.argtypes = [vp, vp, sz, vp, i32, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp]
     L.agt_cpu_project_points.argtypes = [vp, vp, sz, i32, i32, i32, vp, vp, vp, i32, vp, vp]
+    L.agt_cpu_solve_pnp_host.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp]
+    L.agt_cpu_project_points_host.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp]
     return L
 
 
@@ -93,6 +96,19 @@ def _sequence(call, mem, seq, B=3):
     dpo = mem.to(pose); dimg = mem.to(np.zeros((B, n, 2), np.float32)); dj = mem.to(np.zeros((B, 2 * n, 6), np.float64))
     assert call("project_points", h, mem.ptr(obj), 0, 0, n, B, mem.ptr(dpo), Kp, dpx, 5, mem.ptr(dimg), mem.ptr(dj)) == 0
     out["proj"], out["jac"] = mem.back(dimg), mem.back(dj)
+    # the synchronous host-array entry points (round 5): HOST pointers in both libraries
+    hp = lambda a: a.ctypes.data_as(C.c_void_p)
+    obj64 = np.ascontiguousarray(seq.obj, np.float64)
+    img64 = np.ascontiguousarray(seq.corners(1), np.float64)
+    for tag, guess in (("hguess", 1), ("hnoguess", 0)):
+        pose_h = np.concatenate([seq.rvecs[0], seq.tvecs[0]]).astype(np.float64); info_h = np.zeros(4, np.int32); err_h = np.zeros(1)
+        assert call("solve_pnp_host", h, hp(obj64), hp(img64), 1, n, Kp, dpx, 5, hp(pose_h), guess, hp(info_h), hp(err_h)) == 0
+        out["pose_" + tag], out["info_" + tag], out["merr_" + tag] = pose_h[None].copy(), info_h[None].copy(), err_h.copy()
+    pose_h = np.concatenate([seq.rvecs[1], seq.tvecs[1]]).astype(np.float64)
+    proj_h = np.zeros((n, 2), np.float64); jac_h = np.zeros((2 * n, 6), np.float64)
+    assert call("project_points_host", h, hp(obj64), 1, n, hp(pose_h), Kp, dpx, 5, hp(proj_h), hp(jac_h)) == 0
+    out["hproj"], out["hjac"] = proj_h, jac_h
+    assert call("project_points_host", h, hp(obj64), 1, 300, hp(pose_h), Kp, dpx, 5, hp(proj_h), None) == -4               # AGT_ERR_NPOINTS in both
     small = np.ascontiguousarray(fa[:, :100, :160])                  # pyrDown of a crop: 160 x 100 -> 80 x 50
     dsrc = mem.to(small); ddst = mem.to(np.zeros((B, 50, 80), np.uint8))
     assert call("pyr_down_u8", h, mem.ptr(dsrc), 160, 100, 160, 160 * 100, mem.ptr(ddst), 80, 80 * 50, B) == 0
@@ -133,6 +149,11 @@ def test_twin_does_what_the_oracle_does(oracle, seq640):
     assert np.abs(r["pose_guess"] - r["pose_noguess"]).max() < 1e-6
     pp, _ = oracle.projectPoints(seq640.obj, seq640.rvecs[1], seq640.tvecs[1], seq640.K, np.array([0.05, -0.1, 1e-3, -1e-3, 0.02]))
     assert np.abs(r["proj"][1] - pp.reshape(-1, 2)).max() < 1e-3          # (float32 output)
+    # the host-array twins are the same calls with B = 1
+    from accurate_aprilgroup_tracking_amd import synthetic as syn
+    pj, jj = oracle.projectPoints(seq640.obj, seq640.rvecs[1], seq640.tvecs[1], seq640.K, np.array(syn.MILD_DIST, np.float64).ravel(), jacobian=True)
+    assert np.array_equal(r["hproj"], pj.reshape(-1, 2)) and r["hjac"].shape == (96, 6) and np.abs(r["hjac"] - jj).max() < 1e-9
+    assert r["info_hguess"][0, 0] == 1 and r["info_hnoguess"][0, 0] == 1 and np.abs(r["pose_hguess"] - r["pose_hnoguess"]).max() < 1e-6
 
 
 @pytest.mark.gpu
@@ -183,5 +204,9 @@ def test_same_call_sequence_on_the_hip_library_and_on_its_cpu_twin(oracle, seq64
     for k in ("merr_guess", "merr_noguess", "merr_guess_dist"):
         assert np.abs(g[k] - c[k]).max() < 1e-9, k
     assert np.abs(g["proj"] - c["proj"]).max() < 1e-4                      # float32 outputs of values ~1e2: one ulp is 8e-6
-    for k in ("info_guess", "info_noguess", "info_guess_dist"):
+    for k in ("info_guess", "info_noguess", "info_guess_dist", "info_hguess", "info_hnoguess"):
         assert np.array_equal(g[k][:, [0, 1, 2]], c[k][:, [0, 1, 2]]), k   # ok, LM iterations, points used
+    # the host-array entry points (f64 in and out, distorting camera)
+    for k in ("pose_hguess", "pose_hnoguess", "merr_hguess", "merr_hnoguess", "hproj"):
+        assert np.abs(g[k] - c[k]).max() < 1e-9, "%s: %g" % (k, np.abs(g[k] - c[k]).max())
+    assert np.abs(g["hjac"] - c["hjac"]).max() < 1e-6
