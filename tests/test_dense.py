@@ -97,13 +97,17 @@ def test_oracle_converges_to_known_pose(oracle, scene):
     assert st2["iters"] < 50
 
 
+# (round 5: "tilt" = the 14-coefficient model with a tilted sensor -- the dense stage projects through agt_project like the solver)
+TILT14 = np.array([[0.02, -0.01, 1e-3, -1e-3, 0.005, 0.01, -0.005, 0.002, 5e-4, -5e-4, 2e-4, 3e-4, 0.004, -0.003]])
+
+
 @pytest.mark.gpu
-@pytest.mark.parametrize("use_dist", [False, True])
+@pytest.mark.parametrize("use_dist", [False, True, "tilt"])
 def test_hip_matches_oracle(oracle, scene, use_dist):
     import torch
     from accurate_aprilgroup_tracking_amd import cv_hip
     s, mx = scene
-    dist = syn.MILD_DIST if use_dist else None
+    dist = TILT14 if use_dist == "tilt" else (syn.MILD_DIST if use_dist else None)
     T = _template(s, mx, 1)
     rng = np.random.default_rng(1)
     B = 3
