@@ -169,7 +169,13 @@ int camera_on(agt_ctx* c, const double* K, const double* dist, int ndist, AgtCam
     if (!tracker) {
         slot = -1;
         for (int i = 1; i < AGT_TILT_SLOTS; i++) if (c->tilt_valid[i] && !memcmp(c->tilt_host[i], t.m, sizeof(t.m))) { slot = i; break; }
-        if (slot < 0) { c->tilt_next = c->tilt_next % (AGT_TILT_SLOTS - 1) + 1; slot = c->tilt_next; c->tilt_valid[slot] = 0; }
+        if (slot < 0) {
+            c->tilt_next = c->tilt_next % (AGT_TILT_SLOTS - 1) + 1; slot = c->tilt_next;
+            // an eighth distinct tilted camera recycles a slot: launches that read its old content may sit on ANY stream the context was
+            // bound to (agt_set_stream) -- wait for the device once (a camera change of this kind is not a per-frame event)
+            if (c->tilt_valid[slot] && hipDeviceSynchronize() != hipSuccess) return hip_fail(c, hipGetLastError());
+            c->tilt_valid[slot] = 0;
+        }
     }
     if (!c->tilt_valid[slot] || memcmp(c->tilt_host[slot], t.m, sizeof(t.m))) {
         memcpy(c->tilt_host[slot], t.m, sizeof(t.m));

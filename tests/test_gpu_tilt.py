@@ -144,3 +144,20 @@ def test_tracker_on_a_tilted_camera(torch_cuda, oracle, pipeline):
         accepted += int(st[0, H.ST_OK])
         pts = nx.astype(np.float32); pyr = npyr
     assert accepted >= len(s) - 2
+
+
+def test_more_tilted_cameras_than_table_slots(cvh, oracle):
+    """the context keeps the tilt matrices of seven cameras of stateless calls on the device (agt_api.hip camera_on): twelve cameras in
+    turn, then the first ones again -- every projection and solve goes through ITS camera's matrices (a recycled slot is rewritten)"""
+    s = syn.Sequence(1280, 720, n_frames=2, seed=91)
+    cams = [np.array([0.02, -0.01, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0.01 * (i + 1), -0.007 * (i % 5) + 0.002]) for i in range(12)]
+    seen = set()
+    for rnd in range(2):
+        for i, dist in enumerate(cams):
+            img_o = oracle.projectPoints(s.obj, s.rvecs[1], s.tvecs[1], s.K, dist)[0].reshape(-1, 2)
+            img_h = cvh.projectPoints(s.obj, s.rvecs[1], s.tvecs[1], s.K, dist)[0].reshape(-1, 2)
+            assert np.abs(img_h - img_o).max() < 1e-9, (rnd, i)
+            seen.add(tuple(np.round(img_o[0], 6)))
+            ok, rv, tv = cvh.solvePnP(s.obj, img_o, s.K, dist, s.rvecs[0].copy(), s.tvecs[0].copy(), True)
+            assert ok and np.abs(rv.ravel() - s.rvecs[1]).max() < 1e-6 and np.abs(tv.ravel() - s.tvecs[1]).max() < 1e-6, (rnd, i)
+    assert len(seen) == 12                  # the cameras really differ
