@@ -895,6 +895,7 @@ static int launch_group(agt_ctx* c, int B)
     AgtStepTables T;
     memset(&S, 0, sizeof(S));
     memset(&T, 0, sizeof(T));
+    S.pnp.fault = c->fault_dev;                  // (also where the launch has no pose role: the LK role reports a table it cannot use through it)
     long done_before[AGT_MAX_LEVELS + 1];        // [s] = frames available as input of stage s (s = L: input of LK)
     done_before[0] = c->trk_frame;
     for (int s = 0; s < L; s++) done_before[s + 1] = c->n_stage[s];
@@ -1031,6 +1032,15 @@ static int launch_group(agt_ctx* c, int B)
 #endif
     }
     if (!any) return AGT_OK;
+#ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_TABLE_POISON_PNP=k / AGT_TABLE_POISON_LK=k put a word that cannot be an address (the bits of a
+    // NaN) into the second frame's entry of the k-th launch whose pose / LK role runs more than one frame -- what a stale or clobbered LDS
+    // table would hand the role.  tests/test_gpu_tracker.py: the launch must drain, flag and report, not fault.
+    { static const int pk = [] { const char* e = getenv("AGT_TABLE_POISON_PNP"); return e ? atoi(e) : 0; }();
+      static const int lk = [] { const char* e = getenv("AGT_TABLE_POISON_LK"); return e ? atoi(e) : 0; }();
+      static int seen_p = 0, seen_l = 0;
+      if (pk > 0 && S.pnp_nf > 1 && ++seen_p == pk) T.pnp.img[1] = (const float*)0x7ff8dead00000000ull;
+      if (lk > 0 && S.lk_nf > 1 && ++seen_l == lk) T.lk.img[2][0] = (const uint8_t*)0x7ff8dead00000000ull; }
+#endif
     if (agt_step_fits(c->trk_n, B)) {
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: AGT_PYR_SEPARATE=1 issues the pyramid role as its own launch, ahead of LK | PnP
         { static const int sep = [] { const char* e = getenv("AGT_PYR_SEPARATE"); return e ? atoi(e) : 0; }();

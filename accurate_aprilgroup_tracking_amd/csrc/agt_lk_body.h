@@ -255,6 +255,12 @@ __host__ __device__ constexpr size_t lk_lds_bytes(int levels)
 }
 
 
+// A coordinate the tracker will not form an address from: non-finite or |x| >= 2^20.  OpenCV floors such a value to an integer far
+// outside every image (cvFloor of a NaN or of anything beyond the int range is INT_MIN on x86) and so finds the window "outside the
+// image" at every level: status 0, err 0, the position carried -- which is what the bodies below do with it up front (a GPU
+// float -> int conversion turns a NaN into 0, i.e. INTO the image).  Finite positions below 2^20 go through the usual bounds tests.
+__device__ __forceinline__ bool lk_pt_ok(float x, float y) { return fabsf(x) < 1048576.f && fabsf(y) < 1048576.f; }
+
 // Where one frame of the tracker reads and writes.  grouped = image bases come from imgI / imgJ (the frame
 // group of the fused step) instead of P.prev / P.next; have_pos = the previous position comes in registers
 // (frame 2.. of a group: the corner was tracked by this same workgroup a moment ago) instead of from prev_pts.
@@ -266,6 +272,7 @@ struct LkFrameIo {
     const float* prev_pts; float* next_pts; uint8_t* status; float* err;
     bool have_pos; float px, py; int pst;       // pst: the corner's status after the previous frame (with have_pos)
     unsigned* done = nullptr;                   // chained launch (agt_step.hip): arrival counters of this frame, [B]; see lk_publish
+    bool bad = false;                           // frame group: the frame's table entries cannot be addresses (agt_step.hip lk_role) -- nothing of the frame is touched
     uint8_t* iters_out = nullptr;               // stand-alone launches of big batches: iterations the corner took, [B][n] (AgtLkParams::iters_out)
 };
 
@@ -354,6 +361,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
 
     const float halfw = (WIN - 1) * 0.5f;
     const float FLT_SCALE = 1.f / (1 << 20);
+    if (io.bad) { ox = io.px; oy = io.py; ost = 0; return; }      // (wave-uniform; only frames 2.. of a group can be: have_pos holds)
     const float ppx = io.have_pos ? io.px : io.prev_pts[pidx * 2], ppy = io.have_pos ? io.py : io.prev_pts[pidx * 2 + 1];
     // tracker mode: a corner that was lost (left the image, flat patch) is not picked up again by whatever texture
     // sits at its last position -- it stays lost, position carried, until the corner set is re-seeded
@@ -361,6 +369,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         int pst = 1;
         if (io.have_pos) pst = io.pst;
         else if (P->prev_status) pst = P->prev_status[pidx];
+        if (!lk_pt_ok(ppx, ppy)) pst = 0;          // (a wild position is a lost corner: see lk_pt_ok)
         if (!agt_uniform(pst)) {
             if (tid == 0) lk_publish(io, pidx, b, ppx, ppy, 0, 0.f);
             ox = ppx; oy = ppy; ost = 0;
@@ -368,7 +377,14 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         }
     }
     float outx = 0.f, outy = 0.f;              // nextPts[ptidx]
-    if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
+    if (P->flags & AGT_LK_USE_INITIAL_FLOW) {
+        outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1];
+        if (!agt_uniform((int)lk_pt_ok(outx, outy))) {        // a wild initial flow: the search window is outside the next image at every level
+            if (tid == 0) lk_publish(io, pidx, b, outx, outy, 0, 0.f);
+            ox = outx; oy = outy; ost = 0;
+            return;
+        }
+    }
     const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;     // where the search is expected to start
     const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 

@@ -255,6 +255,10 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
     for (int k = 0; k < nf; k++) {
         if (k) lds_barrier();                  // everyone is done with the previous frame's LDS; the table copy is visible
         const LkFrameIo<NLEV> io = frame(k);
+        if (io.bad) {                          // the frame's table entries cannot be addresses: the group ends here for this corner (uniform over
+            if (tid == 0 && owed) lk_arrive(owed, b);      // the workgroup); whoever waits for its frames gives up and reports (agt_step.hip)
+            return;
+        }
         if (k == 0) {
             if (io.have_pos) { px = io.px; py = io.py; pst = io.pst; }       // (lk_reseed_kernel: the start position was computed in the launch)
             else {
@@ -262,6 +266,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 pst = P->prev_status ? (int)P->prev_status[pidx] : 1;
             }
             px = agt_uniform(px); py = agt_uniform(py); pst = agt_uniform(pst);
+            if (!lk_pt_ok(px, py)) pst = 0;    // (a wild position is a lost corner: agt_lk_body.h lk_pt_ok)
         }
 #ifdef AGT_STEP_STAMPS
         if (pidx == 0 && threadIdx.x == 0 && k < 4) agt_chain_stamps[k * 16 + 14] = 0;
@@ -453,7 +458,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                 // at the image origin and is left to the next frame's on-demand path): any branch around a load makes the
                 // compiler copy the register array at the merge, and the copy waits for the loads issued so far.
                 const LkFrameIo<NLEV> nio = frame(k + 1);
-                if (agt_uniform((int)all_safe)) {
+                if (agt_uniform((int)(all_safe && !nio.bad))) {
                     CREPS(4) {
                     nmask = 0;
 #pragma unroll

@@ -131,7 +131,7 @@ __host__ __device__ constexpr size_t lk_rs_lds_bytes(int levels) { return (size_
 // true when every derivative position the 21x21 window of `pt` touches lies inside the image at every level
 __device__ __forceinline__ bool rs_interior(float ppx, float ppy, int max_level, int w0, int h0)
 {
-    bool ok = true;
+    bool ok = lk_pt_ok(ppx, ppy);              // (a NaN converts to 0, "inside": agt_lk_body.h lk_pt_ok)
     int w = w0, h = h0;
     for (int l = 0; l <= max_level; l++) {
         const float scale = 1.f / (float)(1 << l);
@@ -183,7 +183,14 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     int nit = 0;                    // iterations over all levels (only kept where io.iters_out is set)
 
     float outx = 0.f, outy = 0.f;
-    if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
+    if (P->flags & AGT_LK_USE_INITIAL_FLOW) {
+        outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1];
+        if (!agt_uniform((int)lk_pt_ok(outx, outy))) {        // a wild initial flow: lost, position carried (agt_lk_body.h lk_pt_ok)
+            if (tid == 0) lk_publish(io, pidx, b, outx, outy, 0, 0.f);
+            ox = outx; oy = outy; ost = 0;
+            return;
+        }
+    }
     const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;
     const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 

@@ -49,6 +49,46 @@ extern "C" int agt_debug_role_stamps(unsigned long long* host) { return (int)hip
 #define RSTAMP(k, i)
 #endif
 
+
+// ---- Copies whose ordering must not rest on type-based alias rules (round 6; profiles/r06_aperture_violation.md).
+// The per-frame pointer tables (kernel arguments) and the tracker state are copied to / from LDS as raw 8-byte words while every
+// other access to them is typed (pointers, doubles, ints).  Written through `uint32_t*` / `double*` views, the copies were, to the
+// compiler's type-based alias analysis, unrelated to the typed reads that follow them: the order rested on the fences and asm
+// clobbers between them alone.  A character copy aliases every type, so the
+// dependency from a copy to each typed read (and from each typed write to the copy back) is one the optimiser and the machine
+// scheduler both see, under any scheduling strategy.  A `may_alias` 64-bit word is that character copy at its natural alignment
+// (or a 32-bit one).  One word per lane and trip; n8 words, `stride` lanes, lane index `t`.
+typedef unsigned long long __attribute__((may_alias)) agt_word_t;
+__device__ __forceinline__ void agt_copy_words_to_lds(void* dst_lds, const void* src, int n8, int t, int stride)
+{
+    for (int i = t; i < n8; i += stride) static_cast<agt_word_t*>(dst_lds)[i] = static_cast<const agt_word_t*>(src)[i];
+}
+typedef unsigned int __attribute__((may_alias)) agt_halfword_t;
+__device__ __forceinline__ void agt_copy_halfwords_to_lds(void* dst_lds, const void* src, int n4, int t, int stride)
+{
+    for (int i = t; i < n4; i += stride) static_cast<agt_halfword_t*>(dst_lds)[i] = static_cast<const agt_halfword_t*>(src)[i];
+}
+// A pointer that came out of an LDS table is dereferenced only if it looks like one: user-space device and host-mapped addresses
+// on this platform have bits 47.. clear.  Anything else (stale LDS, a clobbered table) would be an access "beyond the largest legal
+// address" -- HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION, which aborts the queue and the process.  The roles turn it into the
+// fail-stop of a chained wait that gave up instead (record flagged, stream frozen, host told): the reference never crashes on a
+// bad frame (detect_pose.py:570-574).
+__device__ __forceinline__ bool agt_ptr_plausible(unsigned long long p) { return (p >> 47) == 0; }
+// ... the LK role's: every image, output and counter pointer a frame of the group took from the LDS copy of the tables (wave-uniform)
+template <int NLEV>
+__device__ __forceinline__ bool lk_table_bad(const agt_lk::LkFrameIo<NLEV>& io, int max_level)
+{
+    unsigned long long acc = (unsigned long long)io.next_pts | (unsigned long long)io.status | (unsigned long long)io.done;
+    bool null_img = io.next_pts == nullptr || io.status == nullptr;
+#pragma unroll
+    for (int l = 0; l < NLEV; l++)
+        if (l <= max_level) {
+            acc |= (unsigned long long)io.imgI[l] | (unsigned long long)io.imgJ[l];
+            null_img = null_img || io.imgI[l] == nullptr || io.imgJ[l] == nullptr;
+        }
+    return agt_uniform((int)(null_img || !agt_ptr_plausible(acc))) != 0;
+}
+
 #ifndef AGT_LKG_OCC
 #define AGT_LKG_OCC 4            // waves per SIMD the one-wave-per-corner LK group kernel is register-allocated for (4: 128 VGPRs)
 #endif
@@ -82,12 +122,11 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
     // frame's corner position and tiles are still in flight; the first frame itself uses the statically indexed `S`.
     AgtLkTables* tab = reinterpret_cast<AgtLkTables*>(my + per - LKB);
     {
+        static_assert(sizeof(AgtLkTables) % 8 == 0, "table copy: 8-byte words");
         const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
-        const __attribute__((address_space(4))) uint32_t* src = (const __attribute__((address_space(4))) uint32_t*)&KT->lk;
-        if (S.lk_nf > 1) {
-            const uint32_t* gsrc = (const uint32_t*)src;              // vector loads: one per lane, all in flight at once
-            for (int i = tid; i < (int)(LKB / 4); i += AGT_WAVE * NW) reinterpret_cast<uint32_t*>(tab)[i] = gsrc[i];
-        }
+        // (vector loads through a generic view of the kernel-argument segment: one word per lane, all in flight at once; a character
+        // copy -- see agt_copy_words_to_lds -- so the typed reads of tab->... below depend on it for every alias analysis)
+        if (S.lk_nf > 1) agt_copy_words_to_lds(tab, (const void*)(const __attribute__((address_space(4))) void*)&KT->lk, (int)(LKB / 8), tid, AGT_WAVE * NW);
     }
     if constexpr (WIN == 21 && NW == 4) {
         // one workgroup per corner: the frame-chained body (agt_lk_chain_body.h) for what the tracker asks for.  A launch of a
@@ -106,6 +145,8 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
 #pragma unroll
                     for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
                     io.next_pts = tab->next[k]; io.status = tab->status[k]; io.done = tab->done[k];
+                    io.bad = lk_table_bad(io, S.lk.max_level);
+                    if (io.bad && threadIdx.x == 0 && S.pnp.fault) __hip_atomic_store(S.pnp.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
                 }
                 return io;
             };
@@ -126,6 +167,8 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
 #pragma unroll
             for (int l = 0; l < NLEV; l++) { io.imgI[l] = tab->img[k][l]; io.imgJ[l] = tab->img[k + 1][l]; }
             io.next_pts = tab->next[k]; io.status = tab->status[k]; io.done = tab->done[k];
+            io.bad = lk_table_bad(io, S.lk.max_level);
+            if (io.bad && (threadIdx.x & (AGT_WAVE * NW - 1)) == 0 && S.pnp.fault) __hip_atomic_store(S.pnp.fault, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         return io;
     };
@@ -147,6 +190,7 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
             const unsigned long long tq0 = __builtin_amdgcn_s_memtime();
 #endif
             const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
+            if (io.bad) return;
             agt_lk::lk_body_rs<NW, NLEV>(&KS->lk, pt, b, my, io, ppx, ppy, px, py, pst);
 #ifdef AGT_STEP_LK_STAMPS
             if ((threadIdx.x & 63) == 0) {       // experiment: slowest / summed per-frame time over all corners, frames in the row-segment loop
@@ -159,6 +203,7 @@ __device__ __forceinline__ void lk_role(const AgtStepParams& S, const AgtStepTab
     }
     for (; k < S.lk_nf; k++) {
         const agt_lk::LkFrameIo<NLEV> io = frame_io(k);
+        if (io.bad) return;
         agt_lk::lk_body<WIN, NW, NLEV>(&KS->lk, pt, b, my, io, px, py, pst);
 #ifdef AGT_STEP_LK_STAMPS
         if ((threadIdx.x & 63) == 0) atomicAdd(&agt_lk_stamps[58], 1ull);
@@ -252,10 +297,10 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
     // stores to be acknowledged before it may signal, the reader's loads go out to L2.  Loaded here, written back by the wave
     // that solves the launch's last frame.
     if (NWV == 1) {
-        if (S.pnp_nf > 1)
-            for (unsigned i = lane; i < sizeof(AgtPnpTables) / 4; i += AGT_WAVE)
-                reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
-        if (lane < (int)(sizeof(AgtTrackState) / 8)) reinterpret_cast<double*>(&sh.ts)[lane] = reinterpret_cast<const double*>(S.pnp.track + blk)[lane];
+        // (character copies: agt_copy_words_to_lds.  The table is copied whenever a later frame will read it -- S.pnp_nf > 1 -- and
+        // read only then: frame 0 takes its pointers from the kernel arguments, frames k >= 1 exist only when S.pnp_nf > 1)
+        if (S.pnp_nf > 1) agt_copy_words_to_lds(sh.tab, (const void*)(const __attribute__((address_space(4))) void*)&KT->pnp, (int)(sizeof(AgtPnpTables) / 8), lane, AGT_WAVE);
+        agt_copy_words_to_lds(&sh.ts, S.pnp.track + blk, (int)(sizeof(AgtTrackState) / 8), lane, AGT_WAVE);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     }
     // (NWV == 2: the caller has copied the tables and the state and zeroed sh.seq with the whole workgroup, behind a barrier)
@@ -268,8 +313,17 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
         RSTAMP(k, 0);
         if (k) {
             if (NWV == 1) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_wave_barrier(); }      // (tables, state: LDS)
-            img = (const void*)sh.tab[k]; mask = (const uint8_t*)sh.tab[AGT_MAX_GROUP + k]; so = (double*)sh.tab[2 * AGT_MAX_GROUP + k];
-            wait = (const unsigned*)sh.tab[3 * AGT_MAX_GROUP + k]; target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
+            unsigned long long t_img = sh.tab[k], t_mask = sh.tab[AGT_MAX_GROUP + k], t_so = sh.tab[2 * AGT_MAX_GROUP + k];
+            unsigned long long t_wait = sh.tab[3 * AGT_MAX_GROUP + k];
+            target = (unsigned)sh.tab[4 * AGT_MAX_GROUP + k];
+            // a table entry that cannot be an address is never dereferenced: the frame takes the give-up path of a chained wait
+            // (nothing solved, record -- if its destination is believable -- flagged, stream frozen, host told)
+            if (!agt_uniform((int)(t_img != 0 && agt_ptr_plausible(t_img | t_mask | t_so | t_wait)))) {
+                late = 1;
+                t_img = (unsigned long long)T.pnp.img[0]; t_mask = 0; t_wait = 0;
+                if (!agt_ptr_plausible(t_so)) t_so = 0;
+            }
+            img = (const void*)t_img; mask = (const uint8_t*)t_mask; so = (double*)t_so; wait = (const unsigned*)t_wait;
         }
         if (wait) {
             if (!late) {
@@ -309,7 +363,7 @@ __device__ __forceinline__ void pnp_role(const AgtStepParams& S, const AgtStepTa
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         RSTAMP(k, 3);
         if (k == S.pnp_nf - 1 && lane < (int)(sizeof(AgtTrackState) / 8))
-            reinterpret_cast<double*>(S.pnp.track + blk)[lane] = reinterpret_cast<const double*>(&sh.ts)[lane];
+            reinterpret_cast<agt_word_t*>(S.pnp.track + blk)[lane] = reinterpret_cast<const agt_word_t*>(&sh.ts)[lane];      // (character copy: see agt_copy_words_to_lds)
         if (NWV > 1) {
             if (lane == 0) *(volatile int*)&sh.seq = k + 1;
         }
@@ -405,10 +459,11 @@ __global__ __launch_bounds__(STEP_THREADS) __attribute__((amdgpu_waves_per_eu(OC
     if (PNP && blk < S.n_pnp) {
         // fused path (n <= 64): two waves alternate over the frames (see pnp_role); the whole workgroup sets their scratch up
         agt_pnp::PnpShared& sh = *reinterpret_cast<agt_pnp::PnpShared*>(lds);
-        for (unsigned i = threadIdx.x; i < sizeof(AgtPnpTables) / 4; i += STEP_THREADS)
-            reinterpret_cast<uint32_t*>(sh.tab)[i] = ((const uint32_t*)(const __attribute__((address_space(4))) uint32_t*)&KT->pnp)[i];
+        // (32-bit words here: the same copy in 64-bit words leaves step_kernel<21,4,6> a dead 48-byte stack object -- a private segment
+        // for every launch; tests/test_kernel_resources.py holds every kernel of the library to none)
+        agt_copy_halfwords_to_lds(sh.tab, (const void*)(const __attribute__((address_space(4))) void*)&KT->pnp, (int)(sizeof(AgtPnpTables) / 4), (int)threadIdx.x, STEP_THREADS);
         if (threadIdx.x == 0) { sh.seq = 0; sh.late = 0; }
-        if (threadIdx.x < sizeof(AgtTrackState) / 8) reinterpret_cast<double*>(&sh.ts)[threadIdx.x] = reinterpret_cast<const double*>(S.pnp.track + blk)[threadIdx.x];
+        agt_copy_words_to_lds(&sh.ts, S.pnp.track + blk, (int)(sizeof(AgtTrackState) / 8), (int)threadIdx.x, STEP_THREADS);
         __syncthreads();
         const int wave = (int)(threadIdx.x / AGT_WAVE);
         if (wave >= 2) return;

@@ -162,6 +162,42 @@ def test_lk_edge_cases(cvh, oracle, seq640):
         _assert_lk_equal(o, g)
 
 
+def test_lk_wild_coordinates_are_lost_corners(cvh, oracle, seq640):
+    """a coordinate that is not finite, or far outside anything an image can be, never reaches an address
+    computation.  OpenCV floors such a value to an integer outside every image (cvFloor(NaN) = INT_MIN on x86) and reports the
+    corner lost with its position carried; a GPU float -> int conversion turns a NaN into 0 -- INTO the image.  The kernels test the
+    position up front (agt_lk_body.h lk_pt_ok): status 0, err 0, nextPts = the position, bit for bit the oracle's answer, in every
+    tracker body (one and four waves per corner, general and row-segment form), with and without an initial flow, and the good
+    corners beside the wild ones are tracked exactly as without them."""
+    a, b = seq640.frame(0), seq640.frame(1)
+    good = seq640.corners(0)[:24].copy()
+    wild = np.array([[np.nan, 10], [10, np.nan], [np.inf, 50], [-np.inf, -np.inf], [1e30, 1e30], [-3e9, 20], [2.0 ** 20, 100],
+                     [2.0 ** 20 - 1, 100], [1.5e6, 2.0e6], [np.nan, np.nan], [200, -np.inf], [3.4e38, 100]], np.float32)
+    pts = np.concatenate([good[:12], wild, good[12:]])
+    ref = None
+    for kw in (dict(maxLevel=2), dict(maxLevel=2, flags=8), dict(maxLevel=0), dict(maxLevel=3), dict(maxLevel=2, winSize=(15, 15)),
+               dict(maxLevel=2, winSize=(31, 31))):
+        o, g = _lk_both(cvh, oracle, a, b, pts, **kw)
+        _assert_lk_equal(o, g)
+        assert not g[1][12:12 + len(wild)].any() and not g[2][12:12 + len(wild)].any()
+        assert np.array_equal(g[0].reshape(-1, 2)[12:12 + len(wild)].view(np.uint32), wild.view(np.uint32)), "position carried"
+        if ref is None:
+            og, gg = _lk_both(cvh, oracle, a, b, good, maxLevel=2)
+            keep = np.r_[0:12, 12 + len(wild):len(pts)]
+            assert np.array_equal(g[0].reshape(-1, 2)[keep].view(np.uint32), gg[0].reshape(-1, 2).view(np.uint32)) and g[1].ravel()[keep].all()
+            ref = True
+    # a big batch takes the one-wave-per-corner kernel (row-segment body for interior corners): same answers
+    big = np.concatenate([np.tile(good, (60, 1)), wild, np.tile(good, (4, 1))])
+    o, g = _lk_both(cvh, oracle, a, b, big, maxLevel=2)
+    _assert_lk_equal(o, g)
+    # initial flow: a wild flow is a lost corner carrying the flow; a wild position with a sane flow carries the position
+    init = pts + 0.5
+    init[0] = [np.nan, np.nan]; init[1] = [np.inf, 3]; init[2] = [1e25, 1e25]; init[3] = [-1e9, 7]
+    o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2, flags=4, nextPts=init)
+    _assert_lk_equal(o, g)
+    assert not g[1][:4].any() and g[1].ravel()[4:12].all()
+
+
 def test_lk_random_texture_other_sizes(cvh, oracle):
     from scipy.ndimage import gaussian_filter, shift
     rng = np.random.default_rng(11)

@@ -724,3 +724,93 @@ def test_chain_give_up_is_fail_stop(torch_cuda, seq640):
     r = out["recovered"]
     assert r["codes"] == [0, 0] and r["chain_fault"] == 0
     assert np.array_equal(np.array(r["rec"]), clean), "agt_tracker_reset recovers the stream"
+
+
+_POISON_CHILD = r'''
+import json, os, sys
+import numpy as np
+sys.path.insert(0, os.environ["AGT_REPO_ROOT"])
+from accurate_aprilgroup_tracking_amd import hiplib as H
+H.LIB_PATH = os.path.join(os.environ["AGT_REPO_ROOT"], "accurate_aprilgroup_tracking_amd", "libagt_hip_dbg.so")
+import torch
+from accurate_aprilgroup_tracking_amd import synthetic as syn
+from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+B = int(os.environ["AGT_TEST_STREAMS"])
+s = syn.Sequence(640, 480, n_tags=12, n_frames=6, seed=0)
+frames = torch.from_numpy(s.frames()).cuda()
+order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+c0 = torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous()
+trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+trk.pipeline(4)
+out = {}
+def run(tag):
+    trk.reset(frames[0:1].repeat(B, 1, 1).contiguous(), c0)
+    so = trk.new_state_buffer(len(order))
+    codes = []
+    keep = []
+    for i, k in enumerate(order):
+        f = frames[k:k + 1].repeat(B, 1, 1).contiguous(); keep.append(f)
+        trk.step(f, so[i])
+    try:
+        trk.join(); codes.append(0)
+    except H.AgtError as e:
+        codes.append(e.code)
+    codes.append(trk.ctx.L.agt_synchronize(trk.ctx.h))
+    st = trk.read_state()
+    out[tag] = dict(rec=so.cpu().numpy().tolist(), codes=codes, chain_fault=[x.chain_fault for x in st])
+run("faulted")          # the knob poisons one table entry of one launch
+run("recovered")        # the knob has fired; agt_tracker_reset must bring the streams back
+print("RESULT " + json.dumps(out))
+'''
+
+
+@pytest.mark.parametrize("role,streams", [("PNP", 1), ("LK", 1), ("PNP", 8), ("LK", 8)])
+def test_poisoned_table_entry_is_fail_stop(torch_cuda, seq640, role, streams):
+    """VERDICT r5 #1 (harden): a per-frame table entry that cannot be an address -- what a stale or clobbered LDS copy of the
+    kernel-argument tables would hand a role -- is never dereferenced.  The diagnostic library puts the bits of a NaN into the
+    second frame's entry of one launch (AGT_TABLE_POISON_PNP / _LK); one stream runs the fused chained step (step_kernel), eight
+    streams the split pipeline (pnp_group_kernel<1> / lk_group_kernel).  Expected: no GPU fault (the child exits 0, the queue is
+    not aborted with HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION), the launch drains, agt_synchronize reports AGT_ERR_CHAIN, frames
+    before the poisoned one are those of a clean run, and agt_tracker_reset brings the streams back bit for bit."""
+    import subprocess
+    import sys
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dbg = os.path.join(root, "accurate_aprilgroup_tracking_amd", "libagt_hip_dbg.so")
+    if not os.path.exists(dbg):
+        subprocess.check_call(["make", "-s", "-j", "8", "-C", os.path.join(root, "accurate_aprilgroup_tracking_amd", "csrc"), "dbg"])
+    env = dict(os.environ, AGT_REPO_ROOT=root, AGT_TEST_STREAMS=str(streams))
+    env["AGT_TABLE_POISON_" + role] = "2"
+    res = subprocess.run([sys.executable, "-c", _POISON_CHILD], env=env, capture_output=True, text=True, timeout=300)
+    assert res.returncode == 0, res.stderr[-2000:]
+    out = json.loads([l for l in res.stdout.splitlines() if l.startswith("RESULT ")][-1][7:])
+    s = seq640
+    frames = torch.from_numpy(s.frames()).cuda()
+    order = [1, 2, 3, 4, 5, 4, 3, 2, 1, 0, 1, 2]
+    B = streams
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+    trk.pipeline(4)
+    trk.reset(frames[0:1].repeat(B, 1, 1).contiguous(), torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous())
+    so = trk.new_state_buffer(len(order))
+    keep = []
+    for i, k in enumerate(order):
+        keep.append(frames[k:k + 1].repeat(B, 1, 1).contiguous())
+        trk.step(keep[-1], so[i])
+    trk.join()
+    clean = so.cpu().numpy()
+    assert clean[:, :, H.ST_OK].all()
+    f, r = out["faulted"], out["recovered"]
+    rec = np.array(f["rec"])
+    assert f["codes"][1] == -8, "agt_synchronize reports AGT_ERR_CHAIN (codes %s)" % f["codes"]
+    differs = np.nonzero((rec != clean).any(axis=(1, 2)))[0]
+    assert len(differs) and differs[0] >= 4, "the poisoned entry belongs to the second multi-frame launch: the first four frames are clean"
+    if role == "PNP" or streams == 1:
+        # the pose role saw the poisoned entry itself (PNP) or gave up waiting for the LK role that did (LK, chained): flagged records
+        flags = rec[:, :, H.ST_FLAGS].astype(int)
+        assert (flags[differs[0]:] & H.TRK_CHAIN_TIMEOUT).all() and not (flags[:differs[0]] & H.TRK_CHAIN_TIMEOUT).any()
+        assert (rec[differs[0]:, :, :8] == 0).all(), "nothing is solved behind a table entry that is not an address"
+        assert all(f["chain_fault"])
+    assert r["codes"] == [0, 0] and not any(r["chain_fault"])
+    assert np.array_equal(np.array(r["rec"]), clean), "agt_tracker_reset recovers the streams"

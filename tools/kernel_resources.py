@@ -19,8 +19,10 @@ def demangle(names):
     return dict(zip(names, out))
 
 
-def main():
-    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "accurate_aprilgroup_tracking_amd", "libagt_hip.so")
+def kernel_rows(lib):
+    """-> one dict per kernel of the library's gfx950 code objects: name (demangled), vgpr (arch + acc), agpr, sgpr, vspill,
+    sspill, scratch (private segment bytes), lds (static), wg -- integers (tests/test_kernel_resources.py holds the product
+    library to them)"""
     rows = []
     with tempfile.TemporaryDirectory() as tmp:
         # the fat binary section holds one offload bundle per translation unit
@@ -44,9 +46,20 @@ def main():
                                  sspill=f("sgpr_spill_count"), scratch=f("private_segment_fixed_size"), lds=f("group_segment_fixed_size"),
                                  wg=f("max_flat_workgroup_size")))
     dm = demangle([r["name"] for r in rows])
+    for r in rows:
+        r["name"] = dm[r["name"]]
+        for k in ("vgpr", "agpr", "sgpr", "vspill", "sspill", "scratch", "lds", "wg"):
+            r[k] = int(r[k])
+    return sorted(rows, key=lambda r: r["name"])
+
+
+def main():
+    lib = sys.argv[1] if len(sys.argv) > 1 else os.path.join(ROOT, "accurate_aprilgroup_tracking_amd", "libagt_hip.so")
+    rows = kernel_rows(lib)
+    dm = {r["name"]: r["name"] for r in rows}
     print("# %s" % os.path.relpath(lib, ROOT))
     print("# vgpr agpr sgpr vgpr_spill sgpr_spill scratch_B static_lds_B max_wg  kernel")
-    for r in sorted(rows, key=lambda r: dm[r["name"]]):
+    for r in rows:
         print("%4s %4s %4s %6s %6s %7s %7s %5s  %s" % (r["vgpr"], r["agpr"], r["sgpr"], r["vspill"], r["sspill"], r["scratch"], r["lds"], r["wg"], dm[r["name"]][:150]))
 
 
