@@ -369,7 +369,6 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         int pst = 1;
         if (io.have_pos) pst = io.pst;
         else if (P->prev_status) pst = P->prev_status[pidx];
-        if (!lk_pt_ok(ppx, ppy)) pst = 0;          // (a wild position is a lost corner: see lk_pt_ok)
         if (!agt_uniform(pst)) {
             if (tid == 0) lk_publish(io, pidx, b, ppx, ppy, 0, 0.f);
             ox = ppx; oy = ppy; ost = 0;
@@ -377,11 +376,15 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         }
     }
     float outx = 0.f, outy = 0.f;              // nextPts[ptidx]
-    if (P->flags & AGT_LK_USE_INITIAL_FLOW) {
-        outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1];
-        if (!agt_uniform((int)lk_pt_ok(outx, outy))) {        // a wild initial flow: the search window is outside the next image at every level
-            if (tid == 0) lk_publish(io, pidx, b, outx, outy, 0, 0.f);
-            ox = outx; oy = outy; ost = 0;
+    if (P->flags & AGT_LK_USE_INITIAL_FLOW) { outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1]; }
+    {
+        // a wild position, or a wild initial flow: the window is outside the image at every level -- status 0, err 0, and nextPts is
+        // what OpenCV leaves there, the start of the search scaled down and up again: the flow if one was given, else the position
+        const bool flow = (P->flags & AGT_LK_USE_INITIAL_FLOW) != 0;
+        if (!agt_uniform((int)(lk_pt_ok(ppx, ppy) && (!flow || lk_pt_ok(outx, outy))))) {
+            const float cx = flow ? outx : ppx, cy = flow ? outy : ppy;
+            if (tid == 0) lk_publish(io, pidx, b, cx, cy, 0, 0.f);
+            ox = cx; oy = cy; ost = 0;
             return;
         }
     }
