@@ -179,8 +179,10 @@ int camera_on(agt_ctx* c, const double* K, const double* dist, int ndist, AgtCam
     }
     if (!c->tilt_valid[slot] || memcmp(c->tilt_host[slot], t.m, sizeof(t.m))) {
         memcpy(c->tilt_host[slot], t.m, sizeof(t.m));
+        // (the copy is waited for, tracker slot or not: the slot may be re-used WITHOUT a copy by a later call on another stream -- agt_set_stream --
+        // and by the tracker's internal streams, none of which is ordered behind this stream.  A new tilted camera is not a per-frame event.  ADVICE r5)
         hipError_t e = hipMemcpyAsync(c->d_tilt + 18 * slot, c->tilt_host[slot], sizeof(t.m), hipMemcpyHostToDevice, c->stream);
-        if (e == hipSuccess && tracker) e = hipStreamSynchronize(c->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
         if (e != hipSuccess) return hip_fail(c, e);
         c->tilt_valid[slot] = 1;
     }
@@ -200,8 +202,10 @@ int ensure_ring(agt_ctx* c, int want)
         ok = ok && hipMalloc((void**)&c->corners[s], B * N * 2 * sizeof(float)) == hipSuccess;
         ok = ok && hipMalloc((void**)&c->status[s], B * N) == hipSuccess;
         ok = ok && hipMemsetAsync(c->status[s], 1, B * N, c->stream) == hipSuccess;
+#ifdef AGT_DEBUG_KNOBS      // (the hybrid LK launch that reads / writes it exists only in the knobs build: ADVICE r5)
         ok = ok && hipMalloc((void**)&c->lk_iters[s], B * N) == hipSuccess;
         ok = ok && hipMemsetAsync(c->lk_iters[s], 0, B * N, c->stream) == hipSuccess;
+#endif
         if (!ok) { hip_fail(c, hipGetLastError()); return AGT_ERR_ALLOC; }      // partial entry is freed by agt_destroy
         c->ring = s + 1;
     }
@@ -232,9 +236,17 @@ int dense_scratch(agt_ctx* c, size_t need, int B)
 
 }  // namespace
 
-// ---- the device's geometry (agt_kernels.h AgtChip), queried once per device
-static AgtChip g_chip[16];
-static int g_chip_state[16];                   // 0 = not queried, 1 = valid, -1 = query failed
+// ---- the device's geometry (agt_kernels.h AgtChip), queried once per device.  Contexts may be created from several threads (one context per
+// thread is the library's threading model): the table is filled under a mutex, read through an acquire load of the entry's state, and
+// sized by the runtime's device count (16 fixed entries turned a valid device 16+ into hipErrorInvalidDevice).
+#include <atomic>
+#include <mutex>
+namespace {
+constexpr int CHIP_MAX = 256;
+AgtChip g_chip[CHIP_MAX];
+std::atomic<int> g_chip_state[CHIP_MAX];       // 0 = not queried, 1 = valid, -1 = query failed
+std::mutex g_chip_mutex;
+}
 static const AgtChip g_chip_default = { 256, 8, 3, "gfx950" };       // a whole MI355X
 
 void agt_chip_from_props(int cus, const char* gcn_arch, AgtChip* out)
@@ -253,23 +265,32 @@ void agt_chip_from_props(int cus, const char* gcn_arch, AgtChip* out)
 
 const AgtChip* agt_chip_of(int device)
 {
-    if (device < 0 || device >= 16) return nullptr;
-    if (g_chip_state[device] == 0) {
-        hipDeviceProp_t p;
-        if (hipGetDeviceProperties(&p, device) == hipSuccess) { agt_chip_from_props(p.multiProcessorCount, p.gcnArchName, &g_chip[device]); g_chip_state[device] = 1; }
-        else { (void)hipGetLastError(); g_chip_state[device] = -1; }
+    if (device < 0 || device >= CHIP_MAX) return nullptr;
+    int st = g_chip_state[device].load(std::memory_order_acquire);
+    if (st == 0) {
+        std::lock_guard<std::mutex> lock(g_chip_mutex);
+        st = g_chip_state[device].load(std::memory_order_relaxed);
+        if (st == 0) {
+            int ndev = 0;
+            hipDeviceProp_t p;
+            if (hipGetDeviceCount(&ndev) == hipSuccess && device < ndev && hipGetDeviceProperties(&p, device) == hipSuccess) {
+                agt_chip_from_props(p.multiProcessorCount, p.gcnArchName, &g_chip[device]); st = 1;
+            } else { (void)hipGetLastError(); st = -1; }
+            g_chip_state[device].store(st, std::memory_order_release);
+        }
     }
-    return g_chip_state[device] == 1 ? &g_chip[device] : nullptr;
+    return st == 1 ? &g_chip[device] : nullptr;
 }
 
 // (every launcher asks this once or twice per launch: while the process has only ever created contexts on ONE device -- the usual
-// case -- the answer is that device's entry, without a runtime call)
-static const AgtChip* g_chip_only = nullptr;
-static int g_chip_devices = 0;
+// case -- the answer is that device's entry, without a runtime call.  g_chip_only: null = no context yet, a table entry = the one device so
+// far, &g_chip_default used as the "several devices" mark; set with a compare-exchange in agt_create, read with one acquire load)
+static std::atomic<const AgtChip*> g_chip_only{nullptr};
 
 const AgtChip& agt_chip_current(void)
 {
-    if (g_chip_devices == 1 && g_chip_only) return *g_chip_only;
+    const AgtChip* only = g_chip_only.load(std::memory_order_acquire);
+    if (only && only != &g_chip_default) return *only;
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) { (void)hipGetLastError(); return g_chip_default; }
     const AgtChip* c = agt_chip_of(dev);
@@ -332,7 +353,10 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     memset(c, 0, sizeof(*c));
     c->cfg = *cfg;
     c->chip = *chip;
-    if (g_chip_only != chip) { g_chip_only = chip; g_chip_devices = g_chip_devices == 0 ? 1 : 2; }
+    {   // first device of the process: remember it; a second one: from now on the launchers ask the runtime which device is current
+        const AgtChip* seen = nullptr;
+        if (!g_chip_only.compare_exchange_strong(seen, chip, std::memory_order_acq_rel) && seen != chip) g_chip_only.store(&g_chip_default, std::memory_order_release);
+    }
     c->stream = (hipStream_t)hip_stream;
     // buildOpticalFlowPyramid level geometry + early stop
     int w = cfg->width, h = cfg->height;
@@ -757,7 +781,9 @@ int agt_tracker_reset(agt_ctx* c, int slot, const float* d_corners, const float*
     if (e == hipSuccess) e = hipMemcpyAsync(c->obj, d_obj, (size_t)n * 3 * sizeof(float), hipMemcpyDeviceToDevice, c->stream);
     if (e == hipSuccess) e = hipMemsetAsync(c->tstate, 0, (size_t)B * sizeof(AgtTrackState), c->stream);
     for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->status[s], 1, (size_t)B * n, c->stream);
+#ifdef AGT_DEBUG_KNOBS
     for (int s = 0; s < c->ring && e == hipSuccess; s++) e = hipMemsetAsync(c->lk_iters[s], 0, (size_t)B * n, c->stream);
+#endif
     // arrival counters of the chained launches: a run counts n corners per stream-frame, the next run may have other n / B
     if (e == hipSuccess) e = hipMemsetAsync(c->lk_done, 0, (size_t)AGT_RING_MAX * c->cfg.max_streams * sizeof(unsigned), c->stream);
     memset(c->lk_target, 0, sizeof(c->lk_target));

@@ -607,7 +607,8 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
 #endif
         constexpr int OCCL = (WIN == 21 && NW == 1) ? AGT_LKG_OCC : 1;
         const long corners = (long)P.lk.n * P.lk_B;
-        const size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
+        size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
+        if (NW == 1 && P.lk.lds_pad > 0) per += (size_t)P.lk.lds_pad;      // agt_lk_occupancy also caps the one-wave group launch (knobs build only: ADVICE r5)
         const unsigned grid8 = agt_xcd_grid(corners, P.xshift);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
         if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);

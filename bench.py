@@ -829,21 +829,31 @@ def per_call_latency(bench):
     # the C-ABI calls alone (arguments prepared once: what a compiled host pays; the cv_hip figures add ~10 us of numpy / ctypes marshalling)
     import ctypes as C
     from accurate_aprilgroup_tracking_amd import hiplib as HL
-    ctx = cv_hip._geom_context(48)
-    Kh = np.ascontiguousarray(sq.K.reshape(-1)); imgf = np.ascontiguousarray(nx, np.float32)
-    pose = np.zeros(6); inf = np.zeros(4, np.int32); ptsf = np.empty((48, 2), np.float32)
+    npts = int(obj.shape[0])                 # (the sequence's corner count: ADVICE r5 -- not a literal 48)
+    ctx = cv_hip._geom_context(npts)
+    Kh = np.ascontiguousarray(sq.K.reshape(-1)); imgf = np.ascontiguousarray(nx, np.float32).reshape(npts, 2)
+    pose = np.zeros(6); inf = np.zeros(4, np.int32); ptsf = np.empty((npts, 2), np.float32)
     vp = lambda a_: a_.ctypes.data_as(C.c_void_p)
-    a_solve = (ctx.h, vp(obj), vp(imgf), HL.F32, 48, vp(Kh), None, 0, vp(pose), 1, vp(inf), None)
-    a_init = (ctx.h, vp(obj), vp(imgf), HL.F32, 48, vp(Kh), None, 0, vp(pose), 0, vp(inf), None)
-    a_proj = (ctx.h, vp(obj), HL.F32, 48, vp(pose), vp(Kh), None, 0, vp(ptsf), None)
+    a_solve = (ctx.h, vp(obj), vp(imgf), HL.F32, npts, vp(Kh), None, 0, vp(pose), 1, vp(inf), None)
+    a_init = (ctx.h, vp(obj), vp(imgf), HL.F32, npts, vp(Kh), None, 0, vp(pose), 0, vp(inf), None)
+    a_proj = (ctx.h, vp(obj), HL.F32, npts, vp(pose), vp(Kh), None, 0, vp(ptsf), None)
 
     def c_solve(args):
         pose[:3] = r0; pose[3:] = t0_
-        ctx.L.agt_solve_pnp_host(*args)
+        return ctx.L.agt_solve_pnp_host(*args)
+
+    def checked(name, fn, solve):
+        """one call whose return code and (solves) info[OK] are looked at before anything is timed: a call that fails at once would read as a
+        very fast one"""
+        rc = fn()
+        if rc != 0 or (solve and inf[HL.INFO_OK] != 1):
+            return {"error": "%s: rc %d, info %s" % (name, rc, inf.tolist())}
+        return med(fn)
     with ctx.lock:
         ctx.use_current_stream()
-        c_abi = {"agt_solve_pnp_host_guess_N48": med(lambda: c_solve(a_solve)), "agt_solve_pnp_host_noguess_N48": med(lambda: c_solve(a_init)),
-                 "agt_project_points_host_N48": med(lambda: ctx.L.agt_project_points_host(*a_proj))}
+        c_abi = {"agt_solve_pnp_host_guess_N%d" % npts: checked("agt_solve_pnp_host (guess)", lambda: c_solve(a_solve), True),
+                 "agt_solve_pnp_host_noguess_N%d" % npts: checked("agt_solve_pnp_host (no guess)", lambda: c_solve(a_init), True),
+                 "agt_project_points_host_N%d" % npts: checked("agt_project_points_host", lambda: ctx.L.agt_project_points_host(*a_proj), False)}
     out = {
         "c_abi_call_only": c_abi,
         "solvePnP_guess_N48": {"hip": med(lambda: cv_hip.solvePnP(obj, nx, sq.K, None, r0.copy(), t0_.copy(), True)),
