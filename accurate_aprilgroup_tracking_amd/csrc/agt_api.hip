@@ -44,6 +44,7 @@ struct agt_ctx {
     double* so_ring[AGT_RING_MAX];           // caller's state_out of the frames in flight
     int pipeline;                            // 1 = software-pipelined fused step (agt_step.hip)
     int group;                               // frames per fused launch (1..AGT_MAX_GROUP)
+    int ramp;                                // split pipeline: frames per group while the pipeline fills (agt_step.hip launch_group: ramp_group)
     int live_ring;                           // ring modulus in use (<= ring): (L + 2) * group, at least AGT_SLOTS
     // big batches: the three stages of a step run on three library-owned streams (stage kernels of different frames
     // overlap: 57 us against 93 us back to back at 64 streams); events carry the exact dependencies
@@ -913,10 +914,15 @@ static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slo
 }
 
 // One fused launch: every pipeline stage advances by up to `group` frames whose input is complete.
-static int launch_group(agt_ctx* c, int B)
+// fmax: the most frames a stage advances by in this call (0 = c->group).  The split pipeline (big batches: three launches per group)
+// runs groups of c->group frames in the steady state but SMALLER ones while it fills and drains (round 6, tools/trace_blocks.py: of a
+// 256-frame block of 64 streams 8 % was the first pyramid launch with nothing beside it and the last pose launch with nothing beside it --
+// a stage's launch covers a whole group, and the next stage waits for all of it): split_ramp() frames at first, doubling per launch.
+static int split_ramp(const agt_ctx* c) { const int r = c->group / 4; return r < 2 ? (c->group < 2 ? c->group : 2) : r; }
+static int launch_group(agt_ctx* c, int B, int fmax = 0)
 {
     const int L = c->eff_max_level;              // pyramid stages 0..L-1 (stage s: level s -> s+1)
-    const int F = c->group, M = c->live_ring;
+    const int F = (fmax > 0 && fmax < c->group) ? fmax : c->group, M = c->live_ring;
     AgtStepParams S;
     AgtStepTables T;
     memset(&S, 0, sizeof(S));
@@ -1231,8 +1237,16 @@ static int step_pipelined(agt_ctx* c, const uint8_t* d_frames, size_t pitch, siz
     c->so_ring[slot] = d_state_out;
     c->trk_frame = t;
     const long first_done = c->eff_max_level > 0 ? c->n_stage[0] : c->n_lk;
-    if (t - first_done < c->group) return AGT_OK;
-    return launch_group(c, B);
+    if (agt_step_fits(c->trk_n, B)) {
+        if (t - first_done < c->group) return AGT_OK;
+        return launch_group(c, B);
+    }
+    // split pipeline: groups grow from split_ramp() to c->group frames while the pipeline fills (see launch_group)
+    if (c->ramp <= 0 || c->ramp > c->group) c->ramp = split_ramp(c);
+    if (t - first_done < c->ramp) return AGT_OK;
+    rc = launch_group(c, B, c->ramp);
+    c->ramp = c->ramp * 2 > c->group ? c->group : c->ramp * 2;
+    return rc;
 }
 
 // Frame T+1 of ONE stream arrives in pinned HOST memory (h_dev: its device address): upload and pyramid in one launch -- the
@@ -1265,10 +1279,14 @@ static int step_pipelined_uploaded(agt_ctx* c, const uint8_t* h_dev, uint8_t* d_
 static int join_pipeline(agt_ctx* c)
 {
     if (c->trk_ready != 2) return AGT_OK;
+    // (split pipeline: the drain runs in groups of split_ramp() frames -- the last pose launch then trails the last LK launch by a
+    // quarter of a group instead of a whole one; afterwards the pipeline is empty and fills again in small groups)
+    const int fmax = agt_step_fits(c->trk_n, c->trk_B) ? 0 : split_ramp(c);
     while (c->n_pnp < c->trk_frame) {
-        int rc = launch_group(c, c->trk_B);
+        int rc = launch_group(c, c->trk_B, fmax);
         if (rc) return rc;
     }
+    c->ramp = 0;
     return c->ms_active ? ms_join(c) : AGT_OK;
 }
 

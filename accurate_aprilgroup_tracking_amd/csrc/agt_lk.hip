@@ -21,16 +21,42 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     io.grouped = false; io.prev_pts = P.prev_pts; io.next_pts = P.next_pts; io.status = P.status; io.err = P.err;
     io.have_pos = false; io.px = io.py = 0.f; io.pst = 1;
     float ox, oy; int ost;
+#ifdef AGT_LK_STAMPS
+    struct CornerLog {
+        int c; unsigned long long t0;
+        __device__ CornerLog(int c_) : c(c_), t0(__builtin_amdgcn_s_memtime()) {}
+        __device__ ~CornerLog() { if ((threadIdx.x & 63) == 0 && threadIdx.x == 0 && c < AGT_LK_CORNER_LOG) { agt_lk_corner_log[c][0] = t0; agt_lk_corner_log[c][1] = __builtin_amdgcn_s_memtime(); } }
+    } corner_log(cidx);
+#endif
     if constexpr (WIN == 21 && (NW == 1 || NW == 4)) {
         // one wave per corner: the row-segment body (agt_lk_rs_body.h) while the window's derivative footprint stays inside
         // the image at every level and the corner is alive; the general body otherwise (wave-uniform choice)
         const long pidx = cidx;
         const float ppx = P.prev_pts[pidx * 2], ppy = P.prev_pts[pidx * 2 + 1];
         const int pst = P.prev_status ? P.prev_status[pidx] : 1;
-        if (agt_uniform((int)(pst != 0 && !(P.flags & 0x10000) && agt_lk::rs_interior(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)))) {
-            agt_lk::lk_body_rs<NW, NLEV>(&P, bX, bY, lds, io, ppx, ppy, ox, oy, ost);
-            return;
+        // (round 6, tools/lkcorners.py: on 64 streams a wave lives 16 .. 31 us on the row-segment body and 35 us on the general one, which the
+        // ~3 % of corners whose window touches the image border at SOME level took for ALL levels -- and the launch lasts as long as its
+        // slowest wave.  The border is mostly reached at the coarsest level only: the general body now tracks just the coarse levels that
+        // need it and hands the position to the row-segment body for the fine ones -- two bodies in sequence, each register-allocated alone.)
+        const int fine = (pst != 0 && !(P.flags & 0x10000)) ? agt_uniform(agt_lk::rs_interior_levels<NLEV>(ppx, ppy, P.max_level, P.prev[0].w, P.prev[0].h)) : 0;
+        // One split point is compiled: the coarsest level alone (by far the common case -- its window covers four times the ground of the
+        // finest one's) of a full-depth pyramid; every other corner that needs the general body somewhere gets it everywhere, as before.
+        // One call site per body: the general one runs all levels, result included, or the coarsest alone; the row-segment one the rest.
+        int top = -1;
+        float cx = 0.f, cy = 0.f;
+        if (fine <= P.max_level) {
+            // (the launch lasts as long as its slowest wave, and that is one of these: the general body's waves issue ahead of the row-segment
+            // waves they share a SIMD with -- those have slack, tools/lkcorners.py)
+            if (NW == 1 && pst != 0) __builtin_amdgcn_s_setprio(3);
+            if (fine != NLEV - 1 || P.max_level != NLEV - 1) { agt_lk::lk_body<WIN, NW, NLEV>(&P, bX, bY, lds, io, ox, oy, ost); return; }
+            agt_lk::lk_body<WIN, NW, NLEV, const AgtLkParams*, NLEV - 1>(&P, bX, bY, lds, io, ox, oy, ost);
+            if (ost < 0) return;                           // (finished there: a wild initial flow)
+            agt_lk::block_sync<NW>();                      // (the row-segment body reuses the LDS behind the tiles)
+            top = fine - 1; cx = ox; cy = oy;
+            if (NW == 1) __builtin_amdgcn_s_setprio(0);
         }
+        agt_lk::lk_body_rs<NW, NLEV>(&P, bX, bY, lds, io, ppx, ppy, ox, oy, ost, top, cx, cy);
+        return;
     }
     agt_lk::lk_body<WIN, NW, NLEV>(&P, bX, bY, lds, io, ox, oy, ost);
 }

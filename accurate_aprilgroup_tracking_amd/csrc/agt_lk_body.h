@@ -34,6 +34,14 @@ extern "C" int agt_debug_lk_stamps(unsigned long long* host64)
 {
     return (int)hipMemcpyFromSymbol(host64, HIP_SYMBOL(agt_lk_stamps), sizeof(agt_lk_stamps));
 }
+// per-corner log of the stand-alone launch (tools/lkcorners.py): entry and exit time of every corner's wave(s) and the
+// iterations it took -- the launch lasts as long as its slowest corner
+#define AGT_LK_CORNER_LOG 8192
+__device__ unsigned long long agt_lk_corner_log[AGT_LK_CORNER_LOG][3];
+extern "C" int agt_debug_lk_corner_log(unsigned long long* host, int n)
+{
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(agt_lk_corner_log), sizeof(unsigned long long) * 3 * (size_t)(n < AGT_LK_CORNER_LOG ? n : AGT_LK_CORNER_LOG));
+}
 #else
 #define STAMP(i)
 #endif
@@ -48,7 +56,14 @@ struct LkCfg {
     static constexpr int INDW = (IW + 6) / 4;           // aligned dwords per I-tile row (incl. <=3 B shift)
     static constexpr int IP = INDW * 4;                 // LDS pitch
     static constexpr int DW = WIN + 1;                  // derivative tile
-    static constexpr int MARGIN = 9;
+    // search margin around the window's expected position.  Four waves per corner (latency: a re-staged tile is a memory round trip on the
+    // corner's critical path): 9 px.  One wave per corner (big batches: the launch moves 3.3 x its algorithmic bytes in whole 128-B lines and
+    // shares HBM with the pyramid pass, tools/trace_blocks.py): 5 px -- a 32-row tile instead of 40, a fifth fewer lines; corners that
+    // move further within a level re-stage, as ever (round 6)
+#ifndef AGT_LK_MARGIN1
+#define AGT_LK_MARGIN1 5
+#endif
+    static constexpr int MARGIN = NW == 1 ? AGT_LK_MARGIN1 : 9;
     static constexpr int JT = WIN + 1 + 2 * MARGIN;     // J search tile
     static constexpr int JNDW = (JT + 6) / 4;
     static constexpr int JP = JNDW * 4;
@@ -255,6 +270,11 @@ __host__ __device__ constexpr size_t lk_lds_bytes(int levels)
 }
 
 
+// 1 / 2^l as a float: the exponent field written directly.  (As the division 1.f / (float)(1 << l) with a run-time l it is the full IEEE
+// sequence -- v_div_scale x 2, v_rcp, four fused multiply-adds, v_div_fmas, v_div_fixup -- on the critical path of every level of every
+// corner, and of every trip of rs_interior: round 6.)  Exact for 0 <= l <= 126.
+__device__ __forceinline__ float lk_level_scale(int l) { return __int_as_float((127 - l) << 23); }
+
 // A coordinate the tracker will not form an address from: non-finite or |x| >= 2^20.  OpenCV floors such a value to an integer far
 // outside every image (cvFloor of a NaN or of anything beyond the int range is INT_MIN on x86) and so finds the window "outside the
 // image" at every level: status 0, err 0, the position carried -- which is what the bodies below do with it up front (a GPU
@@ -330,9 +350,15 @@ __device__ __forceinline__ AgtLevel get_level(const LV& L)
 
 // PP: pointer to the parameters -- `const AgtLkParams*` (stand-alone launch) or a pointer into the kernel-argument
 // segment (fused step, where the level tables are indexed with run-time levels inside a frame loop).
-template <int WIN, int NW, int NLEV, typename PP>
+// STOP > 0 (round 6, agt_lk.hip lk_kernel): only the pyramid levels max_level .. level_stop are tracked here and nothing is
+// published -- the position after level `level_stop` comes back in ox / oy (at that level's scale) for the row-segment body to carry
+// through the finer levels; ost < 0 then says that the corner was finished (published) here after all (lost, wild).
+// (STOP is a template parameter: as a run-time bound of the level loop it cost the one-wave kernel its register allocation -- spills at
+// 128 registers -- and with it known, the prologue requests only the tiles of the levels tracked here.)
+template <int WIN, int NW, int NLEV, typename PP, int STOP = 0>
 __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float& ox, float& oy, int& ost)
 {
+    constexpr int level_stop = STOP;
     using C = LkCfg<WIN, NW>;
     constexpr int T = C::T;
     int* sD = reinterpret_cast<int*>(lds + (P->max_level + 1) * C::LEVEL_LDS);
@@ -371,7 +397,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         else if (P->prev_status) pst = P->prev_status[pidx];
         if (!agt_uniform(pst)) {
             if (tid == 0) lk_publish(io, pidx, b, ppx, ppy, 0, 0.f);
-            ox = ppx; oy = ppy; ost = 0;
+            ox = ppx; oy = ppy; ost = level_stop > 0 ? -1 : 0;
             return;
         }
     }
@@ -384,7 +410,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         if (!agt_uniform((int)(lk_pt_ok(ppx, ppy) && (!flow || lk_pt_ok(outx, outy))))) {
             const float cx = flow ? outx : ppx, cy = flow ? outy : ppy;
             if (tid == 0) lk_publish(io, pidx, b, cx, cy, 0, 0.f);
-            ox = cx; oy = cy; ost = 0;
+            ox = cx; oy = cy; ost = level_stop > 0 ? -1 : 0;
             return;
         }
     }
@@ -392,13 +418,38 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
 
     STAMP(0);
-    // ---- prologue: request every level's tiles before touching any of them
-    {
+    // ---- prologue: request every level's tiles before touching any of them (four waves per corner, the latency form), or -- one wave per
+    // corner, where the 3 + 7 dwords per lane and level are 30 registers of a 128-register kernel -- level by level (round 6: the corners
+    // that still come here with one wave are the few whose windows touch the image border; the others run the row-segment body)
+    if constexpr (NW == 1) {
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            if (l >= STOP && l <= P->max_level) {
+                const float scale = lk_level_scale(l);
+                const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
+                const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+                AgtLevel LI = get_level(P->prev[l]);
+                AgtLevel LJ = get_level(P->next[l]);
+                if (io.grouped) { LI.ptr = io.imgI[l]; LJ.ptr = io.imgJ[l]; }
+                uint32_t ti[C::ILD], tj[C::JLD];
+#pragma unroll
+                for (int k = 0; k < C::ILD; k++) ti[k] = 0;
+#pragma unroll
+                for (int k = 0; k < C::JLD; k++) tj[k] = 0;
+                if (!(ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h)) {
+                    tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti);
+                    tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj);
+                }
+                tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, tid, ti);
+                tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, tid, tj);
+            }
+        }
+    } else {
         uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            if (l <= P->max_level) {
-                const float scale = 1.f / (float)(1 << l);
+            if (l >= STOP && l <= P->max_level) {
+                const float scale = lk_level_scale(l);
                 const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
                 const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
                 AgtLevel LI = get_level(P->prev[l]);
@@ -413,7 +464,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         STAMP(1);
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            if (l <= P->max_level) {
+            if (l >= STOP && l <= P->max_level) {
                 tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, tid, ti[l]);
                 tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, tid, tj[l]);
             }
@@ -425,7 +476,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     int st = 1;
     float errv = 0.f;
 
-    for (int level = P->max_level; level >= 0; level--) {
+    for (int level = P->max_level; level >= level_stop; level--) {
         const AgtLevel LI = get_level(P->prev[level]);
         AgtLevel LJ = get_level(P->next[level]);
         if (io.grouped) {
@@ -437,7 +488,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         const uint8_t* imgJ = LJ.ptr + (long)b * LJ.bstride;
         const uint8_t* sI = lds + level * C::LEVEL_LDS;
         uint8_t* sJ = lds + level * C::LEVEL_LDS + C::IW * C::IP;
-        const float scale = 1.f / (float)(1 << level);
+        const float scale = lk_level_scale(level);
         float prevx = ppx * scale, prevy = ppy * scale;
         float nextx, nexty;
         if (level == P->max_level) {
@@ -450,7 +501,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         prevx -= halfw; prevy -= halfw;
         const int ipx = agt_uniform((int)floorf(prevx)), ipy = agt_uniform((int)floorf(prevy));
         if (ipx < -WIN || ipx >= LI.w || ipy < -WIN || ipy >= LI.h) {
-            if (level == 0) { st = 0; errv = 0.f; }
+            if (STOP == 0 && level == 0) { st = 0; errv = 0.f; }
             continue;
         }
         int iw00, iw01, iw10, iw11;
@@ -459,9 +510,14 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         // ---- Scharr on the fly from the prefetched I tile -> LDS derivative tile
         const int offI = (ipx - 1) - ((ipx - 1) & ~3);
         block_sync<NW>();                      // previous level's readers of sD are done
+        // (one wave per corner: the thread index through an empty asm, per level -- the row / column split of the NSD derivative positions
+        // of a lane is then recomputed in every level instead of being kept alive across the level loop, where it was the value the
+        // register allocator spilled at 128 registers: round 6.  Four waves per corner: as ever.)
+        int tid_l = tid;
+        if constexpr (NW == 1) asm volatile("" : "+v"(tid_l));
 #pragma unroll
         for (int k = 0; k < C::NSD; k++) {
-            const int idx = tid + k * T;
+            const int idx = tid_l + k * T;
             if (idx < C::DW * C::DW) {
                 const int dyy = idx / C::DW, dxx = idx - dyy * C::DW;
                 const int gx = ipx + dxx, gy = ipy + dyy;
@@ -505,7 +561,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         const float minEig = (A22 + A11 - sqrtf((A11 - A22) * (A11 - A22) + 4.f * A12 * A12)) / (float)(2 * WIN * WIN);
         if (P->flags & AGT_LK_GET_MIN_EIGENVALS) errv = minEig;
         if (agt_uniform((int)((double)minEig < P->min_eig_threshold || D < FLT_EPSILON))) {
-            if (level == 0) st = 0;
+            if (STOP == 0 && level == 0) st = 0;
             continue;
         }
         D = 1.f / D;
@@ -540,7 +596,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
             if (j == 1) STAMP(39);
             const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
-                if (level == 0) st = 0;
+                if (STOP == 0 && level == 0) st = 0;
                 break;
             }
             if (j == 1) STAMP(40);
@@ -574,7 +630,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
         }
 
         STAMP(8 + level * 8 + 4);
-        if (st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
+        if (STOP == 0 && st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
             const float npx = outx - halfw, npy = outy - halfw;
             const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) { st = 0; continue; }
@@ -590,6 +646,7 @@ __device__ __forceinline__ void lk_body(PP P, int pt, int b, uint8_t* lds, const
     }
 
     STAMP(3);
+    if (level_stop > 0) { ox = outx; oy = outy; ost = st; return; }       // (the finer levels and the result are the caller's)
     if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
     if (tid == 0 && io.iters_out) io.iters_out[pidx] = (uint8_t)(nit > 255 ? 255 : nit);
     ox = outx; oy = outy; ost = st;

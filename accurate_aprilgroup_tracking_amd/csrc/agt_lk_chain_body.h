@@ -291,7 +291,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
         lvA = needI = needJ = 0;
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            const float scale = 1.f / (float)(1 << l);
+            const float scale = lk_level_scale(l);
             const float prevx = px * scale - halfw, prevy = py * scale - halfw;
             ipx[l] = agt_uniform((int)floorf(prevx)); ipy[l] = agt_uniform((int)floorf(prevy));
             fa[l] = prevx - (float)ipx[l]; fb[l] = prevy - (float)ipy[l];
@@ -446,7 +446,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
 #pragma unroll
         for (int level = NLEV - 1; level >= 0; level--) {
             if (level > maxl) continue;
-            const float scale = 1.f / (float)(1 << level);
+            const float scale = lk_level_scale(level);
             float nextx, nexty;
             if (level == maxl) { nextx = px * scale; nexty = py * scale; }
             else { nextx = outx * 2.f; nexty = outy * 2.f; }
@@ -465,7 +465,7 @@ __device__ __forceinline__ void lk_frames_w4(PP P, int pt, int b, uint8_t* lds, 
                     for (int l = 0; l < NLEV; l++) {
                         typedef const __attribute__((address_space(1))) uint8_t* G8;
                         typedef const __attribute__((address_space(1))) uint32_t* G32;
-                        const float sc = 1.f / (float)(1 << l);
+                        const float sc = lk_level_scale(l);
                         const int cx = agt_uniform((int)floorf(outx * sc - halfw)), cy = agt_uniform((int)floorf(outy * sc - halfw));
                         const int w = gw[l], h = gh[l];
                         const long pitch = gpitch[l], bstride = gbs[l];

@@ -10,7 +10,8 @@
 //     iteration instead of 28 byte reads), aligned with v_alignbyte_b32;
 //   * the fixed-point bilinear tap  v00*iw00 + v01*iw01 + v10*iw10 + v11*iw11  is two v_dot4_u32_u8: the four bytes
 //     are packed into one register with v_perm_b32 and the 15-bit weights are split into high and low bytes
-//     (sum = 256 * dot4(P, WH) + dot4(P, WL), exact); the rounding constant rides in the accumulator input;
+//     (sum = 256 * dot4(P, WH) + dot4(P, WL), exact); the rounding constant rides in the accumulator input
+//     [round 6: two v_dot2_i32_i16 with int16 weights instead -- rs_weights_i16 / rs_tap2 below];
 //   * the I side of a level lives in registers only.  By linearity  sum_ij w_ij * Scharr(I)(x+j, y+i)  =
 //     Scharr(B)(x, y)  with  B = sum_ij w_ij * I(.+j, .+i)  taken WITHOUT rounding (B < 2^22, Scharr(B) < 2^27):
 //     each lane interpolates its 3 x 9 patch of B (27 dot4 pairs) and applies the Scharr taps to it -- no derivative
@@ -25,56 +26,74 @@
 
 namespace agt_lk {
 
-// byte selectors of v_perm_b32(S0 = next row, S1 = this row): { this[k], this[k+1], next[k], next[k+1] }
-constexpr uint32_t RS_SEL0 = 0x05040100u, RS_SEL1 = 0x06050201u, RS_SEL2 = 0x07060302u;
+// Round 6 (the iteration's instruction diet): the fixed-point bilinear tap
+//     v00 * iw00 + v01 * iw01 + v10 * iw10 + v11 * iw11 + c
+// is TWO v_dot2_i32_i16 -- one per image row: the row's two neighbouring bytes zero-extended into the halves of a register (one
+// v_perm_b32), the two weights of the row as int16 halves of a scalar register, the first dot product's result as the second
+// one's accumulator.  Rounds 2-5 ran two v_dot4_u32_u8 per tap (the 15-bit weights split into byte planes) plus a shift-add to
+// join the planes, packed the weights into byte planes on the scalar unit (~25 instructions per iteration) and needed a
+// correction path for iw11 = -1 (a byte plane cannot hold it): the signed 16-bit form has none of the three.
+// byte selectors of v_perm_b32(S0 = bytes 4..7, S1 = bytes 0..3): { b[j], 0, b[j+1], 0 } for j = 0..3 (0x0c selects the constant 0)
+constexpr uint32_t RS_PAIR0 = 0x0c010c00u, RS_PAIR1 = 0x0c020c01u, RS_PAIR2 = 0x0c030c02u, RS_PAIR3 = 0x0c040c03u;
 
-// 14-bit bilinear weights -> the two byte-packed operands of the dot4 pair.  iw11 = 2^14 - (the three rounded products)
-// can come out as -1 when a * b * 2^14 < 1.5: the packed operands then carry 0 for it and `neg11` (wave-uniform, > 0)
-// tells the caller to subtract neg11 * v11 from every tap (rs_fix_taps; a rare scalar branch).
-__device__ __forceinline__ void rs_pack_weights(int iw00, int iw01, int iw10, int iw11, uint32_t& WL, uint32_t& WH, int& neg11)
+typedef short rs_i16x2 __attribute__((ext_vector_type(2)));
+
+// bilinear_weights (agt_lk_body.h) for the dot2 form: a, b = the position's fractions; W01 = { iw00, iw01 }, W23 = { iw10, iw11 } as
+// int16 halves.  Same integers as OpenCV's cvRound((1 - a) * (1 - b) * 2^14) etc., in fewer instructions:
+//   * the factor 2^14 is applied to (1 - b) and b first: a product scaled by a power of two rounds to the scaled rounded product
+//     (no overflow, no denormals: the fractions are multiples of 2^-13 at image coordinates below 2^10 .. 2^11);
+//   * cvRound (nearest, ties to even) of 0 <= t <= 2^14 is the float addition t + 1.5 * 2^23: the sum's low mantissa bits ARE the
+//     rounded integer -- the conversion, and everything after it, happens on the scalar unit (the weights are wave-uniform).
+// a wave-uniform value moved to a scalar register, opaquely on both sides: what is computed FROM it stays on the scalar unit, and the
+// read-first-lane is not hoisted through the float addition that produced it (the compiler otherwise adds on the vector unit after the move)
+__device__ __forceinline__ int rs_scalar(int v)
 {
-    // the weights are wave-uniform: packing them is scalar work (and the dot4s take them as SGPR operands)
-    iw00 = agt_uniform(iw00); iw01 = agt_uniform(iw01); iw10 = agt_uniform(iw10); iw11 = agt_uniform(iw11);
-    neg11 = iw11 < 0 ? -iw11 : 0;
-    iw11 = iw11 < 0 ? 0 : iw11;
-    WL = (uint32_t)(iw00 & 255) | ((uint32_t)(iw01 & 255) << 8) | ((uint32_t)(iw10 & 255) << 16) | ((uint32_t)(iw11 & 255) << 24);
-    WH = (uint32_t)(iw00 >> 8) | ((uint32_t)(iw01 >> 8) << 8) | ((uint32_t)(iw10 >> 8) << 16) | ((uint32_t)(iw11 >> 8) << 24);
+    asm("" : "+v"(v));
+    v = __builtin_amdgcn_readfirstlane(v);
+    asm("" : "+s"(v));
+    return v;
+}
+__device__ __forceinline__ float rs_scalar(float v) { return __int_as_float(rs_scalar(__float_as_int(v))); }
+// a scalar value pinned to a scalar register (the read-first-lane is free when the compiler already holds it in one)
+__device__ __forceinline__ int rs_pin(int v) { v = __builtin_amdgcn_readfirstlane(v); asm("" : "+s"(v)); return v; }
+
+__device__ __forceinline__ void rs_weights_i16(float a, float b, uint32_t& W01, uint32_t& W23)
+{
+    const float MAGIC = 12582912.f;                      // 1.5 * 2^23 = 0x4B400000
+    const float na = 1.f - a, nb = 1.f - b;
+    const float s1 = nb * (float)(1 << W_BITS), s2 = b * (float)(1 << W_BITS);
+    const float y00 = na * s1 + MAGIC, y01 = a * s1 + MAGIC, y10 = na * s2 + MAGIC;
+    const int iw00 = rs_scalar(__float_as_int(y00)) - 0x4B400000, iw01 = rs_scalar(__float_as_int(y01)) - 0x4B400000;
+    const int iw10 = rs_scalar(__float_as_int(y10)) - 0x4B400000;
+    const int iw11 = (1 << W_BITS) - iw00 - iw01 - iw10;              // (may be -1: a signed half holds it)
+    W01 = ((uint32_t)iw00 & 0xffffu) | ((uint32_t)iw01 << 16);
+    W23 = ((uint32_t)iw10 & 0xffffu) | ((uint32_t)iw11 << 16);
 }
 
-// sum of the four taps packed in P, plus `round`
-__device__ __forceinline__ int rs_tap(uint32_t P, uint32_t WL, uint32_t WH, uint32_t round)
+// one tap: A = { upper row's bytes k, k + 1 }, B = { lower row's }, both zero-extended to 16-bit halves; acc: rounding constant etc.
+// (the first dot product is written out: the compiler selects the two-address v_dot2c_i32_i16 for the builtin and copies the
+// accumulator -- a loop-carried constant -- in front of it, one move per tap; the three-address form reads it in place.  The second one's
+// accumulator is the first one's result: dead afterwards, the two-address form costs nothing there.)
+template <bool ACC = true>
+__device__ __forceinline__ int rs_tap2(uint32_t A, uint32_t B, uint32_t W01, uint32_t W23, int acc = 0)
 {
-    const uint32_t lo = __builtin_amdgcn_udot4(P, WL, round, false);
-    const uint32_t hi = __builtin_amdgcn_udot4(P, WH, 0u, false);
-    return (int)((hi << 8) + lo);
+    int t;
+    if (ACC) asm("v_dot2_i32_i16 %0, %1, %2, %3" : "=v"(t) : "v"(A), "s"(W01), "v"(acc));
+    else asm("v_dot2_i32_i16 %0, %1, %2, 0" : "=v"(t) : "v"(A), "s"(W01));
+    return __builtin_amdgcn_sdot2(__builtin_bit_cast(rs_i16x2, B), __builtin_bit_cast(rs_i16x2, W23), t, false);
 }
 
-template <int N>
-__device__ __forceinline__ void rs_fix_taps(int (&raw)[N], const uint32_t (&P)[N], int neg11)
+// the byte pairs (k, k + 1), k = 0 .. N - 1, of one row given as aligned dwords r[0], r[1], .. (bytes 0..3, 4..7, ..): pair k sits in
+// dwords k / 4 and k / 4 + 1 at byte k % 4
+template <int N, int ND>
+__device__ __forceinline__ void rs_row_pairs(const uint32_t (&r)[ND], uint32_t (&Q)[N])
 {
+    static_assert(N + 1 <= 4 * ND, "pair N - 1 reads byte N");
 #pragma unroll
-    for (int k = 0; k < N; k++) raw[k] -= neg11 * (int)(P[k] >> 24);
-}
-
-// N consecutive taps of two rows given as aligned bytes: a0|a1|a2 = bytes 0..11 of the upper row, b0|b1|b2 of the lower
-// one; tap k uses bytes k, k + 1 of both.  N <= 9.
-template <int N>
-__device__ __forceinline__ void rs_pack_taps(uint32_t a0, uint32_t a1, uint32_t a2, uint32_t b0, uint32_t b1, uint32_t b2, uint32_t (&P)[N])
-{
-    P[0] = __builtin_amdgcn_perm(b0, a0, RS_SEL0);
-    if (N > 1) P[1] = __builtin_amdgcn_perm(b0, a0, RS_SEL1);
-    if (N > 2) P[2] = __builtin_amdgcn_perm(b0, a0, RS_SEL2);
-    if (N > 3) {
-        const uint32_t m = __builtin_amdgcn_alignbyte(a1, a0, 3), mu = __builtin_amdgcn_alignbyte(b1, b0, 3);   // bytes 3..6
-        P[3] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
-        if (N > 4) P[4] = __builtin_amdgcn_perm(mu, m, RS_SEL1);
-        if (N > 5) P[5] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
-    }
-    if (N > 6) P[6] = __builtin_amdgcn_perm(b1, a1, RS_SEL2);                                                  // bytes 6, 7
-    if (N > 7) {
-        const uint32_t m = __builtin_amdgcn_alignbyte(a2, a1, 3), mu = __builtin_amdgcn_alignbyte(b2, b1, 3);   // bytes 7..10
-        P[7] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
-        if (N > 8) P[8] = __builtin_amdgcn_perm(mu, m, RS_SEL1);
+    for (int k = 0; k < N; k++) {
+        const uint32_t lo = r[k / 4], hi = (k % 4 == 3) ? r[k / 4 + 1 < ND ? k / 4 + 1 : ND - 1] : 0u;
+        Q[k] = (k % 4 == 0) ? __builtin_amdgcn_perm(hi, lo, RS_PAIR0) : (k % 4 == 1) ? __builtin_amdgcn_perm(hi, lo, RS_PAIR1)
+             : (k % 4 == 2) ? __builtin_amdgcn_perm(hi, lo, RS_PAIR2) : __builtin_amdgcn_perm(hi, lo, RS_PAIR3);
     }
 }
 
@@ -129,17 +148,49 @@ constexpr int RS_BROWS = 23, RS_BP = 24, RS_B_BYTES = RS_BROWS * RS_BP * 4;
 __host__ __device__ constexpr size_t lk_rs_lds_bytes(int levels) { return (size_t)levels * LkCfg<21, 1>::LEVEL_LDS; }
 
 // true when every derivative position the 21x21 window of `pt` touches lies inside the image at every level
+// (NLEV > 0: the trips are unrolled and predicated -- straight-line scalar code at the head of every corner's critical path)
+template <int NLEV = 0>
 __device__ __forceinline__ bool rs_interior(float ppx, float ppy, int max_level, int w0, int h0)
 {
     bool ok = lk_pt_ok(ppx, ppy);              // (a NaN converts to 0, "inside": agt_lk_body.h lk_pt_ok)
     int w = w0, h = h0;
+    if constexpr (NLEV > 0) {
+#pragma unroll
+        for (int l = 0; l < NLEV; l++) {
+            const float scale = lk_level_scale(l);
+            const int ipx = (int)floorf(ppx * scale - 10.f), ipy = (int)floorf(ppy * scale - 10.f);
+            ok = ok && (l > max_level || (ipx >= 0 && ipx + 21 < w && ipy >= 0 && ipy + 21 < h));
+            w = (w + 1) / 2; h = (h + 1) / 2;
+        }
+        return ok;
+    }
     for (int l = 0; l <= max_level; l++) {
-        const float scale = 1.f / (float)(1 << l);
+        const float scale = lk_level_scale(l);
         const int ipx = (int)floorf(ppx * scale - 10.f), ipy = (int)floorf(ppy * scale - 10.f);
         ok = ok && ipx >= 0 && ipx + 21 < w && ipy >= 0 && ipy + 21 < h;
         w = (w + 1) / 2; h = (h + 1) / 2;
     }
     return ok;
+}
+
+// the number of FINE levels 0 .. k - 1 at which every derivative position of the window lies inside the image (0: none, max_level + 1:
+// all = rs_interior).  A window that leaves the image at some level leaves it at every coarser one (it covers twice the ground there),
+// so the levels split into a coarse run for the general body and a fine run for the row-segment body (agt_lk.hip lk_kernel).
+template <int NLEV>
+__device__ __forceinline__ int rs_interior_levels(float ppx, float ppy, int max_level, int w0, int h0)
+{
+    if (!lk_pt_ok(ppx, ppy)) return 0;
+    int w = w0, h = h0, n = 0;
+    bool run = true;
+#pragma unroll
+    for (int l = 0; l < NLEV; l++) {
+        const float scale = lk_level_scale(l);
+        const int ipx = (int)floorf(ppx * scale - 10.f), ipy = (int)floorf(ppy * scale - 10.f);
+        run = run && l <= max_level && ipx >= 0 && ipx + 21 < w && ipy >= 0 && ipy + 21 < h;
+        n += run ? 1 : 0;
+        w = (w + 1) / 2; h = (h + 1) / 2;
+    }
+    return n;
 }
 
 // lane -> (window row, segment) maps of the two shapes: one wave per corner (throughput: 7 consecutive pixels per lane,
@@ -158,16 +209,24 @@ struct RsCfg {
 
 // Track one corner through one frame with NW waves (all 64 * NW threads call).  Preconditions checked by the caller:
 // rs_interior(...) holds and the corner's previous status is 1.  lds: lk_lds_bytes<21, NW>, 16-B aligned.
+// level_top >= 0 (round 6): the corner's coarse levels max_level .. level_top + 1 were tracked by the general body (their windows touch the
+// image border); this call carries the position it reached -- cx, cy, at the scale of level level_top + 1 -- through levels level_top .. 0.
 template <int NW, int NLEV, typename PP>
 __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, const LkFrameIo<NLEV>& io, float ppx, float ppy,
-                                           float& ox, float& oy, int& ost)
+                                           float& ox, float& oy, int& ost, const int level_top = -1, const float cx = 0.f, const float cy = 0.f)
 {
+    const bool cont = level_top >= 0;
+    const int top = cont ? level_top : P->max_level;
     constexpr int WIN = 21;
     using C = LkCfg<WIN, NW>;
     using R = RsCfg<NW>;
     constexpr int T = AGT_WAVE * NW;
     constexpr int PX = R::PX, NB = R::NB;
-    const int tid = NW == 1 ? (int)(threadIdx.x & (AGT_WAVE - 1)) : (int)threadIdx.x;
+    // (the thread index through an empty asm: nothing this body derives from it is shared with the general body that may have run the
+    // coarse levels before it -- shared, those per-lane values stay alive across the whole general body and spill at 128 registers)
+    int tid_raw = (int)threadIdx.x;
+    asm volatile("" : "+v"(tid_raw));
+    const int tid = NW == 1 ? (tid_raw & (AGT_WAVE - 1)) : tid_raw;
     const int lane = tid & (AGT_WAVE - 1), wave = tid / AGT_WAVE;
     const bool act = tid < R::NLANE;
     const int rr = act ? tid / R::SEG : 20, ss = act ? tid - rr * R::SEG : R::SEG - 1;     // window row, segment
@@ -182,8 +241,8 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     int phase = 0;
     int nit = 0;                    // iterations over all levels (only kept where io.iters_out is set)
 
-    float outx = 0.f, outy = 0.f;
-    if (P->flags & AGT_LK_USE_INITIAL_FLOW) {
+    float outx = cx, outy = cy;
+    if (!cont && (P->flags & AGT_LK_USE_INITIAL_FLOW)) {
         outx = io.next_pts[pidx * 2]; outy = io.next_pts[pidx * 2 + 1];
         if (!agt_uniform((int)lk_pt_ok(outx, outy))) {        // a wild initial flow: lost, position carried (agt_lk_body.h lk_pt_ok)
             if (tid == 0) lk_publish(io, pidx, b, outx, outy, 0, 0.f);
@@ -191,8 +250,10 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             return;
         }
     }
-    const float gsx = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx;
-    const float gsy = (P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy;
+    // where the search is expected to start, in level-0 coordinates (the search tiles are requested around it)
+    const float up = __int_as_float((127 + top + 1) << 23);          // 2^(level_top + 1)
+    const float gsx = cont ? cx * up : ((P->flags & AGT_LK_USE_INITIAL_FLOW) ? outx : ppx);
+    const float gsy = cont ? cy * up : ((P->flags & AGT_LK_USE_INITIAL_FLOW) ? outy : ppy);
 
     // exact sums over the corner's lanes of two / three partials, rounded once to float
     auto sum2 = [&](int v0, int v1, float& s0, float& s1) {
@@ -217,13 +278,12 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         constexpr int IK = (C::IW + IR - 1) / IR, JK = (C::JT + JR - 1) / JR;    // loads per tile (3 / 8 with one wave, 1 / 2 with four)
         const bool ion = irow < IR, jon = jrow < JR;
         uint32_t fi[NLEV][IK], fj[NLEV][JK];
-        uint32_t ti[NLEV][C::ILD], tj[NLEV][C::JLD];
         bool fastI[NLEV], fastJ[NLEV];
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
             fastI[l] = fastJ[l] = false;
-            if (l <= P->max_level) {
-                const float scale = 1.f / (float)(1 << l);
+            if (l <= top) {
+                const float scale = lk_level_scale(l);
                 const int ipx = (int)floorf(ppx * scale - halfw), ipy = (int)floorf(ppy * scale - halfw);
                 const int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
                 AgtLevel LI = get_level(P->prev[l]);
@@ -244,7 +304,12 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                                 fi[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * IR) * pitch + ax0, 0);
                         }
                     } else {
-                        tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti[l]);
+                        // (a tile that touches the image border -- rare: loaded by the general loader and stored at once; kept in registers
+                        // until the common store phase, these dwords -- up to 30 per lane over three levels, beside the 33 of the fast path -- were
+                        // what the register allocator spilled first: round 6)
+                        uint32_t ti[C::ILD];
+                        tile_load<C::IW, C::INDW, T>(LI.ptr + (long)b * LI.bstride, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, tid, ti);
+                        tile_store<C::IW, C::INDW, T>(lds + l * C::LEVEL_LDS, tid, ti);
                     }
                 }
                 {
@@ -261,7 +326,9 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                                 fj[l][k] = __builtin_amdgcn_raw_buffer_load_b32(rs, vo, (ty0 + k * JR) * pitch + ax0, 0);
                         }
                     } else {
-                        tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj[l]);
+                        uint32_t tj[C::JLD];
+                        tile_load<C::JT, C::JNDW, T>(LJ.ptr + (long)b * LJ.bstride, LJ.w, LJ.h, LJ.pitch, jx0, jy0, tid, tj);
+                        tile_store<C::JT, C::JNDW, T>(lds + l * C::LEVEL_LDS + C::IW * C::IP, tid, tj);
                     }
                 }
             }
@@ -269,19 +336,19 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         STAMP(1);
 #pragma unroll
         for (int l = 0; l < NLEV; l++) {
-            if (l <= P->max_level) {
+            if (l <= top) {
                 uint8_t* sIl = lds + l * C::LEVEL_LDS;
                 uint8_t* sJl = sIl + C::IW * C::IP;
                 if (fastI[l]) {
 #pragma unroll
                     for (int k = 0; k < IK; k++)
                         if (ion && (k * IR + irow) < C::IW) *reinterpret_cast<uint32_t*>(sIl + (k * IR + irow) * C::IP + 4 * idw) = fi[l][k];
-                } else tile_store<C::IW, C::INDW, T>(sIl, tid, ti[l]);
+                }
                 if (fastJ[l]) {
 #pragma unroll
                     for (int k = 0; k < JK; k++)
                         if (jon && (k * JR + jrow) < C::JT) *reinterpret_cast<uint32_t*>(sJl + (k * JR + jrow) * C::JP + 4 * jdw) = fj[l][k];
-                } else tile_store<C::JT, C::JNDW, T>(sJl, tid, tj[l]);
+                }
             }
         }
     }
@@ -291,7 +358,7 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     int st = 1;
     float errv = 0.f;
 
-    for (int level = P->max_level; level >= 0; level--) {
+    for (int level = top; level >= 0; level--) {
         STAMP(8 + level * 8 + 0);
         AgtLevel LJ = get_level(P->next[level]);
         if (io.grouped) {
@@ -303,10 +370,11 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         const uint8_t* imgJ = LJ.ptr + (long)b * LJ.bstride;
         const uint8_t* sI = lds + level * C::LEVEL_LDS;
         uint8_t* sJ = lds + level * C::LEVEL_LDS + C::IW * C::IP;
-        const float scale = 1.f / (float)(1 << level);
+        const int sJ_lds = agt_uniform((int)(unsigned)(uintptr_t)(__attribute__((address_space(3))) uint8_t*)sJ);      // (the search tile's LDS address: a multiple of 4)
+        const float scale = lk_level_scale(level);
         float prevx = ppx * scale, prevy = ppy * scale;
         float nextx, nexty;
-        if (level == P->max_level) {
+        if (!cont && level == P->max_level) {
             if (P->flags & AGT_LK_USE_INITIAL_FLOW) { nextx = outx * scale; nexty = outy * scale; }
             else { nextx = prevx; nexty = prevy; }
         } else { nextx = outx * 2.f; nexty = outy * 2.f; }
@@ -315,11 +383,8 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         prevx -= halfw; prevy -= halfw;
         const int ipx = agt_uniform((int)floorf(prevx)), ipy = agt_uniform((int)floorf(prevy));
         // (interior by precondition: no bounds test of the I window)
-        int iw00, iw01, iw10, iw11;
-        bilinear_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
-        uint32_t WL, WH;
-        int neg11;
-        rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+        uint32_t W01, W23;                         // the level's I-side weights, then every iteration's J-side weights
+        rs_weights_i16(prevx - (float)ipx, prevy - (float)ipy, W01, W23);
 
         // ---- I side in registers: B = un-rounded bilinear interpolation on the lane's 3 x NB grid (rows rr .. rr+2 of the
         // B grid = tile rows rr .. rr+3, columns x0s .. x0s + NB of the tile shifted by the alignment offset)
@@ -352,26 +417,11 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                         for (int d = 0; d < 3; d++) { ea[d] = __builtin_amdgcn_alignbyte(qa[d + 1], qa[d], sh); eb[d] = __builtin_amdgcn_alignbyte(qb[d + 1], qb[d], sh); }
                         ea[3] = __builtin_amdgcn_alignbyte(0u, qa[3], sh); eb[3] = __builtin_amdgcn_alignbyte(0u, qb[3], sh);
                     }
-                    uint32_t Pk[12];
-                    Pk[0] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL0); Pk[1] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL1); Pk[2] = __builtin_amdgcn_perm(eb[0], ea[0], RS_SEL2);
-                    {
-                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[1], ea[0], 3), mu = __builtin_amdgcn_alignbyte(eb[1], eb[0], 3);      // bytes 3..6
-                        Pk[3] = __builtin_amdgcn_perm(mu, m, RS_SEL0); Pk[4] = __builtin_amdgcn_perm(mu, m, RS_SEL1); Pk[5] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
-                    }
-                    Pk[6] = __builtin_amdgcn_perm(eb[1], ea[1], RS_SEL2);                                                                      // bytes 6, 7
-                    {
-                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[2], ea[1], 3), mu = __builtin_amdgcn_alignbyte(eb[2], eb[1], 3);      // bytes 7..10
-                        Pk[7] = __builtin_amdgcn_perm(mu, m, RS_SEL0); Pk[8] = __builtin_amdgcn_perm(mu, m, RS_SEL1); Pk[9] = __builtin_amdgcn_perm(mu, m, RS_SEL2);
-                    }
-                    Pk[10] = __builtin_amdgcn_perm(eb[2], ea[2], RS_SEL2);                                                                     // bytes 10, 11
-                    {
-                        const uint32_t m = __builtin_amdgcn_alignbyte(ea[3], ea[2], 3), mu = __builtin_amdgcn_alignbyte(eb[3], eb[2], 3);      // bytes 11..14
-                        Pk[11] = __builtin_amdgcn_perm(mu, m, RS_SEL0);
-                    }
+                    uint32_t QA[12], QB[12];
+                    rs_row_pairs<12, 4>(ea, QA); rs_row_pairs<12, 4>(eb, QB);
                     int Bw[12];
 #pragma unroll
-                    for (int k = 0; k < 12; k++) Bw[k] = rs_tap(Pk[k], WL, WH, 0u);
-                    if (neg11) rs_fix_taps<12>(Bw, Pk, neg11);
+                    for (int k = 0; k < 12; k++) Bw[k] = rs_tap2<false>(QA[k], QB[k], W01, W23);
                     if (on) {
                         int4* o = reinterpret_cast<int4*>(sB + br * BP + 12 * seg);
                         o[0] = make_int4(Bw[0], Bw[1], Bw[2], Bw[3]); o[1] = make_int4(Bw[4], Bw[5], Bw[6], Bw[7]); o[2] = make_int4(Bw[8], Bw[9], Bw[10], Bw[11]);
@@ -397,13 +447,13 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 e[i][1] = __builtin_amdgcn_alignbyte(q[2], q[1], sh);
                 e[i][2] = __builtin_amdgcn_alignbyte(q[3], q[2], sh);
             }
+            uint32_t Q[4][NB];
+#pragma unroll
+            for (int i = 0; i < 4; i++) rs_row_pairs<NB, 3>(e[i], Q[i]);
 #pragma unroll
             for (int i = 0; i < 3; i++) {
-                uint32_t Pk[NB];
-                rs_pack_taps<NB>(e[i][0], e[i][1], e[i][2], e[i + 1][0], e[i + 1][1], e[i + 1][2], Pk);
 #pragma unroll
-                for (int k = 0; k < NB; k++) Bv[i][k] = rs_tap(Pk[k], WL, WH, 0u);
-                if (neg11) rs_fix_taps<NB>(Bv[i], Pk, neg11);
+                for (int k = 0; k < NB; k++) Bv[i][k] = rs_tap2<false>(Q[i][k], Q[i + 1][k], W01, W23);
             }
             }
             int Cs[NB], Es[NB];                                 // vertical Scharr halves per column
@@ -427,11 +477,13 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             }
         }
         STAMP(8 + level * 8 + 1);
-        // (idle lanes duplicate the last active one: their partial sums are dropped, their patch values are never masked)
+        // (idle lanes duplicate the last active one; their derivatives are zeroed HERE, once per level, so that every product they
+        // enter -- the level's three, each iteration's two -- is zero without a select of its own: round 6)
+#pragma unroll
+        for (int k = 0; k < PX; k++) { Ix[k] = act ? Ix[k] : 0; Iy[k] = act ? Iy[k] : 0; }
         int a11 = 0, a12 = 0, a22 = 0;
 #pragma unroll
         for (int k = 0; k < PX; k++) { a11 += __mul24(Ix[k], Ix[k]); a12 += __mul24(Ix[k], Iy[k]); a22 += __mul24(Iy[k], Iy[k]); }
-        a11 = act ? a11 : 0; a12 = act ? a12 : 0; a22 = act ? a22 : 0;
         float A11, A12, A22;
         if constexpr (NW == 1) {
             float sdummy;
@@ -453,11 +505,19 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
             continue;
         }
         D = 1.f / D;
+        // (b1, b2 are scaled by 2^-20 before they enter the 2 x 2 solve: a power of two commutes with every rounding on the way to the
+        // step -- (A12 * (s2 * 2^-20) - A22 * (s1 * 2^-20)) * D = (A12 * s2 - A22 * s1) * (D * 2^-20) bit for bit (D * 2^-20 is exact and
+        // far from the denormals: D <= 1 / FLT_EPSILON) -- so the scale rides in D: one multiply less per iteration)
+        const float Ds = D * FLT_SCALE;
         STAMP(8 + level * 8 + 2);
 
         nextx -= halfw; nexty -= halfw;
         float pdx = 0.f, pdy = 0.f;
-        int jx0 = (int)floorf(gsx * scale - halfw) - C::MARGIN, jy0 = (int)floorf(gsy * scale - halfw) - C::MARGIN;
+        // (the position a level hands on is formed once, behind the loop: nextPts = nextPt + halfWin of the last step taken -- and, after an
+        // oscillation, minus half that step -- exactly OpenCV's two assignments; a level that takes no step hands on what it was given)
+        int moved = 0, half_back = 0;
+        float hbx = 0.f, hby = 0.f;
+        int jx0 = agt_uniform((int)floorf(gsx * scale - halfw)) - C::MARGIN, jy0 = agt_uniform((int)floorf(gsy * scale - halfw)) - C::MARGIN;      // (scalar: the tile origin enters every iteration's window address)
         auto restage_j = [&](int inx, int iny) {
             jx0 = inx - C::MARGIN; jy0 = iny - C::MARGIN;
             uint32_t t[C::JLD];
@@ -471,27 +531,27 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         int IvR[PX];
 #pragma unroll
         for (int k = 0; k < PX; k++) IvR[k] = (1 << (W_BITS - 5 - 1)) - (Iv[k] << (W_BITS - 5));
-        // the lane's temporal differences J - I (values * 32) at window position (inx, iny), weights in WL / WH
+        // the lane's temporal differences J - I (values * 32) at window position (inx, iny), weights in W01 / W23
         // (requesting the six dwords BEFORE the weights are computed, as the four-wave bodies do, measured slower here: 41.5-41.7
         // against 41.0-41.1 us per 64-stream step)
         auto window_taps = [&](int inx, int iny, int (&Jv)[PX]) {
             // (the window's origin inside the tile is wave-uniform; the lane's own offset is a constant)
-            const int a = (__mul24(iny - jy0, C::JP) + (inx - (jx0 & ~3))) + lane_off;
+            // (window origin: scalar arithmetic on scalar operands -- one vector add per iteration brings in the lane's part; the tile's
+            // base is a multiple of 4, so the byte shift is that of the offset alone)
+            typedef const __attribute__((address_space(3))) uint32_t* L32;
+            const int a = rs_pin((iny - jy0) * C::JP + (inx - (jx0 & ~3)) + sJ_lds) + lane_off;
             const int shj = a & 3;
-            const uint32_t* p0 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3));
-            const uint32_t* p1 = reinterpret_cast<const uint32_t*>(sJ + (a & ~3) + C::JP);
+            const L32 p0 = (L32)(uintptr_t)(unsigned)(a & ~3);
+            const L32 p1 = (L32)(uintptr_t)(unsigned)((a & ~3) + C::JP);
             uint32_t d[3] = { 0, 0, 0 }, f[3] = { 0, 0, 0 };
 #pragma unroll
             for (int i = 0; i < R::JDW; i++) { d[i] = p0[i]; f[i] = p1[i]; }
-            const uint32_t a0 = __builtin_amdgcn_alignbyte(d[1], d[0], shj), a1 = __builtin_amdgcn_alignbyte(d[2], d[1], shj);
-            const uint32_t b0 = __builtin_amdgcn_alignbyte(f[1], f[0], shj), b1 = __builtin_amdgcn_alignbyte(f[2], f[1], shj);
-            uint32_t Pk[PX];
-            rs_pack_taps<PX>(a0, a1, 0u, b0, b1, 0u, Pk);
+            const uint32_t ra[2] = { __builtin_amdgcn_alignbyte(d[1], d[0], shj), __builtin_amdgcn_alignbyte(d[2], d[1], shj) };
+            const uint32_t rb[2] = { __builtin_amdgcn_alignbyte(f[1], f[0], shj), __builtin_amdgcn_alignbyte(f[2], f[1], shj) };
+            uint32_t QA[PX], QB[PX];
+            rs_row_pairs<PX, 2>(ra, QA); rs_row_pairs<PX, 2>(rb, QB);
 #pragma unroll
-            for (int k = 0; k < PX; k++) Jv[k] = rs_tap(Pk[k], WL, WH, (uint32_t)IvR[k]);
-            if (neg11) rs_fix_taps<PX>(Jv, Pk, neg11);
-#pragma unroll
-            for (int k = 0; k < PX; k++) Jv[k] >>= (W_BITS - 5);
+            for (int k = 0; k < PX; k++) Jv[k] = rs_tap2(QA[k], QB[k], W01, W23, IvR[k]) >> (W_BITS - 5);
         };
         // While the window's corner stays in this box it is inside the image band and inside the search tile: one float test per
         // iteration instead of the two integer ones (which remain, word for word, behind it); and ONE vector -> scalar decision
@@ -500,13 +560,16 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
         auto set_box = [&]() {
             const int lx = jx0 > -WIN ? jx0 : -WIN, hx = (jx0 + C::JT - WIN - 1 < LJ.w - 1 ? jx0 + C::JT - WIN - 1 : LJ.w - 1) + 1;
             const int ly = jy0 > -WIN ? jy0 : -WIN, hy = (jy0 + C::JT - WIN - 1 < LJ.h - 1 ? jy0 + C::JT - WIN - 1 : LJ.h - 1) + 1;
-            bx0 = (float)lx; bx1 = (float)hx; by0 = (float)ly; by1 = (float)hy;
+            bx0 = rs_scalar((float)lx); bx1 = rs_scalar((float)hx); by0 = rs_scalar((float)ly); by1 = rs_scalar((float)hy);     // (scalar operands of the compares; no loop-carried vector copies)
         };
         set_box();
         int slow = agt_uniform((int)!(nextx >= bx0 && nextx < bx1 && nexty >= by0 && nexty < by1));
         for (int j = 0; j < P->max_count; j++) {
             nit++;
-            const int inx = agt_uniform((int)floorf(nextx)), iny = agt_uniform((int)floorf(nexty));
+            // (the floor as a float feeds the fractions, as an integer the address: nextx - (float)(int)floorf(nextx) = nextx - floorf(nextx)
+            // exactly at image coordinates)
+            const float flx = floorf(nextx), fly = floorf(nexty);
+            const int inx = agt_uniform((int)flx), iny = agt_uniform((int)fly);
             if (slow) {
                 if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) {
                     if (level == 0) st = 0;
@@ -514,22 +577,18 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 }
                 if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) { restage_j(inx, iny); set_box(); }
             }
-            bilinear_weights(nextx - (float)inx, nexty - (float)iny, iw00, iw01, iw10, iw11);
-            rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+            rs_weights_i16(nextx - flx, nexty - fly, W01, W23);
             int Jv[PX];
             window_taps(inx, iny, Jv);
             int b1 = 0, b2 = 0;
 #pragma unroll
             for (int k = 0; k < PX; k++) { b1 = rs_mad24(Jv[k], Ix[k], b1); b2 = rs_mad24(Jv[k], Iy[k], b2); }
-            b1 = act ? b1 : 0; b2 = act ? b2 : 0;
             float sb1, sb2;
             sum2(b1, b2, sb1, sb2);
-            const float fb1 = sb1 * FLT_SCALE;
-            const float fb2 = sb2 * FLT_SCALE;
-            const float dx = (A12 * fb2 - A22 * fb1) * D;
-            const float dy = (A12 * fb1 - A11 * fb2) * D;
+            const float dx = (A12 * sb2 - A22 * sb1) * Ds;
+            const float dy = (A12 * sb1 - A11 * sb2) * Ds;
             nextx += dx; nexty += dy;
-            outx = nextx + halfw; outy = nexty + halfw;
+            moved = 1;
             if (j == 0) STAMP(8 + level * 8 + 3);
 #ifdef AGT_LK_STAMPS
             if (pidx == 0 && threadIdx.x == 0) agt_lk_stamps[8 + level * 8 + 6] = j + 1;
@@ -550,19 +609,22 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
                 code = agt_uniform(conv ? 1 : (osc ? 2 : (out_of_box ? 3 : 0)));
             }
             if (code == 1) break;
-            if (code == 2) { outx -= dx * 0.5f; outy -= dy * 0.5f; break; }
+            if (code == 2) { half_back = 1; hbx = dx * 0.5f; hby = dy * 0.5f; break; }
             slow = code == 3;
             pdx = dx; pdy = dy;
         }
 
+        if (moved) {
+            outx = nextx + halfw; outy = nexty + halfw;
+            if (half_back) { outx -= hbx; outy -= hby; }
+        }
         STAMP(8 + level * 8 + 4);
         if (st && io.err && level == 0 && !(P->flags & AGT_LK_GET_MIN_EIGENVALS)) {
             const float npx = outx - halfw, npy = outy - halfw;
             const int inx = agt_uniform((int)floorf(npx)), iny = agt_uniform((int)floorf(npy));
             if (inx < -WIN || inx >= LJ.w || iny < -WIN || iny >= LJ.h) { st = 0; continue; }
             if (inx < jx0 || inx + WIN >= jx0 + C::JT || iny < jy0 || iny + WIN >= jy0 + C::JT) restage_j(inx, iny);
-            bilinear_weights(npx - (float)inx, npy - (float)iny, iw00, iw01, iw10, iw11);
-            rs_pack_weights(iw00, iw01, iw10, iw11, WL, WH, neg11);
+            rs_weights_i16(npx - (float)inx, npy - (float)iny, W01, W23);
             int Jv[PX];
             window_taps(inx, iny, Jv);
             int e = 0;
@@ -581,6 +643,9 @@ __device__ __forceinline__ void lk_body_rs(PP P, int pt, int b, uint8_t* lds, co
     STAMP(3);
     if (tid == 0) lk_publish(io, pidx, b, outx, outy, st, errv);
     if (tid == 0 && io.iters_out) io.iters_out[pidx] = (uint8_t)(nit > 255 ? 255 : nit);
+#ifdef AGT_LK_STAMPS
+    if (tid == 0 && !io.grouped && pidx < AGT_LK_CORNER_LOG) agt_lk_corner_log[pidx][2] = (unsigned long long)nit;
+#endif
     ox = outx; oy = outy; ost = st;
 }
 
