@@ -9,9 +9,13 @@
 #include <time.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <atomic>
+#include <mutex>
+#include <vector>
 
 #define AGT_SLOTS 4              // ring entries every context owns (slots 0 / 1 are also the public pyramid slots)
 #define AGT_RING_MAX 224         // (levels + 1) * AGT_MAX_GROUP frames in flight at the deepest pipeline
+#define AGT_EV_SLOTS 8           // events of the split pipeline, per kind: a launch waits for events at most three launches old (l_ev_hist), slots are re-recorded modulo 8
 // The two-level pyramid pass saves a launch / pipeline stage and 16 % of the pyramid's HBM bytes, but its 41 KB workgroups
 // (3 per CU, eight barriers per tile) stream at 2.5 TB/s against 3.9 + 3.4 TB/s for two single-level passes (8 per CU): it is
 // used where the stage count matters (few streams), the two passes where throughput does (measured at 64 x 720p: 30.5 vs 25 us).
@@ -49,7 +53,8 @@ struct agt_ctx {
     // big batches: the three stages of a step run on three library-owned streams (stage kernels of different frames
     // overlap: 57 us against 93 us back to back at 64 streams); events carry the exact dependencies
     hipStream_t ms_stream[3];                // pyramid, LK, PnP
-    hipEvent_t ms_ev[5][AGT_RING_MAX];       // per ring entry: caller's hand-over, pyramid done, LK done, PnP done, LK done (second half of the streams)
+    hipEvent_t ms_ev[5][AGT_EV_SLOTS];       // per launch (modulo AGT_EV_SLOTS): pyramid done, LK done, [2]: join / hand-over events, PnP done, LK done (second half of the streams)
+    int ms_pool_slot;                        // which set of the process's library streams the context holds (-1: none)
     int ms_ready, ms_active;                 // streams / events exist; frames are in flight on them
     // split mode (more corners in flight than the fused launch takes): the pipeline's groups go out as three launches,
     // pyramid on the caller's stream, LK and PnP on library streams (ms_stream[1], [2])
@@ -100,6 +105,8 @@ struct agt_ctx {
 static int ms_join(agt_ctx* c);
 static int join_pipeline(agt_ctx* c);
 static int ms_init(agt_ctx* c);
+static int ms_pool_acquire(int device, hipStream_t out[3]);
+static void ms_pool_release(int slot);
 
 namespace {
 
@@ -242,6 +249,7 @@ int dense_scratch(agt_ctx* c, size_t need, int B)
 // sized by the runtime's device count (16 fixed entries turned a valid device 16+ into hipErrorInvalidDevice).
 #include <atomic>
 #include <mutex>
+#include <vector>
 namespace {
 constexpr int CHIP_MAX = 256;
 AgtChip g_chip[CHIP_MAX];
@@ -414,8 +422,8 @@ int agt_destroy(agt_ctx* c)
     }
     if (c->ms_ready) {
         for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->ms_stream[i]);
-        for (int k = 0; k < 5; k++) for (int i = 0; i < AGT_RING_MAX; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
-        for (int i = 0; i < 3; i++) (void)hipStreamDestroy(c->ms_stream[i]);
+        for (int k = 0; k < 5; k++) for (int i = 0; i < AGT_EV_SLOTS; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
+        ms_pool_release(c->ms_pool_slot);            // (the streams go back to the process's pool: see ms_pool_acquire)
     }
     if (c->lkerr) (void)hipFree(c->lkerr);
     if (c->obj) (void)hipFree(c->obj);
@@ -1113,7 +1121,7 @@ static int launch_group(agt_ctx* c, int B, int fmax = 0)
     // hardware queues, and four kernels of <= 1 wave per SIMD each stretch one another.)
     const int B1 = (!agt_lk_wide(c->trk_n, B) && (long)c->trk_n * (B / 2) >= 512) ? B / 2 : B;
     const bool two = B1 < B;
-    const int slot_ev = (int)(c->split_seq % AGT_RING_MAX);
+    const int slot_ev = (int)(c->split_seq % AGT_EV_SLOTS);
     bool p_work = false;
     for (int s = 0; s < AGT_MAX_LEVELS - 1; s++) p_work |= S.n_pyr[s] > 0;
     const int p_before = c->last_p_ev, l_before = c->l_ev_hist[0];
@@ -1316,18 +1324,54 @@ int agt_estimate_pose(agt_ctx* c, const float* d_img, const uint8_t* d_mask, int
 // Big batches: pyramid, LK and PnP of one frame as separate kernels on three library-owned streams.  The host runs
 // ahead, so the pyramid of frame t+1 overlaps the LK of frame t and the PnP of frame t-1; every true dependency
 // (and every buffer reuse of the rings) is an event wait, nothing is assumed about timing.
+// The library's streams are a PROCESS resource (round 6).  A process has four hardware queues and the runtime deals
+// every new stream onto them round-robin; it does not hand a destroyed stream's place to the next one.  Contexts that each created and
+// destroyed their own three streams therefore left the next context's streams wherever the deal happened to stand -- two of them on
+// one queue sooner or later, and the split pipeline, which needs its pyramid / LK / LK / pose launches on four different queues, ran
+// 1.5-1.8 x slower from then on.  Now a set of three highest-priority streams per device is created once, lent
+// to the context that runs a split pipeline and taken back at agt_destroy; a second live context on the device gets a second set.
+namespace {
+struct MsPoolEntry { int device; hipStream_t s[3]; bool busy; };
+std::vector<MsPoolEntry> g_ms_pool;
+std::mutex g_ms_pool_mutex;
+}
+static int ms_pool_acquire(int device, hipStream_t out[3])
+{
+    std::lock_guard<std::mutex> lock(g_ms_pool_mutex);
+    for (size_t i = 0; i < g_ms_pool.size(); i++)
+        if (!g_ms_pool[i].busy && g_ms_pool[i].device == device) {
+            g_ms_pool[i].busy = true;
+            for (int k = 0; k < 3; k++) out[k] = g_ms_pool[i].s[k];
+            return (int)i;
+        }
+    // the LK launches are the long pole of a split-mode step and share the chip with the pyramid launches of the caller's stream, whose
+    // short workgroups otherwise take every wave slot first: the library's streams get the highest priority
+    MsPoolEntry e; e.device = device; e.busy = true;
+    int pr_lo = 0, pr_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+    for (int k = 0; k < 3; k++) {
+        if (hipStreamCreateWithPriority(&e.s[k], hipStreamNonBlocking, pr_hi) != hipSuccess) {
+            for (int q = 0; q < k; q++) (void)hipStreamDestroy(e.s[q]);
+            return -1;
+        }
+        out[k] = e.s[k];
+    }
+    g_ms_pool.push_back(e);
+    return (int)g_ms_pool.size() - 1;
+}
+static void ms_pool_release(int slot)
+{
+    std::lock_guard<std::mutex> lock(g_ms_pool_mutex);
+    if (slot >= 0 && slot < (int)g_ms_pool.size()) g_ms_pool[slot].busy = false;
+}
+
 static int ms_init(agt_ctx* c)
 {
     if (c->ms_ready) return AGT_OK;
-    // the LK launches are the long pole of a split-mode step (VALU-issue bound, ~38 us at 64 x 720p) and share the chip with
-    // the pyramid launches of the caller's stream, whose short workgroups otherwise take every wave slot first: the LK (and
-    // PnP) streams get the highest priority so that their workgroups are placed ahead of the pyramid's
-    int pr_lo = 0, pr_hi = 0;
-    (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-    for (int i = 0; i < 3; i++)
-        if (hipStreamCreateWithPriority(&c->ms_stream[i], hipStreamNonBlocking, pr_hi) != hipSuccess) return hip_fail(c, hipGetLastError());
+    c->ms_pool_slot = ms_pool_acquire(c->cfg.device, c->ms_stream);
+    if (c->ms_pool_slot < 0) return hip_fail(c, hipGetLastError());
     for (int k = 0; k < 5; k++)
-        for (int i = 0; i < AGT_RING_MAX; i++)
+        for (int i = 0; i < AGT_EV_SLOTS; i++)
             if (hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) return hip_fail(c, hipGetLastError());
     c->ms_ready = 1;
     return AGT_OK;

@@ -198,6 +198,31 @@ def test_lk_wild_coordinates_are_lost_corners(cvh, oracle, seq640):
     assert not g[1][:4].any() and g[1].ravel()[4:12].all()
 
 
+def test_lk_one_wave_border_levels_hand_over(cvh, oracle, seq720):
+    """Round 6: in a big batch (one wave per corner) a corner whose 21 x 21 window touches the image border only at the COARSEST pyramid
+    level is tracked by the general body at that level and by the row-segment body at the finer ones (agt_lk.hip lk_kernel,
+    rs_interior_levels); one that touches it at a finer level too keeps the general body throughout.  Corners at every distance from
+    every border, mixed into a batch of interior ones: bit-identical to the oracle, status and err included, with and without an
+    initial flow, and with the general body forced on everything as the cross-check."""
+    a, b = seq720.frame(0), seq720.frame(1)
+    h, w = a.shape
+    rng = np.random.default_rng(23)
+    good = np.tile(seq720.corners(0), (24, 1)) + rng.uniform(-0.4, 0.4, (24 * 48, 2)).astype(np.float32)        # 1,152 corners: the one-wave kernel
+    d = np.array([1.5, 7.2, 10.9, 11.1, 14.0, 21.7, 22.3, 33.0, 43.9, 44.6, 47.5, 60.2, 88.0], np.float32)       # level 0 / 1 / 2 need ~11 / 22 / 44 px of room
+    xs = np.linspace(60, w - 60, len(d)).astype(np.float32)
+    ys = np.linspace(60, h - 60, len(d)).astype(np.float32)
+    border = np.concatenate([np.stack([xs, d], 1), np.stack([xs, h - 1 - d], 1), np.stack([d, ys], 1), np.stack([w - 1 - d, ys], 1),
+                             np.stack([d, d], 1), np.stack([w - 1 - d, h - 1 - d], 1)]).astype(np.float32)
+    pts = np.concatenate([good[:600], border, good[600:]])
+    for kw in (dict(maxLevel=2), dict(maxLevel=2, flags=8), dict(maxLevel=1), dict(maxLevel=3)):
+        o, g = _lk_both(cvh, oracle, a, b, pts, **kw)
+        _assert_lk_equal(o, g)
+    init = pts + rng.normal(0, 1.0, pts.shape).astype(np.float32)
+    o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2, flags=4, nextPts=init)
+    _assert_lk_equal(o, g)
+    assert o[1][600:600 + len(border)].sum() > len(border) // 2, "most border corners are still trackable: the hand-over is exercised on live corners"
+
+
 def test_lk_random_texture_other_sizes(cvh, oracle):
     from scipy.ndimage import gaussian_filter, shift
     rng = np.random.default_rng(11)
