@@ -16,10 +16,12 @@
 // are reflections OF LEVEL 1 (pyrDown(L1) reflects L1, which differs from filtering reflected level-0 pixels): columns by the same
 // in-register trick on the level-1 bytes, rows by picking the reflected entry of the level-1 window (all of them are in it).
 // Both exist only in the EDGE form of the row loop (wave-uniform choice).
-// Shipped use (round 4): the FUSED UPLOAD of agt_track_host_frame -- the pass reads a gray frame straight from pinned host memory
+// Shipped uses: (round 4) the FUSED UPLOAD of agt_track_host_frame -- the pass reads a gray frame straight from pinned host memory
 // (one frame: 22.9 us for both levels, PCIe-bound, against a 19 us copy-engine transfer + ~8 us of its submission + a 6 us pyramid
-// launch) and stores the frame's level 0 to HBM on the way (COPY).  As a plain HBM -> HBM pass it is not faster than what it would
-// replace (agt_pyramid.hip agt_pyr2_plan) and stays a knobs-build experiment there.
+// launch) and stores the frame's level 0 to HBM on the way (COPY); (round 5) the plain HBM -> HBM pyramid pass of every launch of >= 16
+// images (agt_pyramid.hip agt_pyr2_plan; pyr_roll2_kernel and the pyramid role of the split pipeline, pyr_group_kernel): with strips
+// walked in alternating directions and the lean horizontal / vertical passes below it moves 1.004 x SURVEY 8d's bytes and streams 64
+// frames of 1280x720 in 18.6 us alone (profiles/r05_c3_kernel_stats.csv); smaller launches keep the tiled two-level pass.
 #pragma once
 #include "agt_pyramid3_body.h"
 

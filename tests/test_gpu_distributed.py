@@ -76,3 +76,28 @@ def test_context_reports_the_device_it_sits_on():
         assert xcds.value == cus.value // 32, "gfx950: one XCD per 32 CUs"
     else:
         assert xcds.value == 1
+
+
+def test_two_rank_rehearsal_of_the_bench_flow_on_one_card():
+    """`bench.py --gpus 2 --workload c4` exactly as the driver starts an N-GPU run without a launcher -- the parent counts
+    devices without touching the GPU and starts the ranks as fresh children (bench.py self_launch: no exec of an initialised process
+    anywhere) -- on the ONE card of this box: the ranks share it and gather over gloo (RCCL needs a GPU per rank), everything else is
+    the N-GPU flow: rank-specific streams (seeds 1000 r + s), one gather of the record block per timed block, max-over-ranks timing,
+    rank 0 printing the line.  Asserted: two ranks, the gathered block is in rank order and holds each rank's own poses, it is
+    labelled a rehearsal.  No scaling figure is read off it."""
+    import json
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env.pop("AGT_DIST_BACKEND", None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "c4", "--steps", "8", "--blocks", "2",
+                        "--warmup", "4", "--render-frames", "6", "--no-cpu-baseline", "--no-extras"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert "REHEARSAL" in r.stderr, "the parent says what it is about to do before it starts the ranks"
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, "rank 0 prints ONE line"
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["rccl_ranks"] == 2 and d["gather_order_ok"] is True
+    assert d["rehearsal"] is True and d["dist_backend"].startswith("gloo")
+    assert d["gathered_shape"][0] == 2 and d["gathered_shape"][1] == 8
+    assert d["config"]["workload"].startswith("c4") and d["scaling"] == "weak" and d["value"] > 0
+    assert d["accepted_frac"] == 1.0 and d["gather_max_abs_pose_err_vs_truth"] < 0.05

@@ -214,3 +214,25 @@ def test_lk_fallback_fills_the_hole(tmp_path, oracle, seq640):
         assert det.last_pose[0] is not None and det.last_error < 2
         assert np.abs(det.last_pose[0].ravel() - s.rvecs[k]).max() < 3e-3
         assert np.abs(det.last_pose[1].ravel() - s.tvecs[k]).max() < 3e-3
+
+
+def test_rodrigues_matrix_to_vector_jacobian():
+    """cv2.Rodrigues(3x3) returns d(rvec)/d(R) as a (9, 3) array (the reference only takes [0]; zeros until round 6).  The formula is
+    cvRodrigues2's; checked here by the chain rule on rotations -- composing it with the vector -> matrix Jacobian must give the
+    identity -- and against central differences along the rotation manifold."""
+    from accurate_aprilgroup_tracking_amd.host_math import Rodrigues
+    rng = np.random.default_rng(3)
+    for _ in range(20):
+        r = rng.normal(0, 0.8, 3)
+        R, Jf = Rodrigues(r)                       # Jf: (3, 9) = dR/dr, rows = components of r
+        rv, Jb = Rodrigues(R)                      # Jb: (9, 3) = (dr/dR)^T
+        assert Jb.shape == (9, 3) and Jb.dtype == np.float64 and np.allclose(rv.ravel(), r, atol=1e-12)
+        assert np.allclose(Jf @ Jb, np.eye(3), atol=1e-9), "d r / d r through R"
+        h = 1e-6
+        for j in range(3):
+            e = np.zeros(3); e[j] = h
+            dR = (Rodrigues(r + e)[0] - Rodrigues(r - e)[0]) / (2 * h)
+            assert np.allclose(Jb.T @ dR.reshape(9), np.eye(3)[j], atol=1e-6)
+    # singular branches: zeros, as OpenCV
+    assert not Rodrigues(np.eye(3))[1].any()
+    assert Rodrigues(np.eye(3, dtype=np.float32))[1].dtype == np.float32
