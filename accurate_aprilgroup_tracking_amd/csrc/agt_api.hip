@@ -536,6 +536,72 @@ int agt_pyramid_build(agt_ctx* c, int slot, const uint8_t* d_frames, size_t pitc
     return pyramid_build_on(c, c->stream, slot, d_frames, pitch, batch_stride, B);
 }
 
+// Both pyramids of a frame pair (slot 0 <- d_prev, slot 1 <- d_next) with ONE launch for levels 1 and 2 (round 6).  A batch of cold
+// pairs pays two pyramid launches per step otherwise, each a stream of its own length with a ramp and a tail and a kernel boundary
+// between them (~2 us between two streaming kernels on one stream): the two-level rolling pass of 2 B images is the same pass, once.
+// The geometry of both frames is one (pitch, batch_stride); deeper levels, other windows and small batches fall back to two builds.
+int agt_pyramid_build_pair(agt_ctx* c, const uint8_t* d_prev, const uint8_t* d_next, size_t pitch, size_t batch_stride, int B)
+{
+    if (!c || !d_prev || !d_next) return AGT_ERR_ARG;
+    int rc = join_pipeline(c);
+    if (rc) return rc;
+    c->prebuilt_t = -1;
+    const int L = c->eff_max_level;
+    bool one = L >= 2 && agt_step_supported(c->cfg.win) && B > 0 && B <= c->cfg.max_streams &&
+               !((pitch & 3) || ((uintptr_t)d_prev & 3) || ((uintptr_t)d_next & 3) || (batch_stride & 3) || pitch < (size_t)c->cfg.width);
+    AgtStepParams S;
+    AgtStepTables T;
+    if (one) {
+        memset(&S, 0, sizeof(S));
+        memset(&T, 0, sizeof(T));
+        S.pnp.fault = c->fault_dev;
+        AgtPyrArgs& A = S.pyr[0];
+        A.sw = c->lw[0]; A.sh = c->lh[0]; A.dw = c->lw[1]; A.dh = c->lh[1];
+        A.spitch = (long)pitch; A.sbatch = (long)batch_stride;
+        A.dpitch = c->lpitch[1]; A.dbatch = (long)c->lh[1] * c->lpitch[1];
+        A.B = B;
+        uintptr_t src_align = 0, dst_align = 0;
+        const uint8_t* src[2] = { d_prev, d_next };
+        for (int k = 0; k < 2; k++) {
+            T.pyr_src[0][k] = src[k]; T.pyr_dst[0][k] = c->lmem[k][1]; T.pyr_dst[1][k] = c->lmem[k][2];
+            src_align |= (uintptr_t)src[k]; dst_align |= (uintptr_t)c->lmem[k][1] | (uintptr_t)c->lmem[k][2];
+        }
+        A.src = T.pyr_src[0][0]; A.dst = T.pyr_dst[0][0];
+        AgtPyrArgs A0 = A, A1 = S.pyr[1];
+        A1.sw = c->lw[1]; A1.sh = c->lh[1]; A1.dw = c->lw[2]; A1.dh = c->lh[2];
+        A1.spitch = c->lpitch[1]; A1.sbatch = (long)c->lh[1] * c->lpitch[1];
+        A1.dpitch = c->lpitch[2]; A1.dbatch = (long)c->lh[2] * c->lpitch[2];
+        A1.B = B; A1.src = nullptr; A1.dst = nullptr;
+        agt_pyr2_plan(&A0, &A1, src_align, dst_align, 2);
+        one = A0.pad != 0 || B <= AGT_PYR2_MAX_B;             // (rolling form for big batches; the tiled two-level pass for small ones)
+        if (one) {
+            S.pyr[0] = A0; S.pyr[1] = A1;
+            S.pyr_fused = 1;
+            S.pyr_nf[0] = 2;
+            S.n_pyr[0] = A0.gx * A0.gy * B * 2;
+        }
+    }
+    if (!one) {
+        rc = pyramid_build_on(c, c->stream, 0, d_prev, pitch, batch_stride, B);
+        return rc ? rc : pyramid_build_on(c, c->stream, 1, d_next, pitch, batch_stride, B);
+    }
+    hipError_t e = agt_launch_step(c->stream, S, T, c->cfg.win, AGT_STEP_PYR);
+    if (e != hipSuccess) return hip_fail(c, e);
+    const uint8_t* src[2] = { d_prev, d_next };
+    for (int k = 0; k < 2; k++) {
+        c->l0_ptr[k] = src[k]; c->l0_pitch[k] = (long)pitch; c->l0_bstride[k] = (long)batch_stride;
+        const uint8_t* sp_ = c->lmem[k][2]; long spitch = c->lpitch[2], sb = (long)c->lh[2] * c->lpitch[2];
+        for (int l = 3; l <= L; l++) {
+            const long db = (long)c->lh[l] * c->lpitch[l];
+            e = agt_launch_pyr_down(c->stream, sp_, c->lw[l - 1], c->lh[l - 1], spitch, sb, c->lmem[k][l], c->lpitch[l], db, B);
+            if (e != hipSuccess) return hip_fail(c, e);
+            sp_ = c->lmem[k][l]; spitch = c->lpitch[l]; sb = db;
+        }
+        c->built_B[k] = B;
+    }
+    return AGT_OK;
+}
+
 int agt_pyramid_max_level(const agt_ctx* c) { return c ? c->eff_max_level : AGT_ERR_ARG; }
 
 int agt_pyramid_level(const agt_ctx* c, int slot, int level, const uint8_t** d_ptr,

@@ -134,6 +134,17 @@ class Context:
                 "agt_pyramid_build")
         self._keep[slot] = frames
 
+    def pyramid_build_pair(self, prev, nxt):
+        """both slots of a frame pair in one call (agt_pyramid_build_pair): slot 0 <- prev, slot 1 <- nxt, cuda uint8 [B,H,W] of one
+        geometry (what cv2.calcOpticalFlowPyrLK(prev, next, ...) builds internally)"""
+        for f in (prev, nxt):
+            assert f.dtype == torch.uint8 and f.is_cuda and f.dim() == 3
+        B, h, w = prev.shape
+        if (h, w) != (self.height, self.width) or tuple(nxt.shape) != tuple(prev.shape) or nxt.stride() != prev.stride():
+            raise error("frame pair: %s / %s do not match the context (%dx%d) or each other" % (tuple(prev.shape), tuple(nxt.shape), self.width, self.height))
+        H.check(self.L.agt_pyramid_build_pair(self.h, _ptr(prev), _ptr(nxt), prev.stride(1), prev.stride(0), B), "agt_pyramid_build_pair")
+        self._keep[0] = prev; self._keep[1] = nxt
+
     def pyramid_level(self, slot, level):
         """copy of one level of a built slot: numpy uint8 [B, h_l, w_l] (tests)"""
         p, w, h, pitch, bs = C.c_void_p(), C.c_int(), C.c_int(), C.c_size_t(), C.c_size_t()
@@ -375,8 +386,7 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
         dev = torch.device("cuda", ctx.device)
         fa = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fa[0, :, :w] = torch.from_numpy(a).to(dev)
         fb = torch.zeros((1, h, wp), dtype=torch.uint8, device=dev); fb[0, :, :w] = torch.from_numpy(b).to(dev)
-        ctx.pyramid_build(0, fa[:, :, :w])      # views keep the padded pitch (multiple of 4)
-        ctx.pyramid_build(1, fb[:, :, :w])
+        ctx.pyramid_build_pair(fa[:, :, :w], fb[:, :, :w])      # views keep the padded pitch (multiple of 4); both pyramids, one call
         pp = torch.from_numpy(pts).to(dev).reshape(1, n, 2).contiguous()
         nx = None
         if nextPts is not None and (flags & OPTFLOW_USE_INITIAL_FLOW):

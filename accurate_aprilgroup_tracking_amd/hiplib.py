@@ -30,7 +30,7 @@ DN_RVEC, DN_TVEC, DN_REFINED, DN_PHOTO_RMS, DN_GEO_RMS, DN_VALID, DN_ITERS, DN_C
 # every symbol include/agt_hip.h declares (tests check the .so exports all of them)
 SYMBOLS = [
     "agt_version", "agt_error_string", "agt_create", "agt_destroy", "agt_set_stream",
-    "agt_last_hip_error", "agt_synchronize", "agt_pyr_down_u8", "agt_pyramid_build",
+    "agt_last_hip_error", "agt_synchronize", "agt_pyr_down_u8", "agt_pyramid_build", "agt_pyramid_build_pair",
     "agt_pyramid_level", "agt_pyramid_max_level", "agt_lk_track", "agt_solve_pnp",
     "agt_project_points", "agt_tracker_reset", "agt_tracker_options", "agt_estimate_pose",
     "agt_tracker_state_size", "agt_tracker_state_read", "agt_track_frame", "agt_track_frames", "agt_tracker_buffers",
@@ -85,6 +85,7 @@ def lib():
     L.agt_synchronize.argtypes = [vp]
     L.agt_pyr_down_u8.argtypes = [vp, vp, i32, i32, sz, sz, vp, sz, sz, i32]
     L.agt_pyramid_build.argtypes = [vp, i32, vp, sz, sz, i32]
+    L.agt_pyramid_build_pair.argtypes = [vp, vp, vp, sz, sz, i32]
     L.agt_pyramid_level.argtypes = [vp, i32, i32, C.POINTER(vp), C.POINTER(i32), C.POINTER(i32),
                                     C.POINTER(sz), C.POINTER(sz)]
     L.agt_pyramid_max_level.argtypes = [vp]

@@ -364,6 +364,7 @@ def main():
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--stream-lk-occupancy", type=int, default=0, help="stream workloads (c2..c5): agt_lk_occupancy of the tracker's context (experiment; 0 = none)")
     ap.add_argument("--lk-occupancy", type=int, default=2, help="c3pairs: cap of the LK kernel's resident waves per SIMD in every context (agt_lk_occupancy; 0 = none)")
+    ap.add_argument("--no-pair-build", action="store_true", help="c3pairs: two agt_pyramid_build calls per batch (the form of rounds 3-5) instead of one agt_pyramid_build_pair")
     ap.add_argument("--pair-contexts", type=int, default=4, help="c3pairs: contexts / streams the independent batches are pipelined over (1 = serial)")
     ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
     ap.add_argument("--blocks", type=int, default=15, help="timed blocks of --steps steps each (median / p10 / p90 over them)")

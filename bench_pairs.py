@@ -82,13 +82,20 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
     vp = lambda t: C.c_void_p(t.data_ptr())
     pitch, bstride = W, W * H
 
+    PAIR_BUILD = not getattr(args, "no_pair_build", False)
+
     def step(j, pose_k, events=None, q=0):
         h, nx, st, info, sq_ = ctxs[q].h, nxs[q], sts[q], infos[q], streams[q]
         rec = (lambda i: events[i].record(sq_)) if events else (lambda i: None)
         rec(0)
-        HL.check(L.agt_pyramid_build(h, 0, vp(prev[j]), pitch, bstride, B), "agt_pyramid_build")
-        rec(1)
-        HL.check(L.agt_pyramid_build(h, 1, vp(nxt[j]), pitch, bstride, B), "agt_pyramid_build")
+        if PAIR_BUILD:
+            # both pyramids of the batch's pairs in one call / one launch of the two-level pass over 2 B images (round 6: agt_pyramid_build_pair)
+            HL.check(L.agt_pyramid_build_pair(h, vp(prev[j]), vp(nxt[j]), pitch, bstride, B), "agt_pyramid_build_pair")
+            rec(1)
+        else:
+            HL.check(L.agt_pyramid_build(h, 0, vp(prev[j]), pitch, bstride, B), "agt_pyramid_build")
+            rec(1)
+            HL.check(L.agt_pyramid_build(h, 1, vp(nxt[j]), pitch, bstride, B), "agt_pyramid_build")
         rec(2)
         HL.check(L.agt_lk_track(h, 0, 1, vp(pts_d[j]), vp(nx), vp(st), None, npts, B, 3, 30, 0.01, 0, 1e-4), "agt_lk_track")
         rec(3)
@@ -158,19 +165,19 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         # longest stage of the serial pass until round 5 capped the tracker's occupancy, which stretches the LK launch ALONE from 36 to
         # 45 us while the pipelined step gets shorter: the longest launch of the serial pass is no longer the kernel that bounds the step)
         dom = max(per, key=lambda n: per[n][0])
-        nlaunches = {"pyramid": 2, "lk": 1, "pnp": 1}              # (round 5: one two-level pass per pyramid build)
+        nlaunches = {"pyramid": 1 if PAIR_BUILD else 2, "lk": 1, "pnp": 1}              # (round 5: one two-level pass per pyramid build; round 6: one per PAIR of builds)
         nlaunch = nlaunches[dom]
         kernel_us_alone = per[dom][1] / nlaunch
         achieved_alone = per[dom][0] / nlaunch / (kernel_us_alone * 1e-6) / 1e9
         # the line's roofline figure is the kernel AS TIMED (pipelined pass); the stand-alone figure rides beside it
-        pipe_us = {"pyramid": float(sp_pipe[0] + sp_pipe[1]) / 2, "lk": float(sp_pipe[2]), "pnp": float(sp_pipe[3])} if sp_pipe is not None else None
+        pipe_us = {"pyramid": float(sp_pipe[0] + sp_pipe[1]) / nlaunches["pyramid"], "lk": float(sp_pipe[2]), "pnp": float(sp_pipe[3])} if sp_pipe is not None else None
         kernel_us = pipe_us[dom] if pipe_us else kernel_us_alone
         achieved = per[dom][0] / nlaunch / (kernel_us * 1e-6) / 1e9
         every = {n: {"avg_launch_us": round(per[n][1] / nlaunches[n], 3), "bytes_per_launch": int(per[n][0] / nlaunches[n]),
                      "algorithmic_GBs": round(per[n][0] / nlaunches[n] / (per[n][1] / nlaunches[n] * 1e-6) / 1e9, 1)} for n in per}
         batch_bytes = B * pair_bytes(W, H, npts)
         whole = batch_bytes / (med / K) / 1e9
-        roof = {"bound": "hbm", "kernel": {"pyramid": "pyr_roll2_kernel (two pyrDown levels per pass, register-rolling, alternating strip directions: L0->L1->L2 of 64 frames per launch, 2 launches per step)", "lk": "lk_kernel<21,1,3> (one wave per corner)",
+        roof = {"bound": "hbm", "kernel": {"pyramid": ("pyr_group_kernel (the two-level register-rolling pass, alternating strip directions: L0->L1->L2 of both frames of 64 pairs = 128 frames in ONE launch per step)" if PAIR_BUILD else "pyr_roll2_kernel (two pyrDown levels per pass, register-rolling, alternating strip directions: L0->L1->L2 of 64 frames per launch, 2 launches per step)"), "lk": "lk_kernel<21,1,3> (one wave per corner)",
                                            "pnp": "pnp_kernel<float,1>"}[dom],
                 "achieved": round(achieved, 3), "peak": B_.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / B_.HBM_PEAK_GBS, 6),
                 "traffic": B_.pmc_traffic({"pyramid": "pyr_roll2_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us_alone),
@@ -190,7 +197,7 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                "vs_baseline": None, "dtype": "u8/i64 (LK), f64 (PnP)", "data": "synthetic",
                "config": {"workload": wl["label"] % B, "pairs_per_step": B, "frames_resident": "%d batches x %d pairs x 2 frames in HBM (%.0f MiB), rotated"
                           % (NBATCH, B, NBATCH * B * 2 * W * H / 2**20),
-                          "launch": "stateless C-ABI calls, per batch in stream order: agt_pyramid_build x 2 (one two-level pass each), agt_lk_track, "
+                          "launch": "stateless C-ABI calls, per batch in stream order: %s, agt_lk_track, " % ("agt_pyramid_build_pair (one two-level pass over both frames of every pair)" if PAIR_BUILD else "agt_pyramid_build x 2 (one two-level pass each)") +
                                     "agt_solve_pnp (guess); consecutive batches round-robin over %d contexts / HIP streams (software pipelining across independent batches)" % NCTX,
                           "contexts": NCTX, "lk_waves_per_simd_cap": lk_occ},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",

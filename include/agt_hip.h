@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 501
+#define AGT_VERSION 502
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -135,6 +135,10 @@ int agt_pyr_down_u8(agt_ctx* ctx, const uint8_t* d_src, int sw, int sh, size_t s
  * is ordered behind every frame in flight; building a slot invalidates the tracker's own use of that entry
  * until the next agt_tracker_reset. */
 int agt_pyramid_build(agt_ctx* ctx, int slot, const uint8_t* d_frames, size_t pitch, size_t batch_stride, int B);
+/* Both slots of a frame pair in one call: slot 0 <- d_prev, slot 1 <- d_next (same pitch / batch stride), i.e. the two pyramids
+ * cv2.calcOpticalFlowPyrLK(prev, next, ...) builds internally -- levels 1 and 2 of all 2 B images by ONE launch of the
+ * two-level pass where it applies (ABI 502).  Same ownership and ordering rules as agt_pyramid_build. */
+int agt_pyramid_build_pair(agt_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_next, size_t pitch, size_t batch_stride, int B);
 /* Introspection (tests): device pointer and geometry of one level of a built slot. */
 int agt_pyramid_level(const agt_ctx* ctx, int slot, int level, const uint8_t** d_ptr,
                       int* w, int* h, size_t* pitch, size_t* batch_stride);

@@ -28,7 +28,7 @@ def cvh(torch_cuda):
 
 def test_library_loaded():
     from accurate_aprilgroup_tracking_amd import hiplib
-    assert hiplib.lib().agt_version() == 501
+    assert hiplib.lib().agt_version() == 502
 
 
 # (round 4: widths that are multiples of 16 on aligned buffers take the register-rolling kernel, agt_pyramid3_body.h -- every level
@@ -95,6 +95,37 @@ def test_pyramid_build_all_levels_bit_exact(torch_cuda, cvh, oracle, shape):
                 ref = oracle.pyrDown(ref)
                 got = ctx.pyramid_level(1, l)[b]
                 assert got.shape == ref.shape and np.array_equal(got, ref), "level %d, stream %d, pad %d" % (l, b, pad)
+
+
+@pytest.mark.parametrize("shape,B,levels", [((720, 1280), 9, 2), ((480, 640), 2, 4), ((270, 480), 11, 3), ((97, 131), 3, 2), ((150, 528), 8, 2),
+                                            ((96, 96), 1, 1), ((301, 1360), 5, 0)])
+def test_pyramid_build_pair_equals_two_builds(torch_cuda, cvh, oracle, shape, B, levels):
+    """agt_pyramid_build_pair (round 6, ABI 502): both slots of a frame pair in one call -- levels 1 and 2 of all 2 B images by ONE launch of
+    the two-level pass (rolling form for >= 16 images of suitable width and pitch, tiled form for small batches), deeper levels and the
+    cases the pass does not take by the single passes.  Every level of both slots against pyrDown applied level by level, and against
+    two agt_pyramid_build calls; then LK on the pair-built slots against the oracle."""
+    torch = torch_cuda
+    h, w = shape
+    rng = np.random.default_rng(h * 11 + w + B)
+    img = rng.integers(0, 256, size=(2, B, h, w), dtype=np.uint8)
+    wp = (w + 3) & ~3
+    d = torch.zeros((2, B, h, wp), dtype=torch.uint8, device="cuda")
+    d[:, :, :, :w] = torch.from_numpy(img).cuda()
+    ctx = cvh.Context(w, h, max_level=levels, max_points=8, max_streams=B)
+    ctx.pyramid_build_pair(d[0, :, :, :w], d[1, :, :, :w])
+    L = ctx.eff_max_level
+    got = [[ctx.pyramid_level(s_, l) for l in range(1, L + 1)] for s_ in (0, 1)]
+    for s_ in (0, 1):
+        for b in range(B):
+            ref = img[s_, b]
+            for l in range(1, L + 1):
+                ref = oracle.pyrDown(ref)
+                assert np.array_equal(got[s_][l - 1][b], ref), "slot %d, level %d, image %d" % (s_, l, b)
+    ctx2 = cvh.Context(w, h, max_level=levels, max_points=8, max_streams=B)
+    ctx2.pyramid_build(0, d[0, :, :, :w]); ctx2.pyramid_build(1, d[1, :, :, :w])
+    for s_ in (0, 1):
+        for l in range(1, L + 1):
+            assert np.array_equal(ctx2.pyramid_level(s_, l), got[s_][l - 1])
 
 
 @pytest.mark.parametrize("shape", [(480, 640), (720, 1280), (1080, 1920), (270, 480), (101, 240), (99, 464), (96, 96), (135, 96), (100, 4112),
