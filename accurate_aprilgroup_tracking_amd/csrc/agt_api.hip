@@ -26,7 +26,7 @@
 struct agt_ctx {
     agt_config cfg;
     AgtChip chip;                            // the device the context was created on (CU / XCD counts: launch rules and block orders)
-    int lk_lds_pad;                          // agt_lk_occupancy: extra LDS per one-wave LK workgroup (0 = no cap)
+    int lk_cap_cu;                           // agt_lk_occupancy_cu: resident one-wave LK workgroups per CU (0 = no cap, -1 = the library's choice)
     hipStream_t stream;
     int last_hip;
     int eff_max_level;                       // after OpenCV's early stop
@@ -398,7 +398,9 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     c->pipeline = agt_step_supported(cfg->win) ? 1 : 0;
     c->reproject = 0; c->min_points = 8; c->gate_px = 2.0;
     c->lk_max_count = 30; c->lk_eps = 0.01; c->lk_min_eig = 1e-4;
+    c->lk_cap_cu = -1;                        // (the library's choice: agt_lk_occupancy_cu)
 #ifdef AGT_DEBUG_KNOBS
+    { const char* e = getenv("AGT_LK_SPLIT_CU"); if (e) c->lk_cap_cu = atoi(e); }     // (residency cap of every one-wave LK launch of the context)
     { const char* e = getenv("AGT_LK_HYBRID"); if (e) c->lk_slow_thr = atoi(e); }
 #endif
 #ifdef AGT_DEBUG_KNOBS      // diagnostic library only: fixed iteration counts (AGT_LK_MAX_COUNT=n AGT_LK_EPS=0) separate the per-iteration
@@ -626,6 +628,8 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
     }
 }
 
+#define AGT_SPLIT_LK_CU 10       // (see agt_lk_occupancy_cu)
+static int lk_lds_min(int per_cu);
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
                        int n, int B, int crit_type, int crit_max_count, double crit_eps,
@@ -648,7 +652,8 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     double eps = (crit_type & AGT_TERM_EPS) ? (crit_eps < 0. ? 0. : crit_eps > 10. ? 10. : crit_eps) : 0.01;
     p.eps2 = eps * eps;
     p.flags = flags;
-    p.lds_pad = c->lk_lds_pad;
+    // (waves == 1: a half-batch launch of the split pipeline -- beside the other half's launch and the pyramid launch of the frames ahead)
+    p.lds_min = lk_lds_min(c->lk_cap_cu >= 0 ? c->lk_cap_cu : (waves == 1 ? AGT_SPLIT_LK_CU : 0));
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
     if (b0) {
@@ -880,26 +885,45 @@ int agt_tracker_options(agt_ctx* c, int reproject, int min_points, double gate_p
     return AGT_OK;
 }
 
-// Occupancy cap of the one-wave-per-corner LK kernel (big batches): at most `waves_per_simd` of its waves resident on a SIMD (0 = no
-// cap: as many as registers and LDS allow, 3-4).  For contexts that SHARE the device with other contexts' kernels: the tracker holds
-// 128 registers and ~9.5 KB of LDS per wave, three of them leave one wave slot of registers per SIMD to anybody else, and a launch
-// lasts as long as its slowest corner -- the HBM-bound pyramid passes of the other batches starve beside it.  The cap is enforced
-// with LDS: every workgroup (one wave) asks for LDS_per_CU / (4 * waves_per_simd) bytes.
+// Residency cap of the one-wave-per-corner LK kernel (big batches): at most `workgroups_per_cu` of its waves resident on a CU (0 = no
+// cap: as many as registers and LDS allow, 14-16; -1 = the library's choice, the default).  For launches that SHARE the device with
+// other kernels: a tracker wave holds 112 registers and ~7.5 KB of LDS, twelve of them on a CU leave one wave slot of registers per SIMD
+// to anybody else, and a launch lasts as long as its slowest corner -- the HBM-bound pyramid passes beside it starve.  The cap is
+// enforced with LDS: every workgroup (one wave) asks for at least LDS_per_CU / workgroups_per_cu bytes (more than its tiles need).
+// The library's choice: none for a launch of its own (agt_lk_track, the fused step); AGT_SPLIT_LK_CU for the half-batch launches of the
+// split pipeline, which run beside the pyramid launch of the frames ahead (round 6, 64 streams of 48 corners: 12 per CU -- all 3,072
+// corners resident, the LK launch alone 30.8 us -- step 39.5-40.2 us; 11: 39.1; 10: 38.4; 9: 38.7-39.5; 8: 40.1 -- with 10 the launch alone
+// takes 41 us, the step is the shortest; gpurun_out/r6s, profiles/r06_experiments.md).
+static int lk_lds_min(int per_cu)
+{
+    if (per_cu <= 0) return 0;
+    // gfx950: 160 KB of LDS per CU (MI355X_MICROARCH.md; hipDeviceProp_t reports the 64 KB a workgroup may ask for, not this).  The
+    // allocation granule is not documented: the size is a multiple of 1,280 B (so of 256 and 512 too) for which per_cu workgroups fit
+    // and per_cu + 1 do not, whether the hardware rounds to 512, 1,024 or 1,280 B (measured: 12,800 B -> 12 per CU, 13,824 B -> 11)
+    const long lds_cu = 160L * 1024;
+    auto up = [](long v, long g) { return (v + g - 1) / g * g; };
+    for (long v = lds_cu / per_cu / 1280 * 1280; v >= 1280; v -= 1280) {
+        bool ok = true;
+        for (long g : { 512L, 1024L, 1280L }) ok = ok && up(v, g) * per_cu <= lds_cu && up(v, g) * (per_cu + 1) > lds_cu;
+        if (ok) return (int)(v > 64L * 1024 ? 64L * 1024 : v);                        // (a workgroup may ask for 64 KB in all)
+    }
+    return 0;
+}
+
+int agt_lk_occupancy_cu(agt_ctx* c, int workgroups_per_cu)
+{
+    if (!c || workgroups_per_cu < -1 || workgroups_per_cu > 32) return AGT_ERR_ARG;
+    int rc = join_pipeline(c);
+    if (rc) return rc;
+    c->lk_cap_cu = workgroups_per_cu;
+    return AGT_OK;
+}
+
+// the same in waves per SIMD (round 5's entry point): 4 x waves_per_simd workgroups per CU, 0 = no cap
 int agt_lk_occupancy(agt_ctx* c, int waves_per_simd)
 {
     if (!c || waves_per_simd < 0 || waves_per_simd > 8) return AGT_ERR_ARG;
-    int rc = join_pipeline(c);
-    if (rc) return rc;
-    c->lk_lds_pad = 0;
-    if (waves_per_simd > 0) {
-        // gfx950: 160 KB of LDS per CU (MI355X_MICROARCH.md; hipDeviceProp_t reports the 64 KB a workgroup may ask for, not this)
-        const long lds_cu = 160L * 1024;
-        const long per_wave = (lds_cu / (4L * waves_per_simd)) & ~1023L;          // 1 KB below the exact share: allocation granularity
-        const long base = 10L * 1024;                                             // what a three-level corner needs anyway (9.5 KB)
-        c->lk_lds_pad = per_wave > base ? (int)(per_wave - base) : 0;
-        if (c->lk_lds_pad > 48 * 1024) c->lk_lds_pad = 48 * 1024;                 // (a workgroup may ask for 64 KB in all)
-    }
-    return AGT_OK;
+    return agt_lk_occupancy_cu(c, 4 * waves_per_simd);
 }
 
 int agt_tracker_tag_gate(agt_ctx* c, int corners_per_tag)
@@ -983,7 +1007,7 @@ static int fill_lk(const agt_ctx* c, AgtLkParams* p, int prev_slot, int next_slo
     p->flags = flags;
     p->min_eig_threshold = min_eig_threshold;
     p->prev_pts = d_prev; p->prev_status = d_prev_status; p->next_pts = d_next; p->status = d_status; p->err = d_err;
-    p->lds_pad = c->lk_lds_pad;
+    p->lds_min = lk_lds_min(c->lk_cap_cu > 0 ? c->lk_cap_cu : 0);
     return AGT_OK;
 }
 

@@ -58,7 +58,7 @@ struct AgtLkParams {
     uint8_t* status;          // [B][n]
     float* err;               // [B][n] or null
     int xshift;               // XCD-aware corner order (agt_xcd_order); set by the launchers
-    int lds_pad;              // host side only: extra dynamic LDS per one-wave workgroup = an occupancy cap (agt_lk_occupancy); 0 = none
+    int lds_min;              // host side only: least dynamic LDS a one-wave workgroup asks for = a residency cap (agt_lk_occupancy_cu); 0 = none
     // HYBRID launch of big batches (round 5, agt_lk.hip lk_hybrid_kernel): a corner that took >= slow_thr iterations (all levels) in the
     // PREVIOUS frame is tracked by FOUR waves (0.5 us per iteration, 5.8 us fixed), the others by one wave each (0.8 / 6.8 us) -- a
     // per-frame launch lasts as long as its slowest corner, and the corners that iterate long do so in every frame.  The two bodies

@@ -11,7 +11,12 @@ namespace {
 // a tag's four corners (and of neighbouring tags) overlap, and with consecutive corners on eight different XCDs each of those
 // L2s fetched the shared lines from HBM for itself (FETCH_SIZE 2.9x the algorithmic bytes at 64 streams).
 template <int WIN, int NW, int NLEV, int OCC>
-__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) void lk_kernel(const AgtLkParams P, const int total)
+#ifdef AGT_LK_NUM_VGPR       // experiment builds (tools/build_variant.sh): a register ceiling below the occupancy attribute's 128
+#define AGT_LK_VGPR_ATTR __attribute__((amdgpu_num_vgpr(AGT_LK_NUM_VGPR)))
+#else
+#define AGT_LK_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) AGT_LK_VGPR_ATTR void lk_kernel(const AgtLkParams P, const int total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     const int cidx = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, P.xshift);
@@ -113,7 +118,7 @@ hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p_in, int B)
     AgtLkParams p = p_in;
     p.xshift = agt_chip_current().xshift;
     size_t lds = agt_lk::lk_lds_bytes<WIN, NW>(p.max_level + 1);
-    if (NW == 1 && p.lds_pad > 0) lds += (size_t)p.lds_pad;          // agt_lk_occupancy: fewer resident LK waves per CU
+    if (NW == 1 && (size_t)p.lds_min > lds) lds = (size_t)p.lds_min;          // agt_lk_occupancy_cu: fewer resident LK waves per CU
 #ifdef AGT_DEBUG_KNOBS      // AGT_LK_LDS_PAD=bytes: extra LDS per workgroup = fewer LK waves per CU (room for other kernels' waves beside them)
     { static const long pad = [] { const char* e = getenv("AGT_LK_LDS_PAD"); return e ? atol(e) : 0L; }(); if (pad > 0 && NW == 1) lds += (size_t)pad; }
 #endif

@@ -489,7 +489,12 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
 }
 
 #ifndef AGT_STEP_NOLICM_TU
-__global__ __launch_bounds__(agt_pyr::NT) void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
+#ifdef AGT_PYRG_NUM_VGPR     // experiment builds: register ceiling of the split pipeline's pyramid launch
+#define AGT_PYRG_VGPR_ATTR __attribute__((amdgpu_num_vgpr(AGT_PYRG_NUM_VGPR)))
+#else
+#define AGT_PYRG_VGPR_ATTR
+#endif
+__global__ __launch_bounds__(agt_pyr::NT) AGT_PYRG_VGPR_ATTR void pyr_group_kernel(const AgtStepParams S, const AgtStepTables T)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
     pyr_role<true>(kernarg_params(), kernarg_tables(), blockIdx.x, 0, lds);
@@ -608,7 +613,7 @@ hipError_t launch_step_t(hipStream_t stream, const AgtStepParams& S, const AgtSt
         constexpr int OCCL = (WIN == 21 && NW == 1) ? AGT_LKG_OCC : 1;
         const long corners = (long)P.lk.n * P.lk_B;
         size_t per = small ? lk_role_lds<WIN, NW, 3>(P.lk.max_level + 1) : lk_role_lds<WIN, NW, AGT_MAX_LEVELS>(P.lk.max_level + 1);
-        if (NW == 1 && P.lk.lds_pad > 0) per += (size_t)P.lk.lds_pad;      // agt_lk_occupancy also caps the one-wave group launch (knobs build only: ADVICE r5)
+        if (NW == 1 && (size_t)P.lk.lds_min > per) per = (size_t)P.lk.lds_min;      // agt_lk_occupancy_cu also caps the one-wave group launch (knobs build only: ADVICE r5)
         const unsigned grid8 = agt_xcd_grid(corners, P.xshift);           // (XCD-aware corner order: lk_role; blocks past the last corner exit)
         if (small) hipLaunchKernelGGL((lk_group_kernel<WIN, NW, 3, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);
         else hipLaunchKernelGGL((lk_group_kernel<WIN, NW, AGT_MAX_LEVELS, OCCL>), dim3(grid8), dim3(AGT_WAVE * NW), per, stream, P, T);

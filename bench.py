@@ -247,8 +247,9 @@ class Bench:
         self.render_s = time.time() - t_r
         sq0 = self.seqs[0]
         self.trk = StreamTracker(W, H, sq0.obj, sq0.K, None, n_streams=B, max_level=LEVELS - 1, win=WIN, enhance_ape=True)
-        if getattr(args, "stream_lk_occupancy", 0):
-            self.trk.ctx.L.agt_lk_occupancy(self.trk.ctx.h, int(args.stream_lk_occupancy))
+        if getattr(args, "stream_lk_cu", -1) != -1:
+            from accurate_aprilgroup_tracking_amd import hiplib as _HL
+            _HL.check(self.trk.ctx.L.agt_lk_occupancy_cu(self.trk.ctx.h, int(args.stream_lk_cu)), "agt_lk_occupancy_cu")
         self._views = {}
         self.pos = 0            # ring index of the newest frame handed to the tracker
         self.clips = not args.per_step_calls
@@ -362,8 +363,8 @@ def main():
     ap.add_argument("--steps", type=int, default=400)
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
-    ap.add_argument("--stream-lk-occupancy", type=int, default=0, help="stream workloads (c2..c5): agt_lk_occupancy of the tracker's context (experiment; 0 = none)")
-    ap.add_argument("--lk-occupancy", type=int, default=2, help="c3pairs: cap of the LK kernel's resident waves per SIMD in every context (agt_lk_occupancy; 0 = none)")
+    ap.add_argument("--stream-lk-cu", type=int, default=-1, help="stream workloads (c2..c5): agt_lk_occupancy_cu of the tracker's context (experiment; -1 = the library's choice, 0 = none)")
+    ap.add_argument("--lk-cu", type=int, default=8, help="c3pairs: cap of the LK kernel's resident workgroups per CU in every context (agt_lk_occupancy_cu; 0 = none)")
     ap.add_argument("--no-pair-build", action="store_true", help="c3pairs: two agt_pyramid_build calls per batch (the form of rounds 3-5) instead of one agt_pyramid_build_pair")
     ap.add_argument("--pair-contexts", type=int, default=4, help="c3pairs: contexts / streams the independent batches are pipelined over (1 = serial)")
     ap.add_argument("--per-step-calls", action="store_true", help="hand the frames over one agt_track_frame call at a time instead of as clips")
@@ -618,10 +619,21 @@ def h2d_inclusive(torch, bench, K):
 def batch_extra(torch, D, HL, args, rank, dev):
     """BASELINE.json configs[2] side measurement: 64 independent 1280x720 streams per step."""
     a = argparse.Namespace(**vars(args))
+    # A block = one detector-refresh interval (REDETECT = 600 frames, 20 s of video at 30 fps): the tracker joins exactly where the application
+    # would -- before the corner set is refreshed -- and a join drains the pipeline (the pose role runs ~20 frames behind the LK role: 5 launches
+    # of 4 frames with nothing beside them, ~0.35 ms).  Rounds 2-5 timed blocks of 256 steps, which carry that drain 2.3 x as often as the
+    # workload does: 38.8-38.9 us per step against 37.3-37.4 on one box (gpurun_out/r6v); that figure stays on the line as `blocks_of_256`.
     a.steps, a.warmup, a.streams, a.render_frames = 256, 16, 64, min(args.render_frames, 8)
     wl = WORKLOADS["c3"]
     b = Bench(torch, wl, a, rank, 1, dev)
     b.trk.pipeline(16)                       # (the c3 workload's default group size)
+    dts256, _, _, st256, _ = b.timed_blocks(D, 15)
+    med256, p10_256, _ = percentiles(dts256)
+    ok256 = float(st256[:, :, HL.ST_OK].mean())
+    del b
+    a.steps = REDETECT
+    b = Bench(torch, wl, a, rank, 1, dev)
+    b.trk.pipeline(16)
     dts, st_w, st_f, st, _ = b.timed_blocks(D, 15)
     med, p10, p90 = percentiles(dts)
     spans = b.stage_spans_us(HL, 40)
@@ -648,6 +660,9 @@ def batch_extra(torch, D, HL, args, rank, dev):
             "pyr_down_algorithmic_GBs": round(pyr_gbs, 1), "pyr_down_frac_of_8TBs": round(pyr_gbs / HBM_PEAK_GBS, 4),
             "pyr_down_bytes_note": "W*H*1.3125 per frame (SURVEY 8d); on the bytes of two single-level passes (level 1 read again: rounds 3-4) that would be %.1f GB/s = %.4f of 8 TB/s"
                                    % (pyr2_gbs, pyr2_gbs / HBM_PEAK_GBS),
+            "steps_per_block": a.steps, "blocks": 15,
+            "blocks_of_256": {"ms_per_step": round(med256 / 256 * 1e3, 4), "ms_per_step_p10": round(p10_256 / 256 * 1e3, 4),
+                              "whole_step_frac_of_8TBs": round(step_bytes / (med256 / 256) / 1e9 / HBM_PEAK_GBS, 4), "accepted_frac": round(ok256, 4)},
             "accepted_frac": round(ok, 4), "pose_err_vs_cpu": pose_err, "copies_bitwise_equal_to_their_seed_stream": bool(copies_ok)}
 
 

@@ -69,11 +69,11 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         with torch.cuda.stream(s_):
             ctxs.append(cv_hip.Context(W, H, max_level=B_.LEVELS - 1, win=B_.WIN, max_points=npts, max_streams=B))     # bound to s_
     L = ctxs[0].L
-    # every context shares the device with the other contexts' pyramid passes: cap the tracker at two waves per SIMD (agt_hip.h
-    # agt_lk_occupancy; --lk-occupancy 0 = uncapped, the form of rounds 3-4)
-    lk_occ = int(getattr(args, "lk_occupancy", 2)) if NCTX > 1 else 0
+    # every context shares the device with the other contexts' pyramid passes: cap the tracker's resident workgroups per CU (agt_hip.h
+    # agt_lk_occupancy_cu; --lk-cu 0 = uncapped, the form of rounds 3-4)
+    lk_occ = int(getattr(args, "lk_cu", 8)) if NCTX > 1 else 0
     for c_ in ctxs:
-        HL.check(L.agt_lk_occupancy(c_.h, lk_occ), "agt_lk_occupancy")
+        HL.check(L.agt_lk_occupancy_cu(c_.h, lk_occ), "agt_lk_occupancy_cu")
     nxs = [torch.zeros((B, npts, 2), dtype=torch.float32, device=dev) for _ in range(NCTX)]
     sts = [torch.zeros((B, npts), dtype=torch.uint8, device=dev) for _ in range(NCTX)]
     pose = torch.zeros((K, B, 6), dtype=torch.float64, device=dev)           # one record per step (the gathered poses)
@@ -199,7 +199,7 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
                           % (NBATCH, B, NBATCH * B * 2 * W * H / 2**20),
                           "launch": "stateless C-ABI calls, per batch in stream order: %s, agt_lk_track, " % ("agt_pyramid_build_pair (one two-level pass over both frames of every pair)" if PAIR_BUILD else "agt_pyramid_build x 2 (one two-level pass each)") +
                                     "agt_solve_pnp (guess); consecutive batches round-robin over %d contexts / HIP streams (software pipelining across independent batches)" % NCTX,
-                          "contexts": NCTX, "lk_waves_per_simd_cap": lk_occ},
+                          "contexts": NCTX, "lk_workgroups_per_cu_cap": lk_occ},
                "timing": {"blocks": len(dts), "steps_per_block": K, "statistic": "median block, max over ranks per block",
                           "ms_per_step_p10": round(p10 / K * 1e3, 5), "ms_per_step_p90": round(p90 / K * 1e3, 5)},
                "roofline": roof, "cpu_baseline": cpu, "max_abs_pose_err_vs_truth": float(err), "tracked_frac": round(tracked, 4),

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 502
+#define AGT_VERSION 503
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -202,12 +202,15 @@ int agt_tracker_reset(agt_ctx* ctx, int slot, const float* d_corners, const floa
  * min_points: corners needed to attempt a pose (default 8 = the reference's >= 2 tags, detect_pose.py:494-496).
  * gate_px: reprojection gate (default 2.0, detect_pose.py:539). */
 int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate_px);
-/* Occupancy cap of the big-batch LK kernel (one wave per corner, > 1024 corners per launch): at most waves_per_simd of its waves
- * resident per SIMD; 0 (default) = no cap.  For contexts that share the device with other contexts' kernels (several batches
- * software-pipelined over contexts / streams, bench.py --workload c3pairs): an uncapped launch fills every SIMD with three
- * trackers for as long as its slowest corner iterates and the HBM-bound pyramid passes of the other batches starve beside it;
- * capped at 2 the cold-pair step of BASELINE configs[2] runs 48.4 -> 45.3 us while the LK launch alone takes 45 instead of 36 us.
- * Results do not depend on it.  No reference counterpart (cv2 has no notion of co-tenancy). */
+/* Residency cap of the big-batch LK kernel (one wave per corner, > 1024 corners per launch): at most workgroups_per_cu of its waves
+ * resident per CU (four SIMDs); 0 = no cap; -1 (default) = the library's choice: none for a launch of its own (agt_lk_track), 10 for
+ * the half-batch launches of the multi-stream tracker, which run beside the pyramid launch of the frames ahead.  For launches that
+ * share the device with other kernels (several batches software-pipelined over contexts / streams, bench.py --workload c3pairs): an
+ * uncapped launch fills every SIMD with three trackers for as long as its slowest corner iterates and the HBM-bound pyramid passes
+ * beside it starve; capped at 8 the cold-pair step of BASELINE configs[2] ran 48.4 -> 45.3 us (round 5) while the LK launch alone
+ * takes 45 instead of 36 us.  Results do not depend on it.  No reference counterpart (cv2 has no notion of co-tenancy).
+ * agt_lk_occupancy: the same in waves per SIMD (4 x waves_per_simd per CU; ABI 500). */
+int agt_lk_occupancy_cu(agt_ctx* ctx, int workgroups_per_cu);
 int agt_lk_occupancy(agt_ctx* ctx, int waves_per_simd);
 /* corners_per_tag = 4: the pose solve of the tracker uses a corner only while all four corners of its tag (corners 4t..4t+3)
  * are usable, and min_points = 8 then means the reference's ">= 2 tags" (detect_pose.py:494-496; its detections are whole

@@ -28,7 +28,7 @@ def cvh(torch_cuda):
 
 def test_library_loaded():
     from accurate_aprilgroup_tracking_amd import hiplib
-    assert hiplib.lib().agt_version() == 502
+    assert hiplib.lib().agt_version() == 503
 
 
 # (round 4: widths that are multiples of 16 on aligned buffers take the register-rolling kernel, agt_pyramid3_body.h -- every level
@@ -353,7 +353,14 @@ def test_lk_occupancy_cap_changes_no_bit(torch_cuda, cvh, oracle, seq640):
             ref = got
         else:
             assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(ref, got)), "cap %d" % cap
+    # round 6 (ABI 503): the cap in workgroups per CU -- what the multi-stream tracker sets for its own half-batch launches (10); -1 = the library's choice
+    for cap in (10, 5, 13, 1, -1):
+        H.check(ctx.L.agt_lk_occupancy_cu(ctx.h, cap), "agt_lk_occupancy_cu")
+        nx, st, er = ctx.lk_track(0, 1, pg, None)
+        got = (nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy())
+        assert all(np.array_equal(x.view(np.uint8), y.view(np.uint8)) for x, y in zip(ref, got)), "cap %d per CU" % cap
     assert ctx.L.agt_lk_occupancy(ctx.h, -1) == -1 and ctx.L.agt_lk_occupancy(ctx.h, 9) == -1
+    assert ctx.L.agt_lk_occupancy_cu(ctx.h, -2) == -1 and ctx.L.agt_lk_occupancy_cu(ctx.h, 33) == -1
 
 
 def test_project_points(cvh, oracle, seq640_dist):

@@ -3,14 +3,18 @@
 (static counts) and every innermost loop (a backward branch whose body contains no other backward branch target), classified.
 VERDICT r2 #2: the instruction-mix table of lk_kernel<21,1,3,4>.
 
-    python tools/isa_mix.py 'lk_kernel<21, 1, 3, 4>' [libagt_hip.so] > profiles/r03_lk_iteration_isa.md
+    python tools/isa_mix.py 'lk_kernel<21, 1, 3, 4>' [libagt_hip.so | kernel.s] [--path A-B,C-D,...] > profiles/r03_lk_iteration_isa.md
+
+kernel.s: a listing written by tools/isa_dump.py (an object that is no longer built).  --path: address ranges (hex, inclusive) of the
+instructions ONE trip of a loop executes on its common path -- the innermost-loop tables count every instruction between a backward
+branch and its target, rare paths included; the path table counts what a trip issues.
 """
 import os, re, subprocess, sys, tempfile
 LLVM = "/opt/rocm/lib/llvm/bin"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 CLASSES = [
-    ("dot4 (bilinear taps)", r"^v_dot4"), ("perm / alignbyte (byte packing)", r"^v_(perm_b32|alignbyte|alignbit)"),
+    ("dot4 / dot2 (bilinear taps)", r"^v_dot[24]"), ("perm / alignbyte (byte packing)", r"^v_(perm_b32|alignbyte|alignbit)"),
     ("DPP / lane swaps (reductions)", r"(_dpp|^v_permlane|^v_mov_b32_dpp)"), ("readlane / readfirstlane", r"^v_read(first)?lane"),
     ("integer multiply / mad", r"^v_(mul_i32_i24|mul_u32_u24|mad_i32_i24|mad_u32_u24|mul_lo|mul_hi|mad_u64|mad_i64)"),
     ("float (weights, 2x2 solve, tests)", r"^v_(pk_)?(add|sub|mul|fma|fmac|mac|rndne|floor|cvt|cmp|rcp|rsq|sqrt|max|min|cndmask|trunc|fract|div).*(f32|f64)|^v_cvt_|^v_rndne|^v_floor"),
@@ -43,9 +47,21 @@ def code_objects(lib, tmp):
             yield co
 
 
+PATH = []
+
+
 def main():
-    want = sys.argv[1]
-    lib = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "accurate_aprilgroup_tracking_amd", "libagt_hip.so")
+    args = sys.argv[1:]
+    if "--path" in args:
+        k = args.index("--path")
+        for r in args[k + 1].split(","):
+            a, b = r.split("-"); PATH.append((int(a, 16), int(b, 16)))
+        del args[k:k + 2]
+    want = args[0]
+    lib = args[1] if len(args) > 1 else os.path.join(ROOT, "accurate_aprilgroup_tracking_amd", "libagt_hip.so")
+    if lib.endswith(".s"):
+        report(want, lib, open(lib).read().splitlines()[1:])
+        return
     with tempfile.TemporaryDirectory() as tmp:
         for co in code_objects(lib, tmp):
             dis = subprocess.run([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", co], capture_output=True, text=True).stdout
@@ -80,7 +96,7 @@ def report(name, lib, body):
                 loops.append((addr_index[tgt], k))
     def is_iter(a, b):
         ops = [o for _, o, _ in ins[a:b + 1]]
-        return any(o.startswith("v_dot4") or o.startswith("v_mul_i32_i24") or o.startswith("v_mad_i32_i24") for o in ops) and \
+        return any(o.startswith("v_dot4") or o.startswith("v_dot2") or o.startswith("v_mul_i32_i24") or o.startswith("v_mad_i32_i24") for o in ops) and \
             any("permlane32_swap" in o for o in ops) and any(o.startswith("ds_read") for o in ops)
     cand = sorted(set((a, b) for (a, b) in loops if is_iter(a, b)))
     inner = [(a, b) for (a, b) in cand if not any((c, d) != (a, b) and c >= a and d <= b for (c, d) in cand)]
@@ -101,6 +117,9 @@ def report(name, lib, body):
                 print("| %s | %d |" % (c, cnt[c]))
         print()
     table(ins, "whole kernel")
+    if PATH:
+        sel = [i for i in ins if any(a <= i[0] <= b for a, b in PATH)]
+        table(sel, "one trip of the iteration loop, common path (%s)" % ", ".join("0x%x..0x%x" % r for r in PATH))
     for n, (a, b) in enumerate(sorted(inner)):
         table(ins[a:b + 1], "LK iteration loop %d (0x%x..0x%x)" % (n, ins[a][0], ins[b][0]))
 

@@ -34,3 +34,5 @@ for rep in range(3):
     for lo, hi in ((0, 8), (8, 12), (12, 16), (16, 24), (24, 200)):
         m = (it >= lo) & (it < hi)
         if m.any(): print("      %3d..%3d iterations: %4d corners, life median %.1f max %.1f" % (lo, hi - 1, m.sum(), np.median(life[m]), life[m].max()))
+    h, edges = np.histogram(life, bins=np.arange(0, life.max() + 2, 2.0))
+    print("   life histogram (2-us bins from 0):", " ".join(str(int(v)) for v in h))
