@@ -180,7 +180,7 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
         roof = {"bound": "hbm", "kernel": {"pyramid": ("pyr_group_kernel (the two-level register-rolling pass, alternating strip directions: L0->L1->L2 of both frames of 64 pairs = 128 frames in ONE launch per step)" if PAIR_BUILD else "pyr_roll2_kernel (two pyrDown levels per pass, register-rolling, alternating strip directions: L0->L1->L2 of 64 frames per launch, 2 launches per step)"), "lk": "lk_kernel<21,1,3> (one wave per corner)",
                                            "pnp": "pnp_kernel<float,1>"}[dom],
                 "achieved": round(achieved, 3), "peak": B_.HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / B_.HBM_PEAK_GBS, 6),
-                "traffic": B_.pmc_traffic({"pyramid": "pyr_roll2_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us_alone),
+                "traffic": B_.pmc_traffic({"pyramid": "pyr_group_kernel c3pairs (pair build)" if PAIR_BUILD else "pyr_roll2_kernel c3pairs", "lk": "lk_kernel<21,1,3> c3pairs", "pnp": "pnp_kernel c3pairs"}[dom], kernel_us_alone),
                 "avg_launch_us": round(kernel_us, 3), "bytes_per_launch": int(per[dom][0] / nlaunch),
                 "measured": ("pipelined pass (the form that is timed: %d contexts round-robin, HIP events on each context's stream around the call)" % NCTX) if pipe_us else "serial pass (one context)",
                 "alone": {"avg_launch_us": round(kernel_us_alone, 3), "achieved": round(achieved_alone, 3), "frac": round(achieved_alone / B_.HBM_PEAK_GBS, 6),

@@ -132,6 +132,8 @@ def raw_entry(run, prefix, name, label, alg=None):
 raw_entry("c5", "dense_accum_kernel", "dense_accum_kernel", "c5: 61,440 samples + 240 corners, one Gauss-Newton launch (update prologue + accumulate)", 61440 * 28)
 raw_entry("c3pairs", "pyr_roll2_kernel", "pyr_roll2_kernel c3pairs", "c3pairs: two pyrDown levels per pass (register-rolling, alternating strip directions) over 64 cold 720p frames, "
           "one launch per pyramid build; algorithmic bytes = 64 x W*H*1.3125 (SURVEY 8d: level 0 read once, levels 1 and 2 written once)", int(64 * 1280 * 720 * 1.3125))
+raw_entry("c3pairs", "pyr_group_kernel", "pyr_group_kernel c3pairs (pair build)", "c3pairs, round 6 (agt_pyramid_build_pair): the two-level rolling pass over BOTH frames of 64 cold 720p pairs = 128 frames "
+          "in one launch; algorithmic bytes = 128 x W*H*1.3125 (SURVEY 8d)", int(128 * 1280 * 720 * 1.3125))
 raw_entry("c3pairs", "lk_kernel<21, 1, 3", "lk_kernel<21,1,3> c3pairs", "c3pairs: 3072 corners, one wave per corner", 64 * (48 * 3 * 1600 + 48 * 21))
 json.dump(traffic, open(tp, "w"), indent=1)
 print(json.dumps({r: {k: v for k, v in d["kernels"].items()} for r, d in durations.items()}, indent=1)[:6000])
