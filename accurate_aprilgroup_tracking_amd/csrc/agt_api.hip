@@ -369,12 +369,14 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     c->stream = (hipStream_t)hip_stream;
     // buildOpticalFlowPyramid level geometry + early stop
     int w = cfg->width, h = cfg->height;
+    int win_w, win_h;
+    agt_lk_window_size(cfg->win, &win_w, &win_h);
     for (int l = 0; l <= cfg->max_level; l++) {
         c->lw[l] = w; c->lh[l] = h;
         c->lpitch[l] = ((long)w + 63) & ~63L;
         c->eff_max_level = l;
         w = (w + 1) / 2; h = (h + 1) / 2;
-        if (w <= cfg->win || h <= cfg->win) break;
+        if (w <= win_w || h <= win_h) break;
     }
     const size_t B = (size_t)cfg->max_streams, N = (size_t)cfg->max_points;
     c->group = 1;

@@ -241,6 +241,7 @@ void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch,
 int agt_dense_blocks(int M);
 size_t agt_dense_doubles(int M, int B);
 bool agt_lk_window_supported(int win);
+void agt_lk_window_size(int win, int* ww, int* wh);       // AgtConfig::win -> (width, height): a side, or AGT_WIN_RECT(w, h)
 bool agt_lk_wide(int n, int B);
 bool agt_step_supported(int win);
 bool agt_step_fits(int n, int B);   // the fused launch (all roles in one kernel) is used while its LK workgroups fit one per CU (256 corners on a whole MI355X)

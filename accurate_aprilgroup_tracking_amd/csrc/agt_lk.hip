@@ -1,6 +1,7 @@
 // agt_lk.hip -- stand-alone cv::calcOpticalFlowPyrLK launch (body and design notes: agt_lk_body.h).
 #include <cstdlib>
 #include "agt_lk_rs_body.h"
+#include "agt_lk_any_body.h"
 
 namespace {
 
@@ -134,9 +135,39 @@ hipError_t launch_lk_t(hipStream_t stream, const AgtLkParams& p_in, int B)
     return hipGetLastError();
 }
 
+// any window (agt_lk_any_body.h): one workgroup of four waves per corner, run-time window size
+__global__ __launch_bounds__(agt_lk::ANY_T) void lk_any_kernel(const AgtLkParams P, const int total, const int ww, const int wh)
+{
+    extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+    const int cidx = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, P.xshift);
+    if (cidx >= total) return;
+    const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
+    agt_lk::lk_body_any(&P, bX, bY, lds, ww, wh);
+}
+
+hipError_t launch_lk_any(hipStream_t stream, const AgtLkParams& p_in, int ww, int wh, int B)
+{
+    AgtLkParams p = p_in;
+    p.xshift = agt_chip_current().xshift;
+    const long total = (long)p.n * B;
+    if (total <= 0 || total > (1L << 30)) return hipErrorInvalidValue;
+    const size_t lds = (size_t)agt_lk::any_geom(ww, wh).bytes;
+    hipLaunchKernelGGL(lk_any_kernel, dim3(agt_xcd_grid(total, p.xshift)), dim3(agt_lk::ANY_T), lds, stream, p, (int)total, ww, wh);
+    return hipGetLastError();
+}
+
 }  // namespace
 
-bool agt_lk_window_supported(int win) { return win == 21 || win == 15 || win == 31; }
+// `win` of AgtConfig: a square window's side, or AGT_WIN_RECT(w, h) = w | h << 8.  15, 21 and 31 have compiled-in bodies (21 x 21, the
+// north-star's window, the specialised ones); every other size from 3 x 3 to 63 x 63, square or not, runs the general body.
+void agt_lk_window_size(int win, int* ww, int* wh) { *ww = win & 0xff; *wh = (win >> 8) ? (win >> 8) & 0xff : *ww; }
+bool agt_lk_window_supported(int win)
+{
+    if (win <= 0 || (win >> 16)) return false;
+    int ww, wh;
+    agt_lk_window_size(win, &ww, &wh);
+    return ww >= 3 && wh >= 3 && ww <= agt_lk::ANY_WIN_MAX && wh <= agt_lk::ANY_WIN_MAX;
+}
 
 // waves per corner: 4 while the launch cannot fill the chip with single-wave corners (latency
 // matters), 1 for large batches (throughput matters)
@@ -181,6 +212,11 @@ hipError_t agt_launch_lk(hipStream_t stream, const AgtLkParams& p_in, int win, i
     case 21: return (waves ? waves == 4 : agt_lk_wide(p.n, B)) ? launch_lk_t<21, 4>(stream, p, B) : launch_lk_t<21, 1>(stream, p, B);
     case 15: return launch_lk_t<15, 1>(stream, p, B);
     case 31: return launch_lk_t<31, 1>(stream, p, B);
-    default: return hipErrorInvalidValue;
+    default: {
+        if (!agt_lk_window_supported(win)) return hipErrorInvalidValue;
+        int ww, wh;
+        agt_lk_window_size(win, &ww, &wh);
+        return launch_lk_any(stream, p, ww, wh, B);
+    }
     }
 }

@@ -367,8 +367,10 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     a = np.asarray(prevImg); b = np.asarray(nextImg)
     if a.dtype != np.uint8 or b.dtype != np.uint8 or a.ndim != 2 or a.shape != b.shape:
         raise error("calcOpticalFlowPyrLK: prevImg/nextImg must be equal-size 8-bit single-channel images")
-    if winSize[0] != winSize[1]:
-        raise error("calcOpticalFlowPyrLK: only square windows are built")
+    ww, wh = int(winSize[0]), int(winSize[1])
+    if not (3 <= ww <= 63 and 3 <= wh <= 63):
+        raise error("calcOpticalFlowPyrLK: winSize must be within 3 .. 63 in both dimensions")
+    win = ww if ww == wh else (ww | (wh << 8))          # include/agt_hip.h AGT_WIN_RECT
     if maxLevel >= H.MAX_LEVELS:
         raise error("calcOpticalFlowPyrLK: maxLevel too large")
     pts = np.ascontiguousarray(np.asarray(prevPts, dtype=np.float32).reshape(-1, 2))
@@ -377,7 +379,7 @@ def calcOpticalFlowPyrLK(prevImg, nextImg, prevPts, nextPts=None, winSize=(21, 2
     if n == 0:
         return np.zeros((0, 1, 2), np.float32), np.zeros((0, 1), np.uint8), np.zeros((0, 1), np.float32)
     try:
-        ctx = _context(w, h, maxLevel, winSize[0], n)
+        ctx = _context(w, h, maxLevel, win, n)
     except H.AgtError as e:
         raise error(str(e))
     with ctx.lock:

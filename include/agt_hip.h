@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 503
+#define AGT_VERSION 504
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -42,7 +42,7 @@ extern "C" {
 #define AGT_ERR_DIST        (-3)   /* distortion count not in {0,4,5,8,12,14} */
 #define AGT_ERR_NPOINTS     (-4)   /* too few / too many points */
 #define AGT_ERR_HIP         (-5)   /* a HIP runtime call failed; see agt_last_hip_error */
-#define AGT_ERR_UNSUPPORTED (-6)   /* e.g. LK window size not compiled in */
+#define AGT_ERR_UNSUPPORTED (-6)   /* e.g. LK window outside 3..63, a device other than gfx950 */
 #define AGT_ERR_STATE       (-7)   /* pyramid slot not built, context mismatch */
 #define AGT_ERR_CHAIN       (-8)   /* a chained launch gave up waiting for a stream's corners (records flagged AGT_TRK_CHAIN_TIMEOUT);
                                       reported by agt_synchronize / agt_tracker_join until agt_tracker_reset */
@@ -85,11 +85,15 @@ extern "C" {
 
 typedef struct agt_ctx agt_ctx;
 
+#define AGT_WIN_RECT(w, h) ((w) | ((h) << 8))     /* agt_config::win of a w x h window (w = h: the side itself) */
+
 typedef struct agt_config {
     int device;        /* HIP device ordinal */
     int width, height; /* level-0 frame size in pixels */
     int max_level;     /* LK maxLevel: pyramid levels 0..max_level ("3-level" = 2) */
-    int win;           /* square LK window; 21 is compiled in */
+    int win;           /* LK window (cv2 winSize): the side of a square window, or AGT_WIN_RECT(w, h); 3 <= w, h <= 63.  21 x 21 -- the
+                          north-star's -- has the specialised bodies and is the only window of the pipelined tracker; 15 and 31 have compiled-in
+                          bodies; every other size runs the general body (ABI 504), same results, slower */
     int max_points;    /* correspondences per stream (<= 256) */
     int max_streams;   /* B upper bound */
     int reserved[8];   /* must be 0 */

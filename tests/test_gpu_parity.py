@@ -28,7 +28,7 @@ def cvh(torch_cuda):
 
 def test_library_loaded():
     from accurate_aprilgroup_tracking_amd import hiplib
-    assert hiplib.lib().agt_version() == 503
+    assert hiplib.lib().agt_version() == 504
 
 
 # (round 4: widths that are multiples of 16 on aligned buffers take the register-rolling kernel, agt_pyramid3_body.h -- every level
@@ -268,6 +268,41 @@ def test_lk_random_texture_other_sizes(cvh, oracle):
         good = o[1].ravel() == 1
         d = (o[0].reshape(-1, 2) - pts)[good]
         assert np.abs(np.median(d, axis=0) - np.array([-2.1, 1.3])).max() < 0.1
+
+
+@pytest.mark.parametrize("win", [(3, 3), (5, 5), (9, 9), (4, 6), (11, 7), (7, 11), (13, 13), (17, 25), (23, 23), (33, 33), (45, 31), (63, 63), (21, 9)])
+def test_lk_any_window_size_bit_exact(cvh, oracle, seq640, win):
+    """VERDICT r5 missing #4: cv2.calcOpticalFlowPyrLK takes ANY winSize; the library had 15 / 21 / 31 compiled in and refused the rest.
+    Round 6 (ABI 504): every window from 3 x 3 to 63 x 63, square or not, even or odd, through the general body (agt_lk_any_body.h: run-time
+    window, one workgroup per corner, one level at a time): nextPts / status / err bit-identical to the oracle -- corners of the scene,
+    points at / beyond every border, random points; maxLevel 0 .. 3 (the pyramid stops early where a level is no larger than the window),
+    initial flow, minimum-eigenvalue errors, iteration-count-only and epsilon-only criteria, a high eigenvalue threshold."""
+    a, b = seq640.frame(0), seq640.frame(2)
+    h, w = a.shape
+    rng = np.random.default_rng(win[0] * 64 + win[1])
+    pts = np.concatenate([
+        seq640.corners(0)[:24],
+        np.array([[0.0, 0.0], [w - 1.0, h - 1.0], [-5.5, 10.25], [w + 3.0, 7.0], [3.2, h + 8.9], [-70.0, -70.0],
+                  [w + 70.0, h + 70.0], [10.5, 10.5], [w - 11.0, h - 11.0], [1.0, h / 2.0]], np.float32),
+        rng.uniform([-20, -20], [w + 20, h + 20], size=(30, 2)).astype(np.float32)])
+    for ml in (0, 1, 2, 3):
+        o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=ml, winSize=win)
+        _assert_lk_equal(o, g)
+    init = pts + rng.normal(0, 1.5, pts.shape).astype(np.float32)
+    for kw in (dict(flags=4, nextPts=init), dict(flags=8), dict(criteria=(1, 5, 0.0)), dict(criteria=(2, 0, 0.03)), dict(minEigThreshold=1e-2)):
+        o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2, winSize=win, **kw)
+        _assert_lk_equal(o, g)
+    if win[0] >= 9 and win[1] >= 9:
+        o, _ = _lk_both(cvh, oracle, a, b, seq640.corners(0), maxLevel=2, winSize=win)
+        assert o[1].sum() >= 40, "the scene's corners are trackable with this window"
+
+
+def test_lk_window_out_of_range_is_refused(cvh):
+    a = np.zeros((64, 64), np.uint8)
+    p = np.array([[10.0, 10.0]], np.float32)
+    for win in ((2, 5), (5, 2), (64, 21), (21, 64), (0, 0)):
+        with pytest.raises(cvh.error):
+            cvh.calcOpticalFlowPyrLK(a, a, p, None, winSize=win)
 
 
 def test_lk_large_batch_single_wave_path(torch_cuda, cvh, oracle, seq640):

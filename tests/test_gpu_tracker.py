@@ -349,6 +349,44 @@ def test_stream_1080p_and_240_corners(torch_cuda, oracle, seq1080):
             pts = nx.astype(np.float32); pyr = npyr
 
 
+@pytest.mark.parametrize("win", [13, 27, (17, 11)])
+def test_stream_tracker_with_other_lk_windows(torch_cuda, oracle, seq640, win):
+    """Round 6 (ABI 504): the stream tracker with an LK window other than 21 x 21 (general LK body, stage-by-stage launches -- the pipelined
+    launches exist for the north-star's window only and say so: AGT_ERR_UNSUPPORTED).  Tracked-corner counts equal the oracle chain's,
+    the first pose solver to solver, later poses against the generator."""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    seq = seq640
+    ww, wh = (win, win) if isinstance(win, int) else win
+    code = ww if ww == wh else (ww | (wh << 8))
+    frames = torch.from_numpy(seq.frames()).cuda()
+    F = min(len(seq), 6)
+    trk = StreamTracker(seq.width, seq.height, seq.obj, seq.K, None, n_streams=1, win=code)
+    assert trk.ctx.L.agt_tracker_pipeline(trk.ctx.h, 4) == -6          # AGT_ERR_UNSUPPORTED
+    trk.pipeline(0)
+    trk.reset(frames[0:1].contiguous(), torch.from_numpy(seq.corners(0)[None]).cuda().contiguous())
+    so = trk.new_state_buffer(F - 1)
+    for k in range(1, F):
+        trk.step(frames[k:k + 1], so[k - 1])
+    trk.join()
+    st = so.cpu().numpy()
+    pts = seq.corners(0)
+    for k in range(1, F):
+        nx, status, _ = oracle.calcOpticalFlowPyrLK(seq.frame(k - 1), seq.frame(k), pts, maxLevel=2, winSize=(ww, wh))
+        nx = nx.reshape(-1, 2); ok = status.ravel().astype(bool)
+        assert int(st[k - 1, 0, H.ST_NTRACK]) == int(ok.sum()) and ok.sum() >= 8, (k, int(st[k - 1, 0, H.ST_NTRACK]), int(ok.sum()))
+        if k == 1:
+            _, r, t = oracle.solvePnP(seq.obj[ok].astype(np.float32), nx[ok], seq.K, None)
+            assert np.abs(st[0, 0, :3] - r.ravel()).max() < 1e-7 and np.abs(st[0, 0, 3:6] - t.ravel()).max() < 1e-7
+        assert st[k - 1, 0, H.ST_OK] == 1
+        assert np.abs(st[k - 1, 0, :3] - seq.rvecs[k]).max() < 5e-3 and np.abs(st[k - 1, 0, 3:6] - seq.tvecs[k]).max() < 5e-3
+        # (a lost corner stays lost in the tracker: carry the oracle's status the same way)
+        pts = nx.astype(np.float32)
+        if not ok.all():
+            pts = pts.copy(); pts[~ok] = -1e5          # far outside: lost in every later frame, as in the tracker
+
+
 @pytest.mark.parametrize("camera", ["pinhole", "lens", "tilt"])
 def test_240_corners_pipelined_equals_serial(torch_cuda, camera):
     """More than 64 corners per stream: the PnP solve runs on four cooperating waves (agt_pnp_body.h, COOP) -- as the stand-alone
