@@ -3,7 +3,9 @@
 // count and register array at compile time; this body is the same algorithm with run-time sizes: one workgroup of four waves per corner,
 // one pyramid level at a time, the I patch (value and both derivatives of every window pixel) kept in LDS instead of registers, plain
 // strided loops over tiles and window.  It is the GENERAL path, not a tuned one: bit-identical results (oracle: oracle/cv_lk.c with
-// win_w / win_h), a third to a half of the specialised bodies' speed.  Reference call shape: cv.calcOpticalFlowPyrLK(prev, next, pts, None,
+// win_w / win_h); measured against the compiled-in bodies on the same windows (tools/lkanybench.py, 1280x720, 48 corners per stream): one stream
+// 36 against 18 us (21 x 21), 32 against 21 (15), 41 against 41 (31); 64 streams 151 against 28 us, 134 against 30, 191 against 89 -- four waves
+// per corner cost a big batch its throughput.  Reference call shape: cv.calcOpticalFlowPyrLK(prev, next, pts, None,
 // winSize=(w, h), ...) -- the reference has no call site (the hole at detect_pose.py:573-574); OpenCV: lkpyramid.cpp LKTrackerInvoker.
 #pragma once
 #include "agt_lk_body.h"

@@ -34,6 +34,13 @@ using agt_pyr3::v4u;
 using agt_pyr3::roll_reflect_row;
 
 constexpr int TILE_GROUPS = 14;     // interior groups per column tile
+// cache-policy bits of the pass's buffer loads / stores (aux operand: 1 = sc0, 2 = nt, 16 = sc1): experiment builds only
+#ifndef AGT_PYR4_LOAD_AUX
+#define AGT_PYR4_LOAD_AUX 0
+#endif
+#ifndef AGT_PYR4_STORE_AUX
+#define AGT_PYR4_STORE_AUX 0
+#endif
 #ifndef AGT_PYR4_RING
 #define AGT_PYR4_RING 8
 #endif
@@ -140,7 +147,7 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         else if constexpr (REV) vo = vbase + r * dpitch_lane;
         else so = r * pitch;
         if (r >= NR) vo = (int)0x80000000u;
-        const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, 0); d[slot] = __builtin_bit_cast(u32x4, t);
+        const v4u t = __builtin_amdgcn_raw_buffer_load_b128(rs, vo, so, AGT_PYR4_LOAD_AUX); d[slot] = __builtin_bit_cast(u32x4, t);
     };
     auto take = [&](int slot, int r, auto odd) {                 // horizontal sums of strip row r (in `slot`), then refill the slot
         if constexpr (COPY) {
@@ -172,11 +179,11 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
         const uint2 px = vgroup8b(a0, a1, a2, a3, a4);
         if constexpr (REV) {
             if (i >= i_lo && i < i_hi)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, a1_lane + __mul24(i, p1_lane), 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, a1_lane + __mul24(i, p1_lane), 0, AGT_PYR4_STORE_AUX);
         } else {
             const int y1 = y1a + i;
             if (writer && i >= 2 && i < 2 * oh2 + 2 && y1 < h1)
-                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, o1base, (i - 2) * pitch1, 0);
+                __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(agt_pyr3::v2u, px), r1, o1base, (i - 2) * pitch1, AGT_PYR4_STORE_AUX);
         }
         // neighbours' level-1 pixels: -2, -1 from the lane on the left, 8 from the lane on the right; the image's own edges
         // reflect level 1 (pixel -2 = 2, -1 = 1; pixel w1 = w1 - 2)
@@ -227,8 +234,8 @@ __device__ __forceinline__ void pyr_roll2_rows(const AgtPyrArgs& A0, const AgtPy
                 E4.x = b1 ? K2.x : (b2 ? up2.x : dn2.x); E4.y = b1 ? K2.y : (b2 ? up2.y : dn2.y);
             }
             const uint32_t o = vgroup4b(E0, E1, K2, E3, E4);
-            if constexpr (REV) { if (j >= j_lo && j < j_hi) __builtin_amdgcn_raw_buffer_store_b32(o, r2, a2_lane + __mul24(j, p2_lane), 0, 0); }
-            else if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, 0);
+            if constexpr (REV) { if (j >= j_lo && j < j_hi) __builtin_amdgcn_raw_buffer_store_b32(o, r2, a2_lane + __mul24(j, p2_lane), 0, AGT_PYR4_STORE_AUX); }
+            else if (writer && oy2 + j < h2) __builtin_amdgcn_raw_buffer_store_b32(o, r2, o2base, j * pitch2, AGT_PYR4_STORE_AUX);
             K0 = K2; K1 = K3; K2 = K4;
         }
     }

@@ -297,6 +297,31 @@ def test_lk_any_window_size_bit_exact(cvh, oracle, seq640, win):
         assert o[1].sum() >= 40, "the scene's corners are trackable with this window"
 
 
+@pytest.mark.parametrize("side", [15, 21, 31])
+def test_lk_general_body_equals_the_compiled_in_windows(torch_cuda, cvh, seq640, side):
+    """The windows with compiled-in bodies through the GENERAL body as well (agt_config::win = AGT_WIN_RECT(s, s) is not the plain side s and
+    takes the run-time-window kernel): two independent implementations of one algorithm, bitwise equal -- small batch (four waves per
+    corner for 21) and a batch big enough for the one-wave kernel with its row-segment body and level hand-over."""
+    torch = torch_cuda
+    a, b = seq640.frame(0), seq640.frame(1)
+    h, w = a.shape
+    rng = np.random.default_rng(side)
+    base = np.concatenate([seq640.corners(0), rng.uniform([-12, -12], [w + 12, h + 12], size=(16, 2)).astype(np.float32)])
+    n = base.shape[0]
+    for B in (1, 1100 // n + 1):
+        fa = torch.from_numpy(np.stack([a] * B)).cuda().contiguous(); fb = torch.from_numpy(np.stack([b] * B)).cuda().contiguous()
+        pg = torch.from_numpy(np.stack([base + 0.37 * q for q in range(B)]).astype(np.float32)).cuda().contiguous()
+        out = []
+        for win in (side, side | (side << 8)):
+            ctx = cvh.Context(w, h, max_level=2, win=win, max_points=n, max_streams=B)
+            ctx.pyramid_build(0, fa); ctx.pyramid_build(1, fb)
+            nx, st, er = ctx.lk_track(0, 1, pg, None)
+            out.append((nx.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()))
+        for x, y in zip(*out):
+            assert np.array_equal(x.view(np.uint8), y.view(np.uint8)), "window %d, batch %d" % (side, B)
+        assert out[0][1].sum() > 0.5 * B * 48
+
+
 def test_lk_window_out_of_range_is_refused(cvh):
     a = np.zeros((64, 64), np.uint8)
     p = np.array([[10.0, 10.0]], np.float32)

@@ -496,6 +496,42 @@ def test_batch64_720p_is_batch_invariant(torch_cuda, seq720):
     assert recs[(1, 4)][:, 0, 6].all()
 
 
+def test_split_pipeline_blocks_repeat_bitwise(torch_cuda, seq720):
+    """Round 6 (the short form of tools/soak.py, which ran 46,621 such blocks: profiles/r06_soak.txt): the 64-stream split pipeline is
+    deterministic -- 60 blocks of the same 39 steps from the same reset state give bitwise the same records, every stream the same as
+    stream 0, none flagged.  A table entry read before it was written, a stale pointer or a lost state update (the class of defect behind
+    round 5's aperture violation, which ALSO produced silently wrong poses once per ~1,000 launches) shows here as a differing block."""
+    torch = torch_cuda
+    from accurate_aprilgroup_tracking_amd import hiplib as H
+    from accurate_aprilgroup_tracking_amd.tracker import StreamTracker
+    s = seq720
+    B = 64
+    F = len(s)
+    frames = torch.from_numpy(s.frames()).cuda()
+    reps = [frames[k].unsqueeze(0).expand(B, -1, -1).contiguous() for k in range(F)]
+    order = (list(range(1, F)) + list(range(F - 2, -1, -1))) * 3 + list(range(1, F))
+    c0 = torch.from_numpy(np.repeat(s.corners(0)[None], B, 0)).cuda().contiguous()
+    trk = StreamTracker(s.width, s.height, s.obj, s.K, None, n_streams=B)
+    trk.pipeline(16)
+    so = trk.new_state_buffer(len(order))
+    ref = None
+    for blk in range(60):
+        so.zero_()
+        trk.reset(reps[0], c0)
+        for i, k in enumerate(order):
+            trk.step(reps[k], so[i])
+        trk.join()
+        assert trk.ctx.L.agt_synchronize(trk.ctx.h) == 0
+        r = so.cpu().numpy().view(np.uint64)
+        if ref is None:
+            ref = r.copy()
+            rec = so.cpu().numpy()
+            assert rec[:, :, H.ST_OK].all() and not ((rec[:, :, 11].astype(np.int64) & 512) != 0).any()
+            assert all(np.array_equal(ref[:, b], ref[:, 0]) for b in range(B))
+        else:
+            assert np.array_equal(r, ref), "block %d differs from block 0 in %d words" % (blk, int((r != ref).sum()))
+
+
 def test_mode_changes_between_runs(torch_cuda, seq640):
     """one context, several runs: 44-stream batch on the library's streams at depth 4, then (reset) a single stream on
     the fused step at depth 4, then the batch again -- ring sizes and moduli follow; every run equals a fresh tracker"""
