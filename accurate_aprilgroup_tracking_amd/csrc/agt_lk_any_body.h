@@ -130,10 +130,13 @@ __device__ __forceinline__ void lk_body_any(const AgtLkParams* P, int pt, int b,
         bilinear_weights(prevx - (float)ipx, prevy - (float)ipy, iw00, iw01, iw10, iw11);
 
         nextx -= halfx; nexty -= halfy;
-        int jx0 = agt_uniform((int)floorf(nextx)) - ANY_MARGIN, jy0 = agt_uniform((int)floorf(nexty)) - ANY_MARGIN;
+        const int inx0 = agt_uniform((int)floorf(nextx)), iny0 = agt_uniform((int)floorf(nexty));
+        int jx0 = inx0 - ANY_MARGIN, jy0 = iny0 - ANY_MARGIN;
         __syncthreads();                                       // the previous level's readers of every tile are done
         any_tile(sI, imgI, LI.w, LI.h, LI.pitch, ipx - 1, ipy - 1, G.ih, G.indw, tid);
-        any_tile(sJ, imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, G.jh, G.jndw, tid);
+        // (a search that starts outside the image -- a far initial flow -- ends at the first iteration's bounds test: no tile for it, and no
+        // reflection of coordinates a million pixels out)
+        if (!(inx0 < -ww || inx0 >= LJ.w || iny0 < -wh || iny0 >= LJ.h)) any_tile(sJ, imgJ, LJ.w, LJ.h, LJ.pitch, jx0, jy0, G.jh, G.jndw, tid);
         __syncthreads();
 
         // ---- Scharr from the I tile -> derivative tile (zero outside the image: the derivative image has a BORDER_CONSTANT border)

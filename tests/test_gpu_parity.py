@@ -207,7 +207,7 @@ def test_lk_wild_coordinates_are_lost_corners(cvh, oracle, seq640):
     pts = np.concatenate([good[:12], wild, good[12:]])
     ref = None
     for kw in (dict(maxLevel=2), dict(maxLevel=2, flags=8), dict(maxLevel=0), dict(maxLevel=3), dict(maxLevel=2, winSize=(15, 15)),
-               dict(maxLevel=2, winSize=(31, 31))):
+               dict(maxLevel=2, winSize=(31, 31)), dict(maxLevel=2, winSize=(13, 13)), dict(maxLevel=3, winSize=(11, 7))):
         o, g = _lk_both(cvh, oracle, a, b, pts, **kw)
         _assert_lk_equal(o, g)
         assert not g[1][12:12 + len(wild)].any() and not g[2][12:12 + len(wild)].any()
@@ -227,6 +227,13 @@ def test_lk_wild_coordinates_are_lost_corners(cvh, oracle, seq640):
     o, g = _lk_both(cvh, oracle, a, b, pts, maxLevel=2, flags=4, nextPts=init)
     _assert_lk_equal(o, g)
     assert not g[1][:4].any() and g[1].ravel()[4:12].all()
+    # a sane flow that points far outside the image (below the 2^20 guard): the search ends at its first bounds test, in every body
+    finit = good + 0.5
+    finit[0] = [9.0e5, 5.0]; finit[1] = [-8.0e5, -7.0e5]; finit[2] = [300.0, 1.0e6 - 3]
+    for ws in ((21, 21), (13, 13), (31, 31), (9, 17)):
+        o, g = _lk_both(cvh, oracle, a, b, good, maxLevel=2, flags=4, nextPts=finit, winSize=ws)
+        _assert_lk_equal(o, g)
+        assert not g[1][:3].any() and g[1].ravel()[3:].all()
 
 
 def test_lk_one_wave_border_levels_hand_over(cvh, oracle, seq720):
