@@ -55,8 +55,10 @@ while time.time() - t0 < SECONDS:
         t_print = time.time()
         print("  %6.0f s: %d blocks, %d differing, %d with unequal copies, %d flagged records" % (t_print - t0, n, bad_blocks, copies_bad, flagged), flush=True)
 dt = time.time() - t0
-launches = n * (K // 16 + 4)
-print("soak: %d blocks of %d steps x %d streams in %.0f s (%.1f M stream-frames, ~%d pose launches, ~%d LK launches): %d blocks differ from block 0, "
+fused = B * c0.shape[1] <= 256              # (agt_step_fits: the fused chained step; else the split pipeline)
+groups = n * (K // 16 + 4)                  # launch groups per block: 16 frames each, plus the fill / drain ramp
+what = ("~%d chained LK | PnP launches (fused step)" % groups) if fused else ("~%d group pose launches, ~%d per-frame LK launches (split pipeline)" % (groups, 2 * n * K))
+print("soak: %d blocks of %d steps x %d streams in %.0f s (%.1f M stream-frames, %s): %d blocks differ from block 0, "
       "%d blocks with unequal copies, %d flagged records, accepted %.4f"
-      % (n, K, B, dt, n * K * B / 1e6, launches, 2 * n * K, bad_blocks, copies_bad, flagged, ok0), flush=True)
+      % (n, K, B, dt, n * K * B / 1e6, what, bad_blocks, copies_bad, flagged, ok0), flush=True)
 sys.exit(1 if (bad_blocks or copies_bad or flagged) else 0)
