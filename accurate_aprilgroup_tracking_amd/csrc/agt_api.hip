@@ -360,6 +360,7 @@ int agt_create(const agt_config* cfg, void* hip_stream, agt_ctx** out)
     agt_ctx* c = new (std::nothrow) agt_ctx;
     if (!c) return AGT_ERR_ALLOC;
     memset(c, 0, sizeof(*c));
+    c->ms_pool_slot = -1;
     c->cfg = *cfg;
     c->chip = *chip;
     {   // first device of the process: remember it; a second one: from now on the launchers ask the runtime which device is current
@@ -424,7 +425,7 @@ int agt_destroy(agt_ctx* c)
         if (c->status[s]) (void)hipFree(c->status[s]);
         if (c->lk_iters[s]) (void)hipFree(c->lk_iters[s]);
     }
-    if (c->ms_ready) {
+    if (c->ms_pool_slot >= 0) {                      // (also after an ms_init that stopped half-way: the slot and the events it did create)
         for (int i = 0; i < 3; i++) (void)hipStreamSynchronize(c->ms_stream[i]);
         for (int k = 0; k < 5; k++) for (int i = 0; i < AGT_EV_SLOTS; i++) if (c->ms_ev[k][i]) (void)hipEventDestroy(c->ms_ev[k][i]);
         ms_pool_release(c->ms_pool_slot);            // (the streams go back to the process's pool: see ms_pool_acquire)
@@ -1439,15 +1440,21 @@ static int ms_pool_acquire(int device, hipStream_t out[3])
     // the LK launches are the long pole of a split-mode step and share the chip with the pyramid launches of the caller's stream, whose
     // short workgroups otherwise take every wave slot first: the library's streams get the highest priority
     MsPoolEntry e; e.device = device; e.busy = true;
+    // (a stream belongs to the device that is current when it is created: the context's, whatever the calling thread has selected)
+    int cur = device;
+    if (hipGetDevice(&cur) != hipSuccess) return -1;
+    if (cur != device && hipSetDevice(device) != hipSuccess) return -1;
     int pr_lo = 0, pr_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
-    for (int k = 0; k < 3; k++) {
+    bool ok = true;
+    for (int k = 0; k < 3 && ok; k++) {
         if (hipStreamCreateWithPriority(&e.s[k], hipStreamNonBlocking, pr_hi) != hipSuccess) {
             for (int q = 0; q < k; q++) (void)hipStreamDestroy(e.s[q]);
-            return -1;
-        }
-        out[k] = e.s[k];
+            ok = false;
+        } else out[k] = e.s[k];
     }
+    if (cur != device) (void)hipSetDevice(cur);
+    if (!ok) return -1;
     g_ms_pool.push_back(e);
     return (int)g_ms_pool.size() - 1;
 }
@@ -1460,11 +1467,11 @@ static void ms_pool_release(int slot)
 static int ms_init(agt_ctx* c)
 {
     if (c->ms_ready) return AGT_OK;
-    c->ms_pool_slot = ms_pool_acquire(c->cfg.device, c->ms_stream);
+    if (c->ms_pool_slot < 0) c->ms_pool_slot = ms_pool_acquire(c->cfg.device, c->ms_stream);        // (a retry after a failed event creation keeps its slot)
     if (c->ms_pool_slot < 0) return hip_fail(c, hipGetLastError());
     for (int k = 0; k < 5; k++)
         for (int i = 0; i < AGT_EV_SLOTS; i++)
-            if (hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) return hip_fail(c, hipGetLastError());
+            if (!c->ms_ev[k][i] && hipEventCreateWithFlags(&c->ms_ev[k][i], hipEventDisableTiming) != hipSuccess) { c->ms_ev[k][i] = nullptr; return hip_fail(c, hipGetLastError()); }
     c->ms_ready = 1;
     return AGT_OK;
 }
