@@ -38,7 +38,7 @@ SYMBOLS = [
     "agt_get_optimal_new_camera_matrix", "agt_undistort_init", "agt_undistort_maps", "agt_undistort_bgr",
     "agt_preprocess_bgr", "agt_dense_refine", "agt_tracker_dense", "agt_track_frame_dense", "agt_track_frames_dense", "agt_upload", "agt_download",
     "agt_tracker_tag_gate", "agt_track_frame_detected", "agt_track_host_frame", "agt_tracker_rewind",
-    "agt_device_info", "agt_xcd_tile_order", "agt_lk_occupancy", "agt_lk_occupancy_cu",
+    "agt_device_info", "agt_xcd_tile_order", "agt_lk_occupancy", "agt_lk_occupancy_cu", "agt_lk_lds_request",
     "agt_solve_pnp_host", "agt_project_points_host",
 ]
 
@@ -108,6 +108,7 @@ def lib():
     L.agt_xcd_tile_order.restype = i32
     L.agt_lk_occupancy.argtypes = [vp, i32]
     L.agt_lk_occupancy_cu.argtypes = [vp, i32]
+    L.agt_lk_lds_request.argtypes = [i32]
     L.agt_solve_pnp_host.argtypes = [vp, vp, vp, i32, i32, vp, vp, i32, vp, i32, vp, vp]
     L.agt_project_points_host.argtypes = [vp, vp, i32, i32, vp, vp, vp, i32, vp, vp]
     L.agt_tracker_buffers.argtypes = [vp, C.POINTER(vp), C.POINTER(vp)]

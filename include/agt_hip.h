@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-#define AGT_VERSION 504
+#define AGT_VERSION 505
 
 #define AGT_OK               0
 #define AGT_ERR_ARG         (-1)   /* NULL pointer / bad size / bad shape (cv2 would raise cv2.error) */
@@ -215,6 +215,11 @@ int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate
  * takes 45 instead of 36 us.  Results do not depend on it.  No reference counterpart (cv2 has no notion of co-tenancy).
  * agt_lk_occupancy: the same in waves per SIMD (4 x waves_per_simd per CU; ABI 500). */
 int agt_lk_occupancy_cu(agt_ctx* ctx, int workgroups_per_cu);
+/* The LDS a one-wave LK workgroup asks for under that cap (host function, no GPU needed; 0 = no cap, or a cap the 64-KB limit of a
+ * workgroup cannot express): workgroups_per_cu + 1 workgroups do not fit in a CU's 160 KB whatever the allocation granule ("at most"),
+ * workgroups_per_cu do for granules up to 512 bytes (one fewer at worst for 1,024 / 1,280; exactly as many at 8 and 10 per CU, the counts
+ * the library uses itself, for those too). */
+int agt_lk_lds_request(int workgroups_per_cu);
 int agt_lk_occupancy(agt_ctx* ctx, int waves_per_simd);
 /* corners_per_tag = 4: the pose solve of the tracker uses a corner only while all four corners of its tag (corners 4t..4t+3)
  * are usable, and min_points = 8 then means the reference's ">= 2 tags" (detect_pose.py:494-496; its detections are whole

@@ -27,7 +27,7 @@ def test_build_and_exports():
         assert hasattr(lib, s), "libagt_hip.so does not export %s" % s
     assert sorted(hiplib.SYMBOLS) == syms, "hiplib.SYMBOLS out of sync with include/agt_hip.h"
     lib.agt_version.restype = ctypes.c_int
-    assert lib.agt_version() == 504
+    assert lib.agt_version() == 505
     lib.agt_error_string.restype = ctypes.c_char_p
     assert lib.agt_error_string(-4) == b"bad point count"
     assert lib.agt_tracker_state_size() > 0

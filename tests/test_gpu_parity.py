@@ -28,7 +28,7 @@ def cvh(torch_cuda):
 
 def test_library_loaded():
     from accurate_aprilgroup_tracking_amd import hiplib
-    assert hiplib.lib().agt_version() == 504
+    assert hiplib.lib().agt_version() == 505
 
 
 # (round 4: widths that are multiples of 16 on aligned buffers take the register-rolling kernel, agt_pyramid3_body.h -- every level
