@@ -364,6 +364,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=40)
     ap.add_argument("--workload", default="c2", choices=sorted(WORKLOADS))
     ap.add_argument("--stream-lk-cu", type=int, default=-1, help="stream workloads (c2..c5): agt_lk_occupancy_cu of the tracker's context (experiment; -1 = the library's choice, 0 = none)")
+    ap.add_argument("--pnp-stream", action="store_true", help="c3pairs experiment: the pose solves of all batches on one more context / stream")
     ap.add_argument("--lk-cu", type=int, default=8, help="c3pairs: cap of the LK kernel's resident workgroups per CU in every context (agt_lk_occupancy_cu; 0 = none)")
     ap.add_argument("--no-pair-build", action="store_true", help="c3pairs: two agt_pyramid_build calls per batch (the form of rounds 3-5) instead of one agt_pyramid_build_pair")
     ap.add_argument("--pair-contexts", type=int, default=4, help="c3pairs: contexts / streams the independent batches are pipelined over (1 = serial)")

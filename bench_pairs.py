@@ -83,6 +83,16 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
     pitch, bstride = W, W * H
 
     PAIR_BUILD = not getattr(args, "no_pair_build", False)
+    # experiment (--pnp-stream): the pose solves of ALL batches on one more context / stream, ordered by events -- a batch's stream goes on to
+    # its next pair build right after the LK launch instead of sitting through a 64-wave solve
+    PNP_SIDE = bool(getattr(args, "pnp_stream", False)) and NCTX > 1
+    if PNP_SIDE:
+        s_pnp = torch.cuda.Stream()
+        with torch.cuda.stream(s_pnp):
+            ctx_pnp = cv_hip.Context(W, H, max_level=B_.LEVELS - 1, win=B_.WIN, max_points=npts, max_streams=B)
+        ev_lk = [torch.cuda.Event() for _ in range(NCTX)]
+        ev_pnp = [torch.cuda.Event() for _ in range(NCTX)]
+        pnp_pending = [False] * NCTX
 
     def step(j, pose_k, events=None, q=0):
         h, nx, st, info, sq_ = ctxs[q].h, nxs[q], sts[q], infos[q], streams[q]
@@ -97,8 +107,17 @@ def measure_pairs(args, torch, D, HL, wl, rank, world, dev, rehearsal):
             rec(1)
             HL.check(L.agt_pyramid_build(h, 1, vp(nxt[j]), pitch, bstride, B), "agt_pyramid_build")
         rec(2)
+        if PNP_SIDE and not events and pnp_pending[q]:
+            sq_.wait_event(ev_pnp[q])                      # the corner arrays of this context are read by its previous batch's solve
         HL.check(L.agt_lk_track(h, 0, 1, vp(pts_d[j]), vp(nx), vp(st), None, npts, B, 3, 30, 0.01, 0, 1e-4), "agt_lk_track")
         rec(3)
+        if PNP_SIDE and not events:
+            ev_lk[q].record(sq_)
+            s_pnp.wait_event(ev_lk[q])
+            HL.check(L.agt_solve_pnp(ctx_pnp.h, vp(obj_d), 0, vp(nx), HL.F32, vp(st), npts, B, Kp, None, 0, vp(pose_k), 1, vp(info), None), "agt_solve_pnp")
+            ev_pnp[q].record(s_pnp)
+            pnp_pending[q] = True
+            return
         # (pose_k holds the extrinsic guess of every pair of batch j on entry -- an input, put there before the timed region --
         # and the solved pose afterwards: agt_solve_pnp works in place, as cv2 does)
         HL.check(L.agt_solve_pnp(h, vp(obj_d), 0, vp(nx), HL.F32, vp(st), npts, B, Kp, None, 0, vp(pose_k), 1, vp(info), None), "agt_solve_pnp")
