@@ -20,6 +20,12 @@ template <int WIN, int NW, int NLEV, int OCC>
 __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(OCC))) AGT_LK_VGPR_ATTR void lk_kernel(const AgtLkParams P, const int total)
 {
     extern __shared__ __attribute__((aligned(16))) uint8_t lds[];
+#ifdef AGT_LK_TOUCH_VGPR     // experiment builds: a clobber of one high register raises the kernel's allocation (e.g. v135: 136 registers = at most
+                             // three of its waves on a SIMD, whatever the CU's LDS would allow)
+#define AGT_STR2(x) #x
+#define AGT_STR(x) AGT_STR2(x)
+    if (NW == 1) asm volatile("" ::: "v" AGT_STR(AGT_LK_TOUCH_VGPR));
+#endif
     const int cidx = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, P.xshift);
     if (cidx >= total) return;
     const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
