@@ -37,7 +37,8 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
     struct CornerLog {
         int c; unsigned long long t0;
         __device__ CornerLog(int c_) : c(c_), t0(__builtin_amdgcn_s_memtime()) {}
-        __device__ ~CornerLog() { if ((threadIdx.x & 63) == 0 && threadIdx.x == 0 && c < AGT_LK_CORNER_LOG) { agt_lk_corner_log[c][0] = t0; agt_lk_corner_log[c][1] = __builtin_amdgcn_s_memtime(); } }
+        __device__ ~CornerLog() { if ((threadIdx.x & 63) == 0 && threadIdx.x == 0 && c < AGT_LK_CORNER_LOG) { agt_lk_corner_log[c][0] = t0; agt_lk_corner_log[c][1] = __builtin_amdgcn_s_memtime();
+                                  agt_lk_corner_log[c][3] = (unsigned long long)__builtin_amdgcn_s_getreg(63492) | ((unsigned long long)__builtin_amdgcn_s_getreg(63508) << 32); } }      // HW_REG_HW_ID, HW_REG_XCC_ID
     } corner_log(cidx);
 #endif
     if constexpr (WIN == 21 && (NW == 1 || NW == 4)) {

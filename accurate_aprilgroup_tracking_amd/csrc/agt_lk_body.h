@@ -37,10 +37,10 @@ extern "C" int agt_debug_lk_stamps(unsigned long long* host64)
 // per-corner log of the stand-alone launch (tools/lkcorners.py): entry and exit time of every corner's wave(s) and the
 // iterations it took -- the launch lasts as long as its slowest corner
 #define AGT_LK_CORNER_LOG 8192
-__device__ unsigned long long agt_lk_corner_log[AGT_LK_CORNER_LOG][3];
+__device__ unsigned long long agt_lk_corner_log[AGT_LK_CORNER_LOG][4];        // entry time, exit time, iterations, HW_ID | XCC_ID << 32 (where the wave ran)
 extern "C" int agt_debug_lk_corner_log(unsigned long long* host, int n)
 {
-    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(agt_lk_corner_log), sizeof(unsigned long long) * 3 * (size_t)(n < AGT_LK_CORNER_LOG ? n : AGT_LK_CORNER_LOG));
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(agt_lk_corner_log), sizeof(unsigned long long) * 4 * (size_t)(n < AGT_LK_CORNER_LOG ? n : AGT_LK_CORNER_LOG));
 }
 #else
 #define STAMP(i)

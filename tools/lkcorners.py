@@ -19,8 +19,8 @@ L = hiplib.lib()
 n = B * 48
 for rep in range(3):
     ctx.lk_track(0, 1, pts, nx, want_err=False); torch.cuda.synchronize()
-    buf = (C.c_ulonglong * (3 * n))(); L.agt_debug_lk_corner_log(buf, n)
-    a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 3).astype(np.int64)
+    buf = (C.c_ulonglong * (4 * n))(); L.agt_debug_lk_corner_log(buf, n)
+    a = np.frombuffer(buf, dtype=np.uint64).reshape(n, 4).astype(np.int64)
     t0 = a[:, 0].min()
     start = (a[:, 0] - t0) / 2100.0; end = (a[:, 1] - t0) / 2100.0      # s_memtime counts shader cycles (~2.1 GHz under load; every XCD has its own base: only differences within a wave mean anything)
     life = end - start
@@ -36,3 +36,28 @@ for rep in range(3):
         if m.any(): print("      %3d..%3d iterations: %4d corners, life median %.1f max %.1f" % (lo, hi - 1, m.sum(), np.median(life[m]), life[m].max()))
     h, edges = np.histogram(life, bins=np.arange(0, life.max() + 2, 2.0))
     print("   life histogram (2-us bins from 0):", " ".join(str(int(v)) for v in h))
+    # where the waves ran (HW_ID: simd [5:4], cu [11:8], sh [12], se [15:13]; XCC_ID [3:0]): corners per SIMD, and a corner's life against the number of
+    # corners its SIMD got in this launch
+    hw = a[:, 3]
+    simd = (hw >> 4) & 3; cu = (hw >> 8) & 15; sh = (hw >> 12) & 1; se = (hw >> 13) & 7; xcc = (hw >> 32) & 15
+    key = (((xcc * 8 + se) * 2 + sh) * 16 + cu) * 4 + simd
+    uniq, inv, cnt = np.unique(key, return_inverse=True, return_counts=True)
+    print("   %d SIMDs used (%d CUs, %d XCCs); corners per SIMD:" % (len(uniq), len(np.unique(key >> 2)), len(np.unique(xcc))),
+          " ".join("%d:%d" % (k, int((cnt == k).sum())) for k in sorted(set(cnt.tolist()))))
+    for k in sorted(set(cnt.tolist())):
+        m = cnt[inv] == k
+        print("      corners on a SIMD that got %d: %4d corners, life median %.1f p90 %.1f max %.1f" % (k, int(m.sum()), np.median(life[m]), np.percentile(life[m], 90), life[m].max()))
+    percu = np.unique(key >> 2, return_counts=True)[1]
+    print("   corners per CU: min %d median %d max %d" % (percu.min(), int(np.median(percu)), percu.max()))
+    for x in sorted(set(xcc.tolist())):
+        m = xcc == x
+        print("      XCC %d: %4d corners, life median %.1f max %.1f" % (x, int(m.sum()), np.median(life[m]), life[m].max()))
+    # the three corners of a SIMD, ranked by life: does the SIMD's issue arbiter serve them in order?
+    if (cnt == 3).all():
+        order = np.argsort(key, kind="stable")
+        trip = np.sort(life[order].reshape(-1, 3), axis=1)
+        wave = ((hw >> 0) & 15)[order].reshape(-1, 3)
+        print("   per SIMD, lives ranked: shortest median %.1f, middle %.1f, longest %.1f us (sum %.1f); start spread within a SIMD median %.2f us"
+              % (np.median(trip[:, 0]), np.median(trip[:, 1]), np.median(trip[:, 2]), np.median(trip.sum(axis=1)),
+                 np.median(np.ptp(start[order].reshape(-1, 3), axis=1))))
+
