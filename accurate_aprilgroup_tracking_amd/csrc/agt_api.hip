@@ -632,6 +632,7 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 }
 
 #define AGT_SPLIT_LK_CU 10       // (see agt_lk_occupancy_cu)
+#define AGT_SPLIT_PYR_OH 6       // strip height (level-2 rows) of the split pipeline's pyramid role (agt_pyramid.hip agt_pyr2_plan)
 static int lk_lds_min(int per_cu);
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
@@ -654,9 +655,10 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     p.max_count = (crit_type & AGT_TERM_COUNT) ? (crit_max_count < 0 ? 0 : crit_max_count > 100 ? 100 : crit_max_count) : 30;
     double eps = (crit_type & AGT_TERM_EPS) ? (crit_eps < 0. ? 0. : crit_eps > 10. ? 10. : crit_eps) : 0.01;
     p.eps2 = eps * eps;
-    p.flags = flags;
+    p.flags = flags & 0xffff;            // (the bits above are internal launch flags)
     // (waves == 1: a half-batch launch of the split pipeline -- beside the other half's launch and the pyramid launch of the frames ahead)
     p.lds_min = lk_lds_min(c->lk_cap_cu >= 0 ? c->lk_cap_cu : (waves == 1 ? AGT_SPLIT_LK_CU : 0));
+    if (c->lk_cap_cu > 0) p.flags |= AGT_LK_FLAG_COTENANT;        // (declared by the caller: agt_lk_occupancy_cu; see agt_lk.hip lk_kernel)
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
     if (b0) {
@@ -1087,7 +1089,8 @@ static int launch_group(agt_ctx* c, int B, int fmax = 0)
             // (fused step: agt_step_fits, <= 256 corners in flight -- its kernel carries the tiled two-level pass only: plan as ONE frame, which
             // keeps the launch below the rolling form's 16 images.  Round 5: except the pyramid-only launch at the head of a run, which is
             // pyr_group_kernel -- 20 frames of 1280x720, the driver's block: 15.1 us tiled, see DESIGN.md section 6 for the rolling figure)
-            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (agt_step_fits(c->trk_n, B) && !pyr_only) ? 1 : (int)cnt);
+            agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (agt_step_fits(c->trk_n, B) && !pyr_only) ? 1 : (int)cnt,
+                          agt_step_fits(c->trk_n, B) ? 16 : AGT_SPLIT_PYR_OH);
             if (!fused && A0.pad != 0 && c->n_stage[1] == c->n_stage[0]) fused = true;       // big batch, rolling form, no backlog
             if (fused) {
                 A = A0; S.pyr[1] = A1;

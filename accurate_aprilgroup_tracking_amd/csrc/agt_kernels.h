@@ -43,6 +43,7 @@ struct AgtPyrArgs {
 
 #define AGT_MAX_GROUP 32         // frames one fused launch may advance each pipeline stage by (the per-frame tables are kernel arguments: 7.4 KB with the parameters)
 
+#define AGT_LK_FLAG_COTENANT 0x20000     // internal launch flag: the context declared co-tenancy (agt_lk_occupancy_cu): tracker waves at issue priority 1
 struct AgtLkParams {
     AgtLevel prev[AGT_MAX_LEVELS];
     AgtLevel next[AGT_MAX_LEVELS];
@@ -50,7 +51,7 @@ struct AgtLkParams {
     int n;                    // points per stream
     int max_count;            // criteria, already clamped
     double eps2;              // epsilon^2
-    int flags;
+    int flags;                // AGT_LK_* of the ABI in the low bits; internal: 0x10000 = general body for every corner (diagnostic), AGT_LK_FLAG_COTENANT
     double min_eig_threshold;
     const float* prev_pts;    // [B][n][2]
     const uint8_t* prev_status;   // [B][n] or null: tracker mode, a corner lost in an earlier frame stays lost (position carried)
@@ -203,7 +204,7 @@ void agt_pyr_grid(int dw, int dh, int* gx, int* gy);
 void agt_pyr_plan(AgtPyrArgs* A, uintptr_t src_align, uintptr_t dst_align, int frames);
 hipError_t agt_launch_pyr_upload2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, uint8_t* copy, long cpitch,
                                   uint8_t* dst1, long dpitch1, uint8_t* dst2, long dpitch2);     // fused upload + two-level pyramid of one frame (agt_pyramid.hip)
-void agt_pyr2_plan(AgtPyrArgs* A0, AgtPyrArgs* A1, uintptr_t src_align, uintptr_t dst_align, int frames);     // the same for the two-level pass      // tiled or register-rolling form of one pyrDown pass (agt_pyramid.hip)
+void agt_pyr2_plan(AgtPyrArgs* A0, AgtPyrArgs* A1, uintptr_t src_align, uintptr_t dst_align, int frames, int oh_cap = 16);     // the same for the two-level pass      // tiled or register-rolling form of one pyrDown pass (agt_pyramid.hip)
 void agt_pyr2_grid(int w2, int h2, int* gx, int* gy);           // tile grid of the two-level pass (64 x 16 tiles of L2)
 int agt_pyr2_lds_bytes(void);
 hipError_t agt_launch_pyr_down2(hipStream_t stream, const uint8_t* src, int sw, int sh, long spitch, long sbatch,

@@ -26,6 +26,11 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
 #define AGT_STR(x) AGT_STR2(x)
     if (NW == 1) asm volatile("" ::: "v" AGT_STR(AGT_LK_TOUCH_VGPR));
 #endif
+    // issue priority 1 for every tracker wave of a context that has DECLARED co-tenancy (agt_lk_occupancy_cu with a count: its launches share
+    // the device with other contexts' pyramid passes, agt_api.hip lk_track_on sets the internal flag): cold pairs 44.4-44.6 -> 43.3-43.4 us per
+    // step (priority 2: the same).  Not for the split pipeline's own launches: c3 37.3-37.6 -> 37.8-38.1 (profiles/r06_experiments.md 17)
+    const bool cotenant = NW == 1 && (P.flags & AGT_LK_FLAG_COTENANT) != 0;
+    if (cotenant) __builtin_amdgcn_s_setprio(1);
     const int cidx = agt_xcd_order((int)blockIdx.x, (int)gridDim.x, P.xshift);
     if (cidx >= total) return;
     const int bY = cidx / P.n, bX = cidx - bY * P.n;          // stream, corner
@@ -66,7 +71,7 @@ __global__ __launch_bounds__(AGT_WAVE * NW) __attribute__((amdgpu_waves_per_eu(O
             if (ost < 0) return;                           // (finished there: a wild initial flow)
             agt_lk::block_sync<NW>();                      // (the row-segment body reuses the LDS behind the tiles)
             top = fine - 1; cx = ox; cy = oy;
-            if (NW == 1) __builtin_amdgcn_s_setprio(0);
+            if (NW == 1) { if (cotenant) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0); }
         }
         agt_lk::lk_body_rs<NW, NLEV>(&P, bX, bY, lds, io, ppx, ppy, ox, oy, ost, top, cx, cy);
         return;

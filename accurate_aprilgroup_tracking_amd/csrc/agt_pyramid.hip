@@ -96,7 +96,7 @@ void agt_pyr2_args(const uint8_t* src, int sw, int sh, long spitch, long sbatch,
 // The register-rolling form of the two-level pass where it applies: A0.pad = level-2 rows per strip, A0.gx = workgroups per image,
 // A0.gy = 1 (A1 likewise); else the tiled form is left as agt_pyr2_args set it up (A0.pad = 0).  src_align / dst_align: OR of every
 // source / destination address of the launch (both destination levels); frames: images per stream in the launch.
-void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintptr_t dst_align, int frames)
+void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintptr_t dst_align, int frames, int oh_cap)
 {
     AgtPyrArgs& A0 = *pA0; AgtPyrArgs& A1 = *pA1;
     A0.pad = A1.pad = 0;
@@ -130,7 +130,13 @@ void agt_pyr2_plan(AgtPyrArgs* pA0, AgtPyrArgs* pA1, uintptr_t src_align, uintpt
     if (strips < 1) strips = 1;
     constexpr int Q = agt_pyr4::L2_PER_TRIP;
     int oh = (int)((A1.dh + strips - 1) / strips + Q - 1) / Q * Q;
-    oh = oh < Q ? Q : (oh > 16 ? 16 : oh);
+    // oh_cap (round 6): 16 for a launch of its own (agt_pyramid_build, agt_pyramid_build_pair: the pass IS the step's long pole there and
+    // every strip pays 9 halo rows of loads and arithmetic); AGT_SPLIT_PYR_OH = 6 (agt_api.hip) for the pyramid role of the split pipeline,
+    // whose launch of up to 1,024 images runs for hundreds of microseconds BESIDE the per-frame LK launches: 64 streams x 16 frames, us per
+    // step over four boxes 16: 36.7-37.6, 10: 36.0-36.2, 8: 35.7-36.3, 6: 35.1-35.9, 4: 35.4-36.3, 2: 40.6 (profiles/r06_experiments.md 17)
+    // -- short-lived pyramid waves give their slots back sooner
+    if (oh_cap < Q) oh_cap = Q;
+    oh = oh < Q ? Q : (oh > oh_cap ? oh_cap : oh);
 #ifdef AGT_DEBUG_KNOBS
     { static const int f = [] { const char* e = getenv("AGT_PYR4_OH"); return e ? atoi(e) : 0; }(); if (f > 0) oh = (f + Q - 1) / Q * Q; }
 #endif
