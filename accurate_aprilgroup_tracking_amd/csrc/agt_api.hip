@@ -659,6 +659,9 @@ static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_s
     // (waves == 1: a half-batch launch of the split pipeline -- beside the other half's launch and the pyramid launch of the frames ahead)
     p.lds_min = lk_lds_min(c->lk_cap_cu >= 0 ? c->lk_cap_cu : (waves == 1 ? AGT_SPLIT_LK_CU : 0));
     if (c->lk_cap_cu > 0) p.flags |= AGT_LK_FLAG_COTENANT;        // (declared by the caller: agt_lk_occupancy_cu; see agt_lk.hip lk_kernel)
+#ifdef AGT_DEBUG_KNOBS      // AGT_LK_COTENANT_PRIO=0: the cap without the issue priority (A/B of the two)
+    { static const int on = [] { const char* e = getenv("AGT_LK_COTENANT_PRIO"); return e ? atoi(e) : 1; }(); if (!on) p.flags &= ~AGT_LK_FLAG_COTENANT; }
+#endif
     p.min_eig_threshold = min_eig_threshold;
     p.prev_pts = d_prev_pts; p.prev_status = d_prev_status; p.next_pts = d_next_pts; p.status = d_status; p.err = d_err;
     if (b0) {

@@ -212,7 +212,8 @@ int agt_tracker_options(agt_ctx* ctx, int reproject, int min_points, double gate
  * share the device with other kernels (several batches software-pipelined over contexts / streams, bench.py --workload c3pairs): an
  * uncapped launch fills every SIMD with three trackers for as long as its slowest corner iterates and the HBM-bound pyramid passes
  * beside it starve; capped at 8 the cold-pair step of BASELINE configs[2] ran 48.4 -> 45.3 us (round 5) while the LK launch alone
- * takes 45 instead of 36 us.  Results do not depend on it.  No reference counterpart (cv2 has no notion of co-tenancy).
+ * takes 45 instead of 36 us.  A context that sets a count also runs its tracker waves at issue priority 1 (round 6: cold pairs 43.1 -> 42.3 us).
+ * Results do not depend on it.  No reference counterpart (cv2 has no notion of co-tenancy).
  * agt_lk_occupancy: the same in waves per SIMD (4 x waves_per_simd per CU; ABI 500). */
 int agt_lk_occupancy_cu(agt_ctx* ctx, int workgroups_per_cu);
 /* The LDS a one-wave LK workgroup asks for under that cap (host function, no GPU needed; 0 = no cap, or a cap the 64-KB limit of a
