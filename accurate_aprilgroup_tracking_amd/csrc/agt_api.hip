@@ -1451,6 +1451,9 @@ static int ms_pool_acquire(int device, hipStream_t out[3])
     if (cur != device && hipSetDevice(device) != hipSuccess) return -1;
     int pr_lo = 0, pr_hi = 0;
     (void)hipDeviceGetStreamPriorityRange(&pr_lo, &pr_hi);
+#ifdef AGT_DEBUG_KNOBS      // AGT_MS_PRIO=low|mid: the library's streams at the lowest / the default priority instead of the highest (A/B)
+    { const char* e = getenv("AGT_MS_PRIO"); if (e && e[0] == 'l') pr_hi = pr_lo; else if (e && e[0] == 'm') pr_hi = 0; }
+#endif
     bool ok = true;
     for (int k = 0; k < 3 && ok; k++) {
         if (hipStreamCreateWithPriority(&e.s[k], hipStreamNonBlocking, pr_hi) != hipSuccess) {
