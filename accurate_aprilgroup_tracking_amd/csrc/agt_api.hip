@@ -632,7 +632,9 @@ static void fill_levels(const agt_ctx* c, int slot, AgtLevel* L)
 }
 
 #define AGT_SPLIT_LK_CU 10       // (see agt_lk_occupancy_cu)
-#define AGT_SPLIT_PYR_OH 6       // strip height (level-2 rows) of the split pipeline's pyramid role (agt_pyramid.hip agt_pyr2_plan)
+#define AGT_SPLIT_PYR_OH 6       // strip height (level-2 rows) of the split pipeline's pyramid role (agt_pyramid.hip agt_pyr2_plan) ...
+#define AGT_SPLIT_PYR_OH_B0 12   // ... for batches of 12 .. 96 streams: measured (session r6ar, us per step, strips of 6 / 16) 8 streams 20.1 / 19.8,
+#define AGT_SPLIT_PYR_OH_B1 96   // 16: 27.5 / 28.3, 32: 29.4 / 29.9, 64: 35.1-35.9 / 36.7-37.6, 128: 63.7 / 62.4
 static int lk_lds_min(int per_cu);
 static int lk_track_on(agt_ctx* c, hipStream_t stream, int prev_slot, int next_slot,
                        const float* d_prev_pts, const uint8_t* d_prev_status, float* d_next_pts, uint8_t* d_status, float* d_err,
@@ -1093,7 +1095,7 @@ static int launch_group(agt_ctx* c, int B, int fmax = 0)
             // keeps the launch below the rolling form's 16 images.  Round 5: except the pyramid-only launch at the head of a run, which is
             // pyr_group_kernel -- 20 frames of 1280x720, the driver's block: 15.1 us tiled, see DESIGN.md section 6 for the rolling figure)
             agt_pyr2_plan(&A0, &A1, src_align, dst_align | d2_align, (agt_step_fits(c->trk_n, B) && !pyr_only) ? 1 : (int)cnt,
-                          agt_step_fits(c->trk_n, B) ? 16 : AGT_SPLIT_PYR_OH);
+                          (agt_step_fits(c->trk_n, B) || B < AGT_SPLIT_PYR_OH_B0 || B > AGT_SPLIT_PYR_OH_B1) ? 16 : AGT_SPLIT_PYR_OH);
             if (!fused && A0.pad != 0 && c->n_stage[1] == c->n_stage[0]) fused = true;       // big batch, rolling form, no backlog
             if (fused) {
                 A = A0; S.pyr[1] = A1;
